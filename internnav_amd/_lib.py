@@ -1,0 +1,90 @@
+"""ctypes binding of libinternnav_amd.so (C-ABI declared in include/internnav_amd.h).
+
+The library is the product path: there is no Python/PyTorch fallback. `lib()` raises if the shared object has
+not been built (`python -m internnav_amd.build`), and every op raises RuntimeError with ina_last_error() on failure.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libinternnav_amd.so"
+
+c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p),
+        ("bias", c_void_p), ("colscale", c_void_p), ("rowscale", c_void_p), ("R", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldw", c_int32), ("ldc", c_int32), ("ldr", c_int32),
+        ("act", c_int32), ("out_dtype", c_int32), ("res_dtype", c_int32), ("glu", c_int32),
+        ("rowscale_div", c_int32), ("batch", c_int32),
+        ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
+        ("force_cfg", c_int32), ("_pad", c_int32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", c_void_p), ("K", c_void_p), ("V", c_void_p), ("O", c_void_p),
+        ("q_bs", c_int64), ("q_rs", c_int64), ("q_hs", c_int64),
+        ("k_bs", c_int64), ("k_rs", c_int64), ("k_hs", c_int64),
+        ("v_bs", c_int64), ("v_rs", c_int64), ("v_hs", c_int64),
+        ("o_bs", c_int64), ("o_rs", c_int64), ("o_hs", c_int64),
+        ("B", c_int32), ("H", c_int32), ("Hkv", c_int32),
+        ("Lq", c_int32), ("Lk", c_int32), ("D", c_int32),
+        ("causal", c_int32), ("kv_start", c_int32), ("kv_bdiv", c_int32),
+        ("scale", c_float),
+        ("cu_q", c_void_p), ("cu_k", c_void_p), ("head_gate", c_void_p),
+        ("accumulate", c_int32), ("_pad", c_int32),
+    ]
+
+
+class NormArgs(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("R", c_void_p), ("Y", c_void_p), ("S", c_void_p),
+        ("gamma", c_void_p), ("beta", c_void_p), ("mod_scale", c_void_p), ("gate", c_void_p), ("G", c_void_p),
+        ("rows", c_int32), ("C", c_int32),
+        ("ldx", c_int32), ("ldr", c_int32), ("ldy", c_int32), ("ldg", c_int32),
+        ("mod_div", c_int32), ("mod_ld", c_int32),
+        ("rms", c_int32), ("eps", c_float),
+    ]
+
+
+# every symbol include/internnav_amd.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ina_abi_version": (C.c_int, []),
+    "ina_last_error": (C.c_char_p, []),
+    "ina_device_check": (C.c_int, [C.c_char_p, C.c_int]),
+    "ina_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "ina_attention_bf16": (C.c_int, [C.POINTER(AttnArgs), c_void_p]),
+    "ina_norm_bf16": (C.c_int, [C.POINTER(NormArgs), c_void_p]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once). Fails loudly when it is missing: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m internnav_amd.build` "
+                "(or __graft_entry__.build()). internnav_amd has no CPU/PyTorch fallback."
+            )
+        h = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)  # AttributeError if the .so is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ina_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"internnav_amd.{what} failed (rc={rc}): {msg}")

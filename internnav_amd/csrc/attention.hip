@@ -1,0 +1,219 @@
+// Flash-style attention forward for gfx950 (bf16 in/out, fp32 softmax + accumulation).
+// Replaces flash-attn 2 / xformers / nn.MultiheadAttention SDPA on the reference hot path:
+//   DINOv2 ViT-S (6 h x d64, 257 tokens), NavDP former/decoder (8 h x d48, causal T=24/32, cross M=34/132/2304),
+//   NextDiT (6 h x d64, T=32 / 36), Qwen2.5-VL ViT windows (16 h x d80, varlen) and LLM prefill (GQA 28q/4kv x d128, causal).
+//
+// One workgroup = NW waves = NW*16 query rows of one (sequence, head); K/V are streamed in KVB-row blocks through LDS
+// and shared by the NW waves. Both MFMAs are issued in the "swapped" form so that lane l always owns query row (l & 15)
+// and lane group g = l >> 4 owns a fixed subset of the keys of the current block:
+//   S^T[kv][q] = K . Q^T   (A operand = K fragment, B operand = Q fragment)  -> lane holds S[q][kv = t*16 + g*4 + r]
+//   O^T[d][q]  = V^T . P^T (A operand = V^T fragment, B operand = P fragment) -> lane holds O[q][d = nt*16 + g*4 + r]
+// P therefore never leaves its lane: the 8 probabilities a lane computed for a 32-key sub-block are exactly its PV B-operand,
+// provided V^T is laid out in LDS with the matching key permutation pos(kv) (see vt_pos below). Softmax statistics are
+// reduced across the 4 lane groups with two xor-shuffles.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int vt_pos(int kv_local) {
+    // key permutation inside each 32-key sub-block: MFMA k index g*8 + j  <->  key (j<4 ? g*4+j : 16+g*4+(j-4))
+    int sub = kv_local >> 5, w = kv_local & 31;
+    int t = w >> 4, x = w & 15;
+    return (sub << 5) + ((x >> 2) << 3) + (x & 3) + (t << 2);
+}
+
+template <int DP, int DV, int NW, int KVB>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int NT = NW * 64;
+    constexpr int KS_LD = DP + 8;
+    constexpr int VT_LD = KVB + 8;
+    constexpr int KCPR = DP / 8;        // 16B chunks per K row (padded width)
+    constexpr int VCPR = DV / 8;
+    constexpr int NKK = DP / 32;
+    constexpr int NST = KVB / 16;       // S tiles per block
+    constexpr int NSB = KVB / 32;       // 32-key sub-blocks per block
+    constexpr int NDT = DV / 16;        // output d tiles
+    __shared__ __attribute__((aligned(16))) bf16 Ks[KVB * KS_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Vt[DV * VT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, lq = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kb = b / p.kv_bdiv;
+    const int kh = h / (p.H / p.Hkv);
+
+    int q_off = 0, k_off = 0, len_q = p.Lq, len_k = p.Lk;
+    if (p.cu_q) { q_off = p.cu_q[b]; len_q = p.cu_q[b + 1] - q_off; }
+    if (p.cu_k) { k_off = p.cu_k[kb]; len_k = p.cu_k[kb + 1] - k_off; }
+    const int qt0 = blockIdx.x * (NW * 16);
+    if (qt0 >= len_q) return;
+
+    const bf16* __restrict__ Q = reinterpret_cast<const bf16*>(p.Q) + (size_t)b * p.q_bs + (size_t)q_off * p.q_rs + (size_t)h * p.q_hs;
+    const bf16* __restrict__ K = reinterpret_cast<const bf16*>(p.K) + (size_t)kb * p.k_bs + (size_t)k_off * p.k_rs + (size_t)kh * p.k_hs;
+    const bf16* __restrict__ V = reinterpret_cast<const bf16*>(p.V) + (size_t)kb * p.v_bs + (size_t)k_off * p.v_rs + (size_t)kh * p.v_hs;
+    bf16* __restrict__ O = reinterpret_cast<bf16*>(p.O) + (size_t)b * p.o_bs + (size_t)q_off * p.o_rs + (size_t)h * p.o_hs;
+
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int q_abs = qt0 + wave * 16 + lq;
+    bf16x8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        int d = kk * 32 + g * 8;
+        qf[kk] = (q_abs < len_q && d < p.D) ? *reinterpret_cast<const bf16x8*>(Q + (size_t)q_abs * p.q_rs + d) : zero8;
+    }
+
+    f32x4 acc_o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) acc_o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;  // exp2 domain
+    const int causal_shift = len_k - len_q;
+
+    int kv_end = len_k;
+    if (p.causal) {
+        int last_q = min(qt0 + NW * 16, len_q) - 1;
+        kv_end = min(len_k, last_q + causal_shift + 1);
+    }
+    const int kv_begin = (p.kv_start / KVB) * KVB;
+
+    for (int kv0 = kv_begin; kv0 < kv_end; kv0 += KVB) {
+        __syncthreads();
+        // ---- stage K block (row-major, zero padded) and V block (transposed + permuted) into LDS
+        for (int q = tid; q < KVB * KCPR; q += NT) {
+            int row = q / KCPR, c = q % KCPR;
+            int kv = kv0 + row;
+            bf16x8 v = (kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
+            *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = v;
+        }
+        for (int q = tid; q < KVB * VCPR; q += NT) {
+            int row = q / VCPR, c = q % VCPR;
+            int kv = kv0 + row;
+            bf16x8 v = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
+            int pos = vt_pos(row);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + pos] = v[i];
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T
+        f32x4 s[NST];
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(t * 16 + lq) * KS_LD + kk * 32 + g * 8]);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (lane owns query q_abs, keys kv0 + t*16 + g*4 + r)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int kv = kv0 + t * 16 + g * 4 + r;
+                bool ok = (kv < len_k) && (kv >= p.kv_start) && (!p.causal || kv <= q_abs + causal_shift);
+                float v = ok ? s[t][r] * sc : -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = exp2f(s[t][r] - m_use);
+                s[t][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[i][r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (bf16)s[2 * sb][r];
+                pf[4 + r] = (bf16)s[2 * sb + 1][r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NDT; ++nt) {
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + sb * 32 + g * 8]);
+                acc_o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc_o[nt], 0, 0, 0);
+            }
+        }
+    }
+
+    if (q_abs >= len_q) return;
+    const float inv_l = (l_run > 0.f) ? 1.0f / l_run : 0.f;
+    float gate = 1.0f;
+    if (p.head_gate) gate = tanhf(p.head_gate[h]);
+#pragma unroll
+    for (int nt = 0; nt < NDT; ++nt) {
+        int d = nt * 16 + g * 4;
+        if (d >= p.D) continue;
+        bf16* op = O + (size_t)q_abs * p.o_rs + d;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc_o[nt][r] * inv_l * gate;
+        if (p.accumulate) {
+            bf16x4 old = *reinterpret_cast<const bf16x4*>(op);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)old[r];
+        }
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(op) = o;
+    }
+}
+
+template <int DP, int DV>
+int launch_d(const AttnArgs& p, hipStream_t stream) {
+    // short query sequences: fewer waves per workgroup; short key sequences: 32-key blocks
+    const bool small_k = p.Lk <= 48;
+    int nw = (p.Lq <= 16) ? 1 : (p.Lq <= 32 ? 2 : 4);
+    dim3 grid((p.Lq + nw * 16 - 1) / (nw * 16), p.H, p.B);
+#define INA_ATTN_LAUNCH(NW_, KVB_) \
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, DV, NW_, KVB_>), grid, dim3(NW_ * 64), 0, stream, p)
+    if (nw == 1) { if (small_k) INA_ATTN_LAUNCH(1, 32); else INA_ATTN_LAUNCH(1, 64); }
+    else if (nw == 2) { if (small_k) INA_ATTN_LAUNCH(2, 32); else INA_ATTN_LAUNCH(2, 64); }
+    else { if (small_k) INA_ATTN_LAUNCH(4, 32); else INA_ATTN_LAUNCH(4, 64); }
+#undef INA_ATTN_LAUNCH
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int ina_launch_attention(const AttnArgs& p_in, hipStream_t stream) {
+    AttnArgs p = p_in;
+    if (p.kv_bdiv <= 0) p.kv_bdiv = 1;
+    INA_REQUIRE(p.B > 0 && p.H > 0 && p.Hkv > 0 && p.H % p.Hkv == 0, "attention: bad B/H/Hkv (%d,%d,%d)", p.B, p.H, p.Hkv);
+    INA_REQUIRE(p.Lq > 0 && p.Lk > 0, "attention: empty sequence Lq=%d Lk=%d", p.Lq, p.Lk);
+    INA_REQUIRE(p.q_rs % 8 == 0 && p.k_rs % 8 == 0 && p.v_rs % 8 == 0 && p.o_rs % 4 == 0 && p.q_hs % 8 == 0 && p.k_hs % 8 == 0 &&
+                    p.v_hs % 8 == 0 && p.o_hs % 4 == 0 && p.q_bs % 8 == 0 && p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 4 == 0,
+                "attention: strides must keep 16-byte row alignment");
+    INA_REQUIRE(((uintptr_t)p.Q % 16) == 0 && ((uintptr_t)p.K % 16) == 0 && ((uintptr_t)p.V % 16) == 0 && ((uintptr_t)p.O % 8) == 0,
+                "attention: misaligned pointer");
+    switch (p.D) {
+        case 48: return launch_d<64, 48>(p, stream);
+        case 64: return launch_d<64, 64>(p, stream);
+        case 80: return launch_d<96, 80>(p, stream);
+        case 128: return launch_d<128, 128>(p, stream);
+        default: ina_set_error("attention: unsupported head dim %d (48/64/80/128)", p.D); return -2;
+    }
+}

@@ -1,0 +1,85 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of internnav_amd.
+// Wave = 64 lanes everywhere in this tree; MFMA tiles are 16x16x32 bf16 -> f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define INA_WAVE 64
+
+// activation codes shared by the GEMM epilogue and the C-ABI (include/internnav_amd.h)
+enum : int {
+    INA_ACT_NONE = 0,
+    INA_ACT_GELU_ERF = 1,   // nn.GELU() default (DINOv2 Mlp, NavDP decoder 'gelu')
+    INA_ACT_GELU_TANH = 2,  // nn.GELU(approximate="tanh") (cond_projector, caption_projection)
+    INA_ACT_RELU = 3,       // nn.TransformerDecoderLayer default FFN, vlm_embed_mlp
+    INA_ACT_SILU = 4,       // timestep embedder, adaLN SiLU
+};
+
+enum : int { INA_DT_BF16 = 0, INA_DT_F32 = 1 };
+
+__device__ __forceinline__ float ina_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float ina_gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float ina_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float ina_act(float v, int act) {
+    switch (act) {
+        case INA_ACT_GELU_ERF: return ina_gelu_erf(v);
+        case INA_ACT_GELU_TANH: return ina_gelu_tanh(v);
+        case INA_ACT_RELU: return v > 0.f ? v : 0.f;
+        case INA_ACT_SILU: return ina_silu(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware remap of a 1-D workgroup id: MI355X dispatches block b to XCD b % 8, each XCD has a
+// private 4 MiB L2. Give every XCD one contiguous chunk of the logical tile order so neighbouring
+// tiles (which share operand panels) hit the same L2. Bijective for any nwg (guide §5, T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    if (nwg < NX * 2) return bid;
+    int xcd = bid % NX, idx = bid / NX;
+    int q = nwg / NX, r = nwg % NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define INA_HIP_CHECK(expr)                                                          \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            ina_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -1;                                                               \
+        }                                                                            \
+    } while (0)
+
+#define INA_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            ina_set_error(__VA_ARGS__);        \
+            return -2;                         \
+        }                                      \
+    } while (0)
+
+void ina_set_error(const char* fmt, ...);

@@ -1,0 +1,251 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue( A[M,K] . W[N,K]^T )
+//
+// A is the activation matrix (row-major, K contiguous), W is an nn.Linear weight exactly as PyTorch stores
+// it ([out_features, in_features], K contiguous) - both operands are therefore K-contiguous and their MFMA
+// fragments are plain 16-byte LDS reads.  Replaces every cuBLAS nn.Linear on the reference hot path
+// (SURVEY.md 2c "cuBLAS GEMMs (all nn.Linear)").
+//
+// Structure: 128x128 (or 64x128 / 128x64 / 64x64) output tile per 256-thread workgroup, BK = 64, two LDS
+// stages, register-staged global->LDS copies (tile t+1 is in flight in VGPRs while tile t is multiplied),
+// LDS rows padded by 16 B so the ds_read_b128 fragment reads are bank-conflict free.
+// The MFMA is issued "swapped" (W fragment as the A operand, activation fragment as the B operand) so each
+// lane ends up holding 4 consecutive output columns of one output row -> 8-byte bf16 / 16-byte f32 stores.
+//
+// Epilogue (fused, fp32): +bias[n] -> activation -> *colscale[n] (LayerScale) -> *rowscale[m] -> +residual[m,n]
+// -> store bf16 or f32.  Optional GLU mode pairs neighbouring 16-column blocks (gate,up) and writes
+// act(gate)*up to N/2 columns (Qwen SwiGLU, LuminaFeedForward).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int BM, int BN, int BK, int WM, int WN>
+struct GemmCfg {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int TM = BM / WM;  // wave tile rows
+    static constexpr int TN = BN / WN;
+    static constexpr int FM = TM / 16;
+    static constexpr int FN = TN / 16;
+    static constexpr int LDS_K = BK + 8;  // padded row (bf16 elements)
+    static constexpr int CPR = BK / 8;    // 16-byte chunks per tile row
+    static constexpr int A_CHUNKS = BM * CPR / NT;
+    static constexpr int B_CHUNKS = BN * CPR / NT;
+    static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * LDS_K * sizeof(bf16);
+};
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
+    using C = GemmCfg<BM, BN, BK, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* As = reinterpret_cast<bf16*>(smem_raw);                  // [2][BM][LDS_K]
+    bf16* Bs = As + 2 * BM * C::LDS_K;                             // [2][BN][LDS_K]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int nwg = tiles_m * tiles_n;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int tm = id / tiles_n, tn = id % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (size_t)blockIdx.y * p.strideA;
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (size_t)blockIdx.y * p.strideW;
+
+    bf16x8 ra[C::A_CHUNKS], rb[C::B_CHUNKS];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < C::A_CHUNKS; ++i) {
+            int q = tid + i * C::NT;
+            int row = q / C::CPR, c = q % C::CPR;
+            int gm = m0 + row, gk = k0 + c * 8;
+            ra[i] = (gm < p.M && gk < p.K) ? *reinterpret_cast<const bf16x8*>(A + (size_t)gm * p.lda + gk) : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_CHUNKS; ++i) {
+            int q = tid + i * C::NT;
+            int row = q / C::CPR, c = q % C::CPR;
+            int gn = n0 + row, gk = k0 + c * 8;
+            rb[i] = (gn < p.N && gk < p.K) ? *reinterpret_cast<const bf16x8*>(W + (size_t)gn * p.ldw + gk) : zero8;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        bf16* as = As + buf * BM * C::LDS_K;
+        bf16* bs = Bs + buf * BN * C::LDS_K;
+#pragma unroll
+        for (int i = 0; i < C::A_CHUNKS; ++i) {
+            int q = tid + i * C::NT;
+            int row = q / C::CPR, c = q % C::CPR;
+            *reinterpret_cast<bf16x8*>(as + row * C::LDS_K + c * 8) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_CHUNKS; ++i) {
+            int q = tid + i * C::NT;
+            int row = q / C::CPR, c = q % C::CPR;
+            *reinterpret_cast<bf16x8*>(bs + row * C::LDS_K + c * 8) = rb[i];
+        }
+    };
+
+    f32x4 acc[C::FM][C::FN];
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int frow = lane & 15;        // row inside a 16-row fragment
+    const int fk = (lane >> 4) * 8;    // k offset of this lane's 8 contiguous elements
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nk) load_tiles((t + 1) * BK);
+        const bf16* as = As + buf * BM * C::LDS_K + (wm * C::TM + frow) * C::LDS_K + fk;
+        const bf16* bs = Bs + buf * BN * C::LDS_K + (wn * C::TN + frow) * C::LDS_K + fk;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 fa[C::FM], fb[C::FN];
+#pragma unroll
+            for (int i = 0; i < C::FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(as + i * 16 * C::LDS_K + kk * 32);
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 16 * C::LDS_K + kk * 32);
+#pragma unroll
+            for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::FN; ++j)
+                    // swapped operands: D[row = n_local][col = m_local]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds rows m = ..+ (lane&15), columns n = ..+ (lane>>4)*4 + {0..3}
+    const int out_bf16 = (p.out_dtype == INA_DT_BF16);
+    const float* __restrict__ bias = p.bias;
+    const float* __restrict__ colscale = p.colscale;
+    const float* __restrict__ rowscale = p.rowscale;
+    const size_t cbatch = (size_t)blockIdx.y * p.strideC;
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i) {
+        const int m = m0 + wm * C::TM + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const float rs = rowscale ? rowscale[m / p.rowscale_div] : 1.0f;
+        if (!p.glu) {
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) {
+                const int n = n0 + wn * C::TN + j * 16 + (lane >> 4) * 4;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r];
+                    if (bias) x += bias[n + r];
+                    x = ina_act(x, p.act);
+                    if (colscale) x *= colscale[n + r];
+                    v[r] = x * rs;
+                }
+                if (p.R) {
+                    const size_t ro = (size_t)blockIdx.y * p.strideR + (size_t)m * p.ldr + n;
+                    if (p.res_dtype == INA_DT_BF16) {
+                        bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.R) + ro);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                    } else {
+                        f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    }
+                }
+                const size_t co = cbatch + (size_t)m * p.ldc + n;
+                if (out_bf16) {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = o;
+                }
+            }
+        } else {
+            // GLU: W rows are interleaved in 16-row blocks [gate16 | up16]; output column block = pair index
+#pragma unroll
+            for (int j = 0; j < C::FN; j += 2) {
+                const int n = n0 + wn * C::TN + j * 16 + (lane >> 4) * 4;  // gate column in interleaved space
+                if (n >= p.N) continue;
+                const int no = ((n0 + wn * C::TN + j * 16) >> 1) + (lane >> 4) * 4;  // output column
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float g = acc[i][j][r], u = acc[i][j + 1][r];
+                    if (bias) { g += bias[n + r]; u += bias[n + 16 + r]; }
+                    v[r] = ina_act(g, p.act) * u * rs;
+                }
+                const size_t co = cbatch + (size_t)m * p.ldc + no;
+                if (out_bf16) {
+                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = o;
+                } else {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_cfg(const GemmArgs& p, hipStream_t stream) {
+    using C = GemmCfg<BM, BN, BK, WM, WN>;
+    static bool attr_done = false;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, BK, WM, WN>;
+    if (!attr_done) {
+        INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)C::LDS_BYTES));
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    dim3 grid(tiles, p.batch, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, stream, p);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
+    GemmArgs p = p_in;
+    if (p.rowscale_div <= 0) p.rowscale_div = 1;
+    if (p.batch <= 0) p.batch = 1;
+    INA_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    INA_REQUIRE(p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0, "gemm: K/lda/ldw must be multiples of 8 (K=%d lda=%d ldw=%d)",
+                p.K, p.lda, p.ldw);
+    INA_REQUIRE(p.N % 4 == 0 && p.ldc % 4 == 0, "gemm: N/ldc must be multiples of 4 (N=%d ldc=%d)", p.N, p.ldc);
+    INA_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W % 16) == 0 && ((uintptr_t)p.C % 8) == 0, "gemm: misaligned pointer");
+    INA_REQUIRE(!p.R || p.ldr % 4 == 0, "gemm: ldr must be a multiple of 4");
+    INA_REQUIRE(!p.glu || (p.N % 32 == 0), "gemm: GLU mode needs N %% 32 == 0");
+    // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
+    int cfg = p.force_cfg;
+    if (cfg <= 0) {
+        if (p.M <= 64) cfg = (p.N >= 128) ? 3 : 4;
+        else if (t128 >= 256 || (p.M >= 128 && p.N >= 128 && t128 >= 96)) cfg = 1;
+        else if (p.N <= 64) cfg = 5;
+        else cfg = 2;
+    }
+    switch (cfg) {
+        case 1: return launch_cfg<128, 128, 64, 2, 2>(p, stream);
+        case 2: return launch_cfg<64, 128, 64, 2, 2>(p, stream);   // wave tile 32x64
+        case 3: return launch_cfg<64, 128, 64, 1, 4>(p, stream);   // wave tile 64x32 (skinny M)
+        case 4: return launch_cfg<64, 64, 64, 2, 2>(p, stream);    // wave tile 32x32
+        case 5: return launch_cfg<128, 64, 64, 2, 2>(p, stream);   // wave tile 64x32 (narrow N)
+        default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
+    }
+}

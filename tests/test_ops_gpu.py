@@ -1,0 +1,252 @@
+"""GPU numerics of the op-level kernels against a plain PyTorch fp32 reference of the same op (same bf16 inputs).
+
+Tolerances: outputs are bf16 (8 mantissa bits): |err| <= 2^-8 * |ref| + small abs slack from fp32 accumulation order.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand(shape, gen, scale=1.0, dtype=torch.bfloat16):
+    return (torch.randn(shape, generator=gen, dtype=torch.float32) * scale).to(dtype).to(_dev())
+
+
+def _close(out, ref, rtol=1.0 / 128, atol=2e-2):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    err = (out - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = (err > bound).sum().item()
+    assert bad == 0, f"{bad}/{err.numel()} elements out of tolerance, max err {err.max().item():.4g}, ref max {ref.abs().max().item():.4g}"
+
+
+@pytest.fixture(scope="module")
+def ops(built_lib):
+    from internnav_amd import _lib, ops
+
+    name = (b" " * 64)
+    import ctypes
+
+    buf = ctypes.create_string_buffer(64)
+    _lib.check(_lib.lib().ina_device_check(buf, 64), "device_check")
+    return ops
+
+
+GEMM_SHAPES = [
+    # M, N, K  (hot-path shapes: ViT-S qkv/proj/mlp, NavDP decoder, DiT, Qwen ViT/LLM slices, ragged edges)
+    (257 * 3, 1152, 384), (257 * 3, 384, 1536), (768, 1536, 384), (100, 384, 384), (1, 384, 384),
+    (24 * 64, 1152, 384), (4096, 3840, 1280), (1000, 1280, 3424), (920, 4608, 3584), (64, 3584, 3584),
+    (130, 132, 72), (513, 68, 200), (256, 384, 592), (33, 4, 8), (2048, 2048, 2048),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain(ops, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    out = ops.linear(x, w)
+    ref = x.float() @ w.float().t()
+    _close(out, ref)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_gemm_every_tile_config(ops, cfg):
+    g = torch.Generator().manual_seed(cfg)
+    M, N, K = 300, 260, 328
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    bias = torch.randn(N, generator=g).to(_dev())
+    out = ops.linear(x, w, bias=bias, force_cfg=cfg)
+    _close(out, x.float() @ w.float().t() + bias)
+
+
+@pytest.mark.parametrize("act", ["gelu", "gelu_tanh", "relu", "silu"])
+def test_gemm_epilogue_full(ops, act):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 771, 384, 384
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    bias = torch.randn(N, generator=g).to(_dev())
+    cs = torch.randn(N, generator=g).to(_dev())
+    res = _rand((M, N), g)
+    rs = torch.randn((M + 2) // 3, generator=g).to(_dev())
+    out = ops.linear(x, w, bias=bias, act=act, colscale=cs, residual=res, rowscale=rs, rowscale_div=3)
+    y = x.float() @ w.float().t() + bias
+    y = {"gelu": torch.nn.functional.gelu, "gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+         "relu": torch.relu, "silu": torch.nn.functional.silu}[act](y)
+    y = y * cs * rs.repeat_interleave(3)[:M, None] + res.float()
+    _close(out, y)
+
+
+def test_gemm_f32_out_and_f32_residual(ops):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 130, 1536, 384
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    res = torch.randn((M, N), generator=g).to(_dev())
+    out = ops.linear(x, w, residual=res, out_dtype=torch.float32)
+    assert out.dtype == torch.float32
+    _close(out, x.float() @ w.float().t() + res, rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_glu(ops):
+    g = torch.Generator().manual_seed(6)
+    M, K, I = 333, 384, 1024
+    x = _rand((M, K), g)
+    wg, wu = _rand((I, K), g, scale=K ** -0.5), _rand((I, K), g, scale=K ** -0.5)
+    bg, bu = torch.randn(I, generator=g), torch.randn(I, generator=g)
+    # interleave rows in 16-row blocks: [gate16 | up16]
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    b = torch.stack([bg.view(I // 16, 16), bu.view(I // 16, 16)], dim=1).reshape(2 * I).contiguous().to(_dev())
+    out = ops.linear(x, w, bias=b, act="silu", glu=True)
+    ref = torch.nn.functional.silu(x.float() @ wg.float().t() + bg.to(_dev())) * (x.float() @ wu.float().t() + bu.to(_dev()))
+    _close(out, ref)
+
+
+def test_gemm_strided_views(ops):
+    g = torch.Generator().manual_seed(8)
+    big = _rand((200, 1152), g)
+    x = big[:, 384:768]  # row-strided view (lda = 1152)
+    w = _rand((384, 384), g, scale=384 ** -0.5)
+    outbuf = torch.zeros(200, 768, dtype=torch.bfloat16, device=_dev())
+    ops.linear(x, w, out=outbuf[:, 384:])
+    _close(outbuf[:, 384:], x.float() @ w.float().t())
+    assert outbuf[:, :384].abs().max().item() == 0
+
+
+def _ref_attn(q, k, v, scale, causal=False, kv_start=0):
+    # q [B,Lq,H,D], k/v [B,Lk,Hkv,D]
+    B, Lq, H, D = q.shape
+    Lk, Hkv = k.shape[1], k.shape[2]
+    qf = q.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3).repeat_interleave(H // Hkv, dim=1)
+    vf = v.float().permute(0, 2, 1, 3).repeat_interleave(H // Hkv, dim=1)
+    s = qf @ kf.transpose(-1, -2) * scale
+    mask = torch.zeros(Lq, Lk, device=q.device)
+    if causal:
+        i = torch.arange(Lq, device=q.device)[:, None]
+        j = torch.arange(Lk, device=q.device)[None, :]
+        mask = mask.masked_fill(j > i + (Lk - Lq), float("-inf"))
+    if kv_start:
+        mask[:, :kv_start] = float("-inf")
+    p = torch.softmax(s + mask, dim=-1)
+    return (p @ vf).permute(0, 2, 1, 3)
+
+
+ATTN_CASES = [
+    # B, Lq, Lk, H, Hkv, D, causal, kv_start
+    (3, 257, 257, 6, 6, 64, False, 0),      # DINOv2 ViT-S
+    (5, 24, 24, 8, 8, 48, True, 0),         # NavDP decoder self-attn (T=24, causal)
+    (4, 32, 32, 8, 8, 48, True, 0),         # N1 NavDP head (T=32)
+    (4, 24, 132, 8, 8, 48, False, 0),       # NavDP cross-attn
+    (4, 24, 132, 8, 8, 48, False, 4),       # critic memory mask (first 4 cond slots hidden)
+    (2, 128, 2304, 8, 8, 48, False, 0),     # former_net cross-attn
+    (4, 32, 36, 6, 6, 64, False, 0),        # NextDiT cross-attn
+    (4, 32, 32, 6, 6, 64, False, 0),        # NextDiT self-attn
+    (2, 32, 512, 12, 12, 64, False, 0),     # QFormer cross-attn
+    (2, 784, 784, 16, 16, 80, False, 0),    # Qwen ViT full-attention block
+    (1, 920, 920, 28, 4, 128, True, 0),     # LLM prefill (GQA, causal)
+    (2, 4, 924, 28, 4, 128, True, 0),       # latent queries on a cached prefix
+    (3, 1, 17, 8, 8, 48, False, 0),         # TokenCompressor-like single query
+]
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,Hkv,D,causal,kv_start", ATTN_CASES)
+def test_attention_dense(ops, B, Lq, Lk, H, Hkv, D, causal, kv_start):
+    g = torch.Generator().manual_seed(B * 1000 + Lq + Lk + D)
+    q, k, v = _rand((B, Lq, H, D), g), _rand((B, Lk, Hkv, D), g), _rand((B, Lk, Hkv, D), g)
+    scale = D ** -0.5
+    out = ops.attention(q, k, v, scale=scale, causal=causal, kv_start=kv_start)
+    _close(out, _ref_attn(q, k, v, scale, causal, kv_start), atol=1.5e-2)
+
+
+def test_attention_packed_qkv_and_broadcast_kv(ops):
+    """q/k/v as strided views of one fused qkv buffer; K/V shared by groups of 4 query batches (NavDP samples)."""
+    g = torch.Generator().manual_seed(77)
+    B, L, H, D = 8, 24, 8, 48
+    qkv = _rand((B, L, 3 * H * D), g)
+    q = qkv[..., : H * D].view(B, L, H, D)
+    k = qkv[..., H * D: 2 * H * D].view(B, L, H, D)
+    v = qkv[..., 2 * H * D:].view(B, L, H, D)
+    out = ops.attention(q, k, v, causal=True)
+    _close(out, _ref_attn(q, k, v, D ** -0.5, True), atol=1.5e-2)
+    mem_k, mem_v = _rand((2, 132, H, D), g), _rand((2, 132, H, D), g)
+    out2 = ops.attention(q, mem_k, mem_v, kv_bdiv=4)
+    ref2 = _ref_attn(q, mem_k.repeat_interleave(4, 0), mem_v.repeat_interleave(4, 0), D ** -0.5)
+    _close(out2, ref2, atol=1.5e-2)
+
+
+def test_attention_varlen_windows(ops):
+    """Qwen2.5-VL window attention: ragged windows (64/32/16 tokens) packed on one token axis."""
+    g = torch.Generator().manual_seed(99)
+    lens = [64, 64, 32, 64, 16, 32, 64]
+    T, H, D = sum(lens), 16, 80
+    q, k, v = _rand((T, H, D), g), _rand((T, H, D), g), _rand((T, H, D), g)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=_dev())
+    out = ops.attention(q, k, v, cu_q=cu, cu_k=cu, max_q=64, max_k=64)
+    ref = torch.empty_like(out, dtype=torch.float32)
+    o = 0
+    for n in lens:
+        ref[o:o + n] = _ref_attn(q[None, o:o + n], k[None, o:o + n], v[None, o:o + n], D ** -0.5)[0]
+        o += n
+    _close(out, ref, atol=1.5e-2)
+
+
+def test_attention_gate_and_accumulate(ops):
+    g = torch.Generator().manual_seed(3)
+    B, Lq, Lk, H, D = 3, 32, 36, 6, 64
+    q, k, v = _rand((B, Lq, H, D), g), _rand((B, Lk, H, D), g), _rand((B, Lk, H, D), g)
+    base = _rand((B, Lq, H, D), g)
+    gate = torch.randn(H, generator=g).to(_dev())
+    out = base.clone()
+    ops.attention(q, k, v, head_gate=gate, out=out, accumulate=True)
+    ref = base.float() + _ref_attn(q, k, v, D ** -0.5) * torch.tanh(gate)[None, None, :, None]
+    _close(out, ref, atol=2e-2)
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 384), (77, 768), (300, 1280), (50, 3584), (9, 5120), (1, 8)])
+@pytest.mark.parametrize("rms", [False, True])
+def test_norm_plain(ops, rows, C, rms):
+    g = torch.Generator().manual_seed(rows + C)
+    x = _rand((rows, C), g, scale=2.0)
+    gamma, beta = torch.randn(C, generator=g).to(_dev()), torch.randn(C, generator=g).to(_dev())
+    if rms:
+        out = ops.norm(x, gamma=gamma, eps=1e-6, rms=True)
+        xf = x.float()
+        ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma
+    else:
+        out = ops.norm(x, gamma=gamma, beta=beta, eps=1e-6)
+        ref = torch.nn.functional.layer_norm(x.float(), (C,), gamma, beta, 1e-6)
+    _close(out, ref)
+
+
+def test_norm_residual_modulation_gate(ops):
+    g = torch.Generator().manual_seed(21)
+    B, T, C = 6, 32, 384
+    x, r, base = _rand((B * T, C), g), _rand((B * T, C), g), _rand((B * T, C), g)
+    gamma = torch.randn(C, generator=g).to(_dev())
+    emb = torch.randn(B, 4 * C, generator=g).to(_dev())
+    s = torch.empty_like(x)
+    out = ops.norm(x, gamma=gamma, eps=1e-5, rms=True, residual=r, sum_out=s, mod_scale=emb[:, :C], mod_div=T)
+    xs = x.float() + r.float()
+    _close(s, xs)
+    nrm = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
+    _close(out, nrm * (1 + emb[:, :C].repeat_interleave(T, 0)))
+    out2 = ops.norm(x, gamma=gamma, eps=1e-5, rms=True, gate=emb[:, C:2 * C], gate_base=base, mod_div=T)
+    xf = x.float()
+    nrm2 = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
+    _close(out2, base.float() + torch.tanh(emb[:, C:2 * C]).repeat_interleave(T, 0) * nrm2)
+
+
+def test_bad_arguments_fail_loudly(ops):
+    x = torch.zeros(4, 12, dtype=torch.bfloat16, device=_dev())  # K % 8 != 0
+    w = torch.zeros(8, 12, dtype=torch.bfloat16, device=_dev())
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.linear(x, w)
+    q = torch.zeros(1, 4, 2, 40, dtype=torch.bfloat16, device=_dev())
+    with pytest.raises(RuntimeError, match="unsupported head dim"):
+        ops.attention(q, q, q)
