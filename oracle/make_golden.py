@@ -1,0 +1,157 @@
+"""Generate tests/golden/*.pt by executing the REAL reference modules (from /root/reference) on CPU.  TEST INFRASTRUCTURE.
+
+Run in the build container only:  python -m oracle.make_golden [--only NAME]
+For each unit the reference module is constructed under the stubs of `oracle/ref_loader.py`, loaded with the seeded
+state-dict of `oracle/weights.py` (strict key/shape check of our tables against the reference constructor), run on the
+seeded inputs, and its outputs are saved in fp32. The oracle restatement is evaluated on the same inputs and the
+max-abs difference is printed and stored next to the outputs (`oracle_max_abs_diff`), so the fixture both pins the
+oracle and documents how tightly. `tests/test_oracle_golden.py` re-checks oracle-vs-fixture on every CPU test run.
+"""
+from __future__ import annotations
+
+import argparse
+from pathlib import Path
+
+import torch
+
+from . import dinov2 as o_dino
+from . import navdp as o_navdp
+from . import ref_loader as R
+from . import weights as W
+
+GOLD = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def _load_strict(module, sd, allow_missing_prefixes=(), skip_buffers=()):
+    ref_sd = module.state_dict()
+    for k, v in sd.items():
+        assert k in ref_sd, f"our key {k} does not exist in the reference module"
+        assert tuple(ref_sd[k].shape) == tuple(v.shape), f"{k}: ours {tuple(v.shape)} vs reference {tuple(ref_sd[k].shape)}"
+    missing = [k for k in ref_sd if k not in sd and not k.startswith(tuple(allow_missing_prefixes)) and k not in skip_buffers]
+    assert not missing, f"reference parameters without a counterpart in oracle/weights.py: {missing[:8]}"
+    module.load_state_dict({k: v.to(ref_sd[k].dtype) for k, v in sd.items()}, strict=False)
+    return module.float().eval()
+
+
+def gold_dinov2():
+    sd = W.materialize(W.dinov2_vits_spec(), seed=3)
+    vit = _load_strict(R.dinov2_vits(), sd)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        ref = vit.get_intermediate_layers(img)[0]
+        mine = o_dino.forward_tokens(img, sd)
+    return dict(seed=3, img_seed=7, tokens=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
+
+
+class _Inject:
+    """Feed explicit noise into the reference's sampler loop: the initial torch.randn and every scheduler.step."""
+
+    def __init__(self, mod, sched, x_init, step_noise):
+        self.queue = [n for n in step_noise]
+        self.x_init = x_init
+        orig = sched.step
+
+        def step(model_output, timestep, sample, **kw):
+            return orig(model_output, timestep, sample, noise=self.queue.pop(0))
+
+        sched.step = step
+        self.mod = mod
+
+
+def gold_navdpnet(B=2):
+    torch_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        npm = R.navdp_policy_module()
+        cfg = W.NAVDPNET_CFG
+        il = dict(image_size=224, memory_size=cfg["memory_size"], predict_size=cfg["predict_size"], pixel_channel=4,
+                  temporal_depth=cfg["temporal_depth"], heads=cfg["heads"], channels=3, dropout=0.1,
+                  token_dim=cfg["token_dim"], scratch=False, finetune=False)
+        net = npm.NavDPNet(npm.NavDPModelConfig(model_cfg={"model": {}, "local_rank": 0, "il": il}))
+    finally:
+        torch.load = torch_load
+    sd = W.navdpnet_state_dict(seed=0)
+    net = _load_strict(net, sd, allow_missing_prefixes=("pixel_encoder.", "image_encoder.", "pixel_aux_head.", "image_aux_head."))
+    net._device = torch.device("cpu")
+    net.cond_critic_mask = net.cond_critic_mask.float()
+    inp = W.navdpnet_inputs(B, seed=0)
+    negs, poss, rgbds = [], [], []
+    with torch.no_grad():
+        for b in range(B):
+            _Inject(npm, net.noise_scheduler, inp["x_init"][b], inp["step_noise"][:, b])
+            # the reference draws the initial noise with torch.randn (navdp_policy.py:308): patch it for this call
+            real_randn = torch.randn
+            torch.randn = lambda *a, **k: inp["x_init"][b].clone()
+            try:
+                neg, pos = net.predict_pointgoal_batch_action_vel(inp["goal"][b:b + 1].numpy(), inp["images"][b:b + 1],
+                                                                  inp["depths"][b:b + 1])
+            finally:
+                torch.randn = real_randn
+            negs.append(neg)
+            poss.append(pos)
+            rgbds.append(net.rgbd_encoder(inp["images"][b:b + 1], inp["depths"][b:b + 1]))
+            net.noise_scheduler.step = net.noise_scheduler.__class__.step.__get__(net.noise_scheduler)
+        neg, pos, rgbd = torch.stack(negs), torch.stack(poss), torch.cat(rgbds)
+        o_neg, o_pos, o_fin, o_cr, o_rgbd = o_navdp.navdpnet_pointgoal(sd, inp["goal"], inp["images"], inp["depths"],
+                                                                     inp["x_init"], inp["step_noise"], cfg, return_all=True)
+    d = max((neg - o_neg).abs().max().item(), (pos - o_pos).abs().max().item(), (rgbd - o_rgbd).abs().max().item())
+    return dict(B=B, seed=0, negative=neg, positive=pos, rgbd_embed=rgbd, oracle_max_abs_diff=d)
+
+
+def gold_n1_navdp(B=2):
+    torch_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        n1 = R.n1_navdp_module()
+        cfg = W.N1_NAVDP_CFG
+        m = n1.NavDP_Policy_DPT_CriticSum_DAT(memory_size=cfg["memory_size"], navdp_version=0.1, input_dtype="fp32")
+    finally:
+        torch.load = torch_load
+    sd = W.n1_navdp_state_dict(seed=1)
+    m = _load_strict(m, sd, allow_missing_prefixes=("point_encoder.", "critic_head.", "pg_embed_mlp.", "pg_pred_mlp.",
+                                                    "decoder_layer."),
+                     skip_buffers=("goal_compressor.positional_encoding.pe",))
+    # the RGB-D backbone keeps its default input_dtype="bf16" constants (bf16-rounded ImageNet mean/std), as in the
+    # reference N1 build (internvla_n1_arch.py:13); only the arithmetic is lifted to fp32 for the fixture
+    m.rgbd_encoder.input_dtype = torch.float32
+    m.rgbd_encoder.preprocess_mean = m.rgbd_encoder.preprocess_mean.float()
+    m.rgbd_encoder.preprocess_std = m.rgbd_encoder.preprocess_std.float()
+    m.tgt_mask = m.tgt_mask.float()
+    inp = W.n1_navdp_inputs(B, seed=1)
+    outs = []
+    with torch.no_grad():
+        for b in range(B):
+            _Inject(n1, m.noise_scheduler, inp["x_init"][b], inp["step_noise"][:, b])
+            real_randn = torch.randn
+            # the reference draws the initial noise with torch.randn (navdp.py:242): patch it for the duration of the call
+            torch.randn = lambda *a, **k: inp["x_init"][b].clone()
+            try:
+                outs.append(m.predict_pointgoal_action_async(inp["vlm_tokens"][b:b + 1], inp["images"][b:b + 1], inp["depths"][b:b + 1]))
+            finally:
+                torch.randn = real_randn
+            m.noise_scheduler.step = m.noise_scheduler.__class__.step.__get__(m.noise_scheduler)
+        ref = torch.stack(outs)
+        mine = o_navdp.n1_navdp_async(sd, inp["vlm_tokens"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"], cfg)
+    return dict(B=B, seed=1, trajectories=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
+
+
+UNITS = {"dinov2": gold_dinov2, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    GOLD.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+    for name, fn in UNITS.items():
+        if a.only and a.only != name:
+            continue
+        out = fn()
+        print(f"[golden] {name}: oracle vs reference max|diff| = {out['oracle_max_abs_diff']:.3e}", flush=True)
+        torch.save(out, GOLD / f"{name}.pt")
+
+
+if __name__ == "__main__":
+    main()
