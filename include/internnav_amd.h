@@ -37,6 +37,14 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select):
+ * lets a binding verify its struct mirrors against the compiled layout. */
+int ina_struct_size(int k);
+/* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
+ * stream and its algorithmic FLOPs / bytes are tallied per kernel class (0 gemm, 1 attention, 2 norm, 3 elementwise).
+ * ina_prof_enable(0|1) also clears the tally; ina_prof_read synchronises on the recorded events. Eager launches only. */
+int ina_prof_enable(int on);
+int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
  *      (reference: torch.nn.Linear call sites, e.g. dinov2_layers/attention.py:46-48, mlp.py:27-29,
@@ -90,25 +98,113 @@ typedef struct ina_attn_args {
 } ina_attn_args;
 int ina_attention_bf16(const ina_attn_args* args, void* stream);
 
-/* ---- LayerNorm / RMSNorm (+ residual-in, + NextDiT modulation / tanh gate); reference: nn.LayerNorm call sites
- *      (dinov2_layers/block.py:83-87, navdp.py:78,193), diffusers RMSNorm / LuminaRMSNormZero (nextdit_traj.py:109-119). */
+/* One-level row map: logical row r -> physical row (r / seg_len) * seg_stride + off + r % seg_len (seg_len 0 = identity).
+ * Lets norm / embed kernels drop the ViT cls token, concatenate token groups and scatter into [env, slot] buffers
+ * (reference: torch.cat call sites navdp_backbone.py:187,281; navdp_policy.py:162-164; navdp.py:182-185). */
+typedef struct ina_rowmap {
+    int32_t seg_len, seg_stride, off, _pad;
+} ina_rowmap;
+
+/* ---- LayerNorm / RMSNorm (+ NextDiT modulation / tanh gate / base add / positional table); reference: nn.LayerNorm call
+ *      sites (dinov2_layers/block.py:83-87, navdp.py:78,193), diffusers RMSNorm / LuminaRMSNormZero (nextdit_traj.py:109-119,146,172-176).
+ *      t = norm(X[in_map(r)]) * gamma + beta ; t *= 1 + mod_scale[r/mod_div] ; t *= tanh(gate[r/mod_div]) ; t += G[r] ; t += P[r % p_mod]
+ *      -> Y[out_map(r)] (bf16) and/or Y32[out_map(r)] (f32). */
 typedef struct ina_norm_args {
-    const void* X;
-    const void* R;
-    void* Y;
-    void* S;
-    const float* gamma;
-    const float* beta;
-    const float* mod_scale;
-    const float* gate;
-    const void* G;
+    const void* X;          /* bf16|f32 (x_dtype) rows of C, row stride ldx */
+    void* Y;                /* bf16 out or NULL */
+    void* Y32;              /* f32 out or NULL */
+    const float* gamma;     /* f32 [C] or NULL */
+    const float* beta;      /* f32 [C] or NULL */
+    const float* mod_scale; /* f32 [rows/mod_div, mod_ld] or NULL */
+    const float* gate;      /* f32 [rows/mod_div, mod_ld] or NULL */
+    const void* G;          /* bf16|f32 (g_dtype) [rows, ldg] base added after gating, or NULL */
+    const float* P;         /* f32 [p_mod, C] table or NULL */
+    ina_rowmap in_map, out_map;
     int32_t rows, C;
-    int32_t ldx, ldr, ldy, ldg;
+    int32_t ldx, ldy, ldy32, ldg;
+    int32_t x_dtype, g_dtype;
     int32_t mod_div, mod_ld;
-    int32_t rms;
+    int32_t p_mod, rms;
     float eps;
+    int32_t _pad;
 } ina_norm_args;
 int ina_norm_bf16(const ina_norm_args* args, void* stream);
+
+/* ---- patchify: NHWC frames -> im2col rows of the ViT patch-embed conv, fused with the input normalisation.
+ *      out[(i*gh + py)*gw + px, c*ps*ps + y*ps + x] = (img[i, py*ps+y, px*ps+x, c] - mean[c]) * inv_std[c]   (bf16),
+ *      columns >= 3*ps*ps are zero padding. C == 1 replicates the channel 3x (depth frames).
+ *      reference: navdp_backbone.py:155-181,258-279 + dinov2_layers/patch_embed.py:151-164 (Conv2d 14x14 stride 14). */
+typedef struct ina_patchify_args {
+    const void* img;        /* f32|bf16 (in_dtype) [n, H, W, C] */
+    void* out;              /* bf16 [n * gh * gw, ldo] */
+    float mean[3];
+    float inv_std[3];
+    int32_t n, H, W, C;
+    int32_t ps, ldo, in_dtype, _pad;
+} ina_patchify_args;
+int ina_patchify(const ina_patchify_args* args, void* stream);
+
+/* ---- embed3: Y[out_map(r)] = W[:, 0:3] . X[r, 0:3] + b + P[r % p_mod]   (nn.Linear(3, C) + positional table; X NULL = table fill)
+ *      reference: input_embed / point_encoder / action_encoder (navdp_policy.py:160,165; navdp.py:178,190; internvla_n1.py:402-410). */
+typedef struct ina_embed3_args {
+    const float* X;         /* f32 [rows, 3] or NULL */
+    const float* W;         /* f32 [C, 3] */
+    const float* b;         /* f32 [C] or NULL */
+    const float* P;         /* f32 [p_mod, C] or NULL */
+    void* Y;                /* bf16|f32 (out_dtype) */
+    ina_rowmap out_map;
+    int32_t rows, C, ldy, p_mod;
+    int32_t out_dtype, x_div;   /* x row = r / x_div (0 means 1): broadcast one vector to x_div consecutive rows */
+} ina_embed3_args;
+int ina_embed3(const ina_embed3_args* args, void* stream);
+
+/* ---- head3: final norm + Linear(C, 3) + sampler update, one wave per row.
+ *      e = W . (norm(X[r]) * gamma + beta) * (1 + mod_scale[r / mod_div]) ... + b
+ *      mode 0: eps_out[r] = e ; mode 1 (DDPM, diffusers DDPMScheduler.step): x0 = clamp((s - c1 e) c0, +-clip),
+ *      s <- c2 x0 + c3 s + c4 noise[r] ; mode 2 (FlowMatch Euler): s <- s + c0 e.
+ *      reference: navdp_policy.py:167-169,312-315; navdp.py:193-195,247-250; internvla_n1.py:418-431. */
+typedef struct ina_head3_args {
+    const void* X;          /* bf16|f32 (x_dtype) [rows, ldx] */
+    const float* gamma;     /* f32 [C] or NULL */
+    const float* beta;      /* f32 [C] or NULL */
+    const float* mod_scale; /* f32 [rows/mod_div, mod_ld] or NULL */
+    const float* W;         /* f32 [3, C] */
+    const float* b;         /* f32 [3] */
+    float* sample;          /* f32 [rows, 3], updated in place (modes 1, 2) */
+    const float* noise;     /* f32 [rows, 3] or NULL */
+    float* eps_out;         /* f32 [rows, 3] or NULL */
+    float coef[5];
+    float clip;
+    float eps;
+    int32_t rows, C, ldx, x_dtype;
+    int32_t mode, mod_div, mod_ld;
+} ina_head3_args;
+int ina_head3(const ina_head3_args* args, void* stream);
+
+/* ---- seqpool_head: out[s] = w . mean_t( norm(X[s*T + t]) * gamma + beta ) + b   (critic head, navdp_policy.py:183-184) */
+typedef struct ina_seqpool_args {
+    const void* X;
+    const float* gamma;
+    const float* beta;
+    const float* w;         /* f32 [C] */
+    const float* b;         /* f32 [1] */
+    float* out;             /* f32 [nseq] */
+    float eps;
+    int32_t nseq, T, C, ldx, x_dtype, _pad;
+} ina_seqpool_args;
+int ina_seqpool_head(const ina_seqpool_args* args, void* stream);
+
+/* ---- select_traj: per env, rank the S samples by critic value; neg = the k lowest (ascending), pos = the k highest
+ *      (descending); trajectories are cumsum_t(sample * scale).  reference: navdp_policy.py:317-320. */
+typedef struct ina_select_args {
+    const float* critic;    /* f32 [B, S] */
+    const float* sample;    /* f32 [B, S, T, 3] */
+    float* neg;             /* f32 [B, k, T, 3] */
+    float* pos;             /* f32 [B, k, T, 3] */
+    float scale;
+    int32_t B, S, T, k, _pad;
+} ina_select_args;
+int ina_select_traj(const ina_select_args* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,14 +43,65 @@ class AttnArgs(C.Structure):
     ]
 
 
+class RowMap(C.Structure):
+    _fields_ = [("seg_len", c_int32), ("seg_stride", c_int32), ("off", c_int32), ("_pad", c_int32)]
+
+
 class NormArgs(C.Structure):
     _fields_ = [
-        ("X", c_void_p), ("R", c_void_p), ("Y", c_void_p), ("S", c_void_p),
-        ("gamma", c_void_p), ("beta", c_void_p), ("mod_scale", c_void_p), ("gate", c_void_p), ("G", c_void_p),
+        ("X", c_void_p), ("Y", c_void_p), ("Y32", c_void_p),
+        ("gamma", c_void_p), ("beta", c_void_p), ("mod_scale", c_void_p), ("gate", c_void_p), ("G", c_void_p), ("P", c_void_p),
+        ("in_map", RowMap), ("out_map", RowMap),
         ("rows", c_int32), ("C", c_int32),
-        ("ldx", c_int32), ("ldr", c_int32), ("ldy", c_int32), ("ldg", c_int32),
+        ("ldx", c_int32), ("ldy", c_int32), ("ldy32", c_int32), ("ldg", c_int32),
+        ("x_dtype", c_int32), ("g_dtype", c_int32),
         ("mod_div", c_int32), ("mod_ld", c_int32),
-        ("rms", c_int32), ("eps", c_float),
+        ("p_mod", c_int32), ("rms", c_int32),
+        ("eps", c_float), ("_pad", c_int32),
+    ]
+
+
+class PatchifyArgs(C.Structure):
+    _fields_ = [
+        ("img", c_void_p), ("out", c_void_p),
+        ("mean", c_float * 3), ("inv_std", c_float * 3),
+        ("n", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32),
+        ("ps", c_int32), ("ldo", c_int32), ("in_dtype", c_int32), ("_pad", c_int32),
+    ]
+
+
+class Embed3Args(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("W", c_void_p), ("b", c_void_p), ("P", c_void_p), ("Y", c_void_p),
+        ("out_map", RowMap),
+        ("rows", c_int32), ("C", c_int32), ("ldy", c_int32), ("p_mod", c_int32),
+        ("out_dtype", c_int32), ("x_div", c_int32),
+    ]
+
+
+class Head3Args(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("mod_scale", c_void_p), ("W", c_void_p), ("b", c_void_p),
+        ("sample", c_void_p), ("noise", c_void_p), ("eps_out", c_void_p),
+        ("coef", c_float * 5), ("clip", c_float), ("eps", c_float),
+        ("rows", c_int32), ("C", c_int32), ("ldx", c_int32), ("x_dtype", c_int32),
+        ("mode", c_int32), ("mod_div", c_int32), ("mod_ld", c_int32),
+    ]
+
+
+class SeqpoolArgs(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("w", c_void_p), ("b", c_void_p), ("out", c_void_p),
+        ("eps", c_float),
+        ("nseq", c_int32), ("T", c_int32), ("C", c_int32), ("ldx", c_int32), ("x_dtype", c_int32), ("_pad", c_int32),
+    ]
+
+
+class SelectArgs(C.Structure):
+    _fields_ = [
+        ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
+        ("scale", c_float),
+        ("B", c_int32), ("S", c_int32), ("T", c_int32), ("k", c_int32), ("_pad", c_int32),
     ]
 
 
@@ -62,6 +113,14 @@ SYMBOLS = {
     "ina_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_void_p]),
     "ina_attention_bf16": (C.c_int, [C.POINTER(AttnArgs), c_void_p]),
     "ina_norm_bf16": (C.c_int, [C.POINTER(NormArgs), c_void_p]),
+    "ina_patchify": (C.c_int, [C.POINTER(PatchifyArgs), c_void_p]),
+    "ina_embed3": (C.c_int, [C.POINTER(Embed3Args), c_void_p]),
+    "ina_head3": (C.c_int, [C.POINTER(Head3Args), c_void_p]),
+    "ina_seqpool_head": (C.c_int, [C.POINTER(SeqpoolArgs), c_void_p]),
+    "ina_select_traj": (C.c_int, [C.POINTER(SelectArgs), c_void_p]),
+    "ina_struct_size": (C.c_int, [C.c_int]),
+    "ina_prof_enable": (C.c_int, [C.c_int]),
+    "ina_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

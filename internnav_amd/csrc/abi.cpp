@@ -15,7 +15,59 @@ void ina_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- per-launch event timing -----------------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
+}  // namespace
+
+InaProfScope::InaProfScope(int kind, double flops, double bytes, hipStream_t s) : idx(-1), stream(s) {
+    if (!g_prof_on) return;
+    ProfRec r{kind, nullptr, nullptr, flops, bytes};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+    idx = (int)g_prof.size() - 1;
+}
+InaProfScope::~InaProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[idx].b, stream);
+}
+
 extern "C" {
+
+int ina_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes) {
+    INA_REQUIRE(kind >= 0 && kind < INA_PROF_KINDS, "prof_read: bad kind %d", kind);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0, fl = 0, by = 0;
+    int64_t n = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
+        INA_HIP_CHECK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        INA_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t; fl += r.flops; by += r.bytes; ++n;
+    }
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = n;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return 0;
+}
 
 int ina_abi_version(void) { return INA_ABI_VERSION; }
 
@@ -48,5 +100,33 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
     INA_REQUIRE(args != nullptr, "norm: null args");
     return ina_launch_norm(*args, reinterpret_cast<hipStream_t>(stream));
 }
+
+/* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify,
+ * 4 embed3, 5 head3, 6 seqpool, 7 select */
+int ina_struct_size(int k) {
+    switch (k) {
+        case 0: return (int)sizeof(ina_gemm_args);
+        case 1: return (int)sizeof(ina_attn_args);
+        case 2: return (int)sizeof(ina_norm_args);
+        case 3: return (int)sizeof(ina_patchify_args);
+        case 4: return (int)sizeof(ina_embed3_args);
+        case 5: return (int)sizeof(ina_head3_args);
+        case 6: return (int)sizeof(ina_seqpool_args);
+        case 7: return (int)sizeof(ina_select_args);
+        default: return -1;
+    }
+}
+
+#define INA_ENTRY(name, T, launch)                                             \
+    int name(const T* args, void* stream) {                                     \
+        INA_REQUIRE(args != nullptr, #name ": null args");                      \
+        return launch(*args, reinterpret_cast<hipStream_t>(stream));            \
+    }
+INA_ENTRY(ina_patchify, ina_patchify_args, ina_launch_patchify)
+INA_ENTRY(ina_embed3, ina_embed3_args, ina_launch_embed3)
+INA_ENTRY(ina_head3, ina_head3_args, ina_launch_head3)
+INA_ENTRY(ina_seqpool_head, ina_seqpool_args, ina_launch_seqpool)
+INA_ENTRY(ina_select_traj, ina_select_args, ina_launch_select)
+#undef INA_ENTRY
 
 }  // extern "C"

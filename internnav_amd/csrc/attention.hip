@@ -187,6 +187,10 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
     const bool small_k = p.Lk <= 48;
     int nw = (p.Lq <= 16) ? 1 : (p.Lq <= 32 ? 2 : 4);
     dim3 grid((p.Lq + nw * 16 - 1) / (nw * 16), p.H, p.B);
+    // algorithmic FLOPs: QK^T + PV over the unmasked keys (dense bound Lq x Lk for varlen: cu_* lengths live on the device)
+    const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)(p.Lk - p.kv_start);
+    InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
+                      2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)(p.B / p.kv_bdiv) * p.Hkv * p.Lk), stream);
 #define INA_ATTN_LAUNCH(NW_, KVB_) \
     hipLaunchKernelGGL((attn_fwd_kernel<DP, DV, NW_, KVB_>), grid, dim3(NW_ * 64), 0, stream, p)
     if (nw == 1) { if (small_k) INA_ATTN_LAUNCH(1, 32); else INA_ATTN_LAUNCH(1, 64); }

@@ -83,3 +83,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     } while (0)
 
 void ina_set_error(const char* fmt, ...);
+
+// Optional per-launch timing (ina_prof_enable): every launch function opens a scope that records a hipEvent pair on the
+// launch stream around its kernel and tallies the algorithmic FLOPs / bytes of that launch. bench.py reads the totals per
+// kernel class for the live roofline line; disabled (the default) it costs one branch. Not usable under graph capture.
+enum : int { INA_PROF_GEMM = 0, INA_PROF_ATTN = 1, INA_PROF_NORM = 2, INA_PROF_ELEMENTWISE = 3, INA_PROF_KINDS = 4 };
+struct InaProfScope {
+    InaProfScope(int kind, double flops, double bytes, hipStream_t stream);
+    ~InaProfScope();
+    int idx;
+    hipStream_t stream;
+};

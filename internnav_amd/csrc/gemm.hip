@@ -213,6 +213,9 @@ int launch_cfg(const GemmArgs& p, hipStream_t stream) {
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid(tiles, p.batch, 1);
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
+    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
+                      (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;

@@ -11,7 +11,17 @@
 using GemmArgs = ina_gemm_args;
 using AttnArgs = ina_attn_args;
 using NormArgs = ina_norm_args;
+using PatchifyArgs = ina_patchify_args;
+using Embed3Args = ina_embed3_args;
+using Head3Args = ina_head3_args;
+using SeqpoolArgs = ina_seqpool_args;
+using SelectArgs = ina_select_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
 int ina_launch_norm(const NormArgs& p, hipStream_t stream);
+int ina_launch_patchify(const PatchifyArgs& p, hipStream_t stream);
+int ina_launch_embed3(const Embed3Args& p, hipStream_t stream);
+int ina_launch_head3(const Head3Args& p, hipStream_t stream);
+int ina_launch_seqpool(const SeqpoolArgs& p, hipStream_t stream);
+int ina_launch_select(const SelectArgs& p, hipStream_t stream);

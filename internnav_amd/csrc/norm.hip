@@ -150,6 +150,9 @@ int ina_launch_norm(const NormArgs& p_in, hipStream_t stream) {
     INA_REQUIRE(!p.G || p.ldg % 8 == 0, "norm: ldg must be a multiple of 8");
     INA_REQUIRE((!p.mod_scale && !p.gate) || (p.mod_ld > 0 && p.mod_ld % 4 == 0), "norm: modulation needs mod_ld (multiple of 4)");
     const int nchunks = p.C / 8;
+    InaProfScope prof(INA_PROF_NORM, 8.0 * p.rows * p.C,
+                      (double)p.rows * p.C * ((p.x_dtype == INA_DT_F32 ? 4.0 : 2.0) + (p.Y ? 2.0 : 0.0) + (p.Y32 ? 4.0 : 0.0) +
+                                              (p.G ? (p.g_dtype == INA_DT_F32 ? 4.0 : 2.0) : 0.0)), stream);
     if (nchunks <= 16) launch_norm<1, 4>(p, stream);        // C <= 128: 4 rows per wave
     else if (nchunks <= 32) launch_norm<1, 2>(p, stream);   // C <= 256
     else if (nchunks <= 64) launch_norm<1, 1>(p, stream);

@@ -40,34 +40,53 @@ def _as2d(x: torch.Tensor) -> torch.Tensor:
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
-           rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0) -> torch.Tensor:
-    """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K]."""
+           rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
+           batched: bool = False) -> torch.Tensor:
+    """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
+
+    batched=True: x is [Bt, M, K] and out [Bt, M, N] views with arbitrary batch strides (rows contiguous-strided inside a
+    batch); residual is [Bt, M, N] or a [M, N] table broadcast over the batch (e.g. positional embeddings).
+    """
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
-    lead = x.shape[:-1]
-    x2 = _as2d(x)
-    assert x2.dim() == 2 and w.dim() == 2 and w.stride(1) == 1
-    M, K = x2.shape
-    N = w.shape[0]
-    assert w.shape[1] == K, f"K mismatch {w.shape} vs {x2.shape}"
+    assert w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
     n_out = N // 2 if glu else N
-    if out is None:
-        out = torch.empty(*lead, n_out, dtype=out_dtype, device=x.device)
-    o2 = _as2d(out)
-    assert o2.shape == (M, n_out)
     a = GemmArgs()
-    a.A, a.W, a.C = x2.data_ptr(), w.data_ptr(), o2.data_ptr()
+    if batched:
+        assert x.dim() == 3 and x.stride(2) == 1 and out is not None and out.dim() == 3 and out.stride(2) == 1
+        Bt, M, _ = x.shape
+        assert out.shape == (Bt, M, n_out)
+        a.A, a.C = x.data_ptr(), out.data_ptr()
+        a.lda, a.ldc = x.stride(1), out.stride(1)
+        a.batch, a.strideA, a.strideC = Bt, x.stride(0), out.stride(0)
+        if residual is not None:
+            assert residual.stride(-1) == 1 and residual.shape[-2:] == (M, n_out)
+            a.R, a.ldr, a.res_dtype = residual.data_ptr(), residual.stride(-2), _DT[residual.dtype]
+            a.strideR = residual.stride(0) if residual.dim() == 3 else 0
+    else:
+        lead = x.shape[:-1]
+        x2 = _as2d(x)
+        assert x2.dim() == 2
+        M = x2.shape[0]
+        if out is None:
+            out = torch.empty(*lead, n_out, dtype=out_dtype, device=x.device)
+        o2 = _as2d(out)
+        assert o2.shape == (M, n_out), f"out {tuple(o2.shape)} vs {(M, n_out)}"
+        a.A, a.C = x2.data_ptr(), o2.data_ptr()
+        a.lda, a.ldc = x2.stride(0), o2.stride(0)
+        a.batch = 1
+        if residual is not None:
+            r2 = _as2d(residual)
+            assert r2.shape == (M, n_out)
+            a.R, a.ldr, a.res_dtype = r2.data_ptr(), r2.stride(0), _DT[r2.dtype]
+    assert x.shape[-1] == K, f"K mismatch {tuple(w.shape)} vs {tuple(x.shape)}"
+    a.W, a.ldw = w.data_ptr(), w.stride(0)
     a.bias, a.colscale, a.rowscale = _ptr(_f32(bias)), _ptr(_f32(colscale)), _ptr(_f32(rowscale))
     a.M, a.N, a.K = M, N, K
-    a.lda, a.ldw, a.ldc = x2.stride(0), w.stride(0), o2.stride(0)
-    if residual is not None:
-        r2 = _as2d(residual)
-        assert r2.shape == (M, n_out)
-        a.R, a.ldr, a.res_dtype = r2.data_ptr(), r2.stride(0), _DT[r2.dtype]
     a.act = ACT[act] if not isinstance(act, int) else act
     a.out_dtype = _DT[out.dtype]
     a.glu = 1 if glu else 0
     a.rowscale_div = rowscale_div
-    a.batch = 1
     a.force_cfg = force_cfg
     _lib.check(_lib.lib().ina_gemm_bf16(C.byref(a), _stream()), "gemm_bf16")
     return out
@@ -122,28 +141,41 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
     return out
 
 
+def _rowmap(m) -> _lib.RowMap:
+    r = _lib.RowMap()
+    if m is not None:
+        r.seg_len, r.seg_stride, r.off = int(m[0]), int(m[1]), int(m[2])
+    return r
+
+
 def norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
-         eps: float = 1e-5, rms: bool = False, residual: Optional[torch.Tensor] = None,
-         sum_out: Optional[torch.Tensor] = None, mod_scale: Optional[torch.Tensor] = None,
-         gate: Optional[torch.Tensor] = None, gate_base: Optional[torch.Tensor] = None, mod_div: int = 1,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """LayerNorm / RMSNorm over the last dim of bf16 x (+ optional residual-in, modulation, tanh-gated base)."""
-    assert x.dtype == torch.bfloat16
+         eps: float = 1e-5, rms: bool = False, mod_scale: Optional[torch.Tensor] = None,
+         gate: Optional[torch.Tensor] = None, base: Optional[torch.Tensor] = None, mod_div: int = 1,
+         pos: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+         out32: Optional[torch.Tensor] = None, rows: Optional[int] = None, in_map=None, out_map=None) -> torch.Tensor:
+    """LayerNorm / RMSNorm over the last dim of x (bf16 or f32) -> out (bf16) and/or out32 (f32).
+
+    t = norm(x) * gamma + beta; t *= 1 + mod_scale[r // mod_div]; t *= tanh(gate[r // mod_div]); t += base[r]; t += pos[r % len(pos)].
+    in_map / out_map = (seg_len, seg_stride, off) gather / scatter logical rows; `rows` = number of logical rows (default: all of x).
+    """
+    assert x.dtype in _DT
     x2 = _as2d(x)
-    rows, Cdim = x2.shape
-    if out is None:
+    Cdim = x2.shape[1]
+    if rows is None:
+        rows = x2.shape[0]
+    if out is None and out32 is None:
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    y2 = _as2d(out)
     a = NormArgs()
-    a.X, a.Y = x2.data_ptr(), y2.data_ptr()
-    a.rows, a.C, a.ldx, a.ldy = rows, Cdim, x2.stride(0), y2.stride(0)
-    if residual is not None:
-        r2 = _as2d(residual)
-        a.R, a.ldr = r2.data_ptr(), r2.stride(0)
-    if sum_out is not None:
-        s2 = _as2d(sum_out)
-        assert s2.stride(0) == y2.stride(0)
-        a.S = s2.data_ptr()
+    a.X, a.x_dtype, a.ldx = x2.data_ptr(), _DT[x2.dtype], x2.stride(0)
+    a.rows, a.C = rows, Cdim
+    if out is not None:
+        y2 = _as2d(out)
+        assert y2.dtype == torch.bfloat16 and y2.shape[1] == Cdim
+        a.Y, a.ldy = y2.data_ptr(), y2.stride(0)
+    if out32 is not None:
+        z2 = _as2d(out32)
+        assert z2.dtype == torch.float32 and z2.shape[1] == Cdim
+        a.Y32, a.ldy32 = z2.data_ptr(), z2.stride(0)
     a.gamma, a.beta = _ptr(_f32(gamma)), _ptr(_f32(beta))
     if mod_scale is not None:
         assert mod_scale.dtype == torch.float32 and mod_scale.stride(-1) == 1
@@ -153,11 +185,102 @@ def norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[t
         a.gate, a.mod_ld = gate.data_ptr(), gate.stride(0)
         if mod_scale is not None:
             assert mod_scale.stride(0) == gate.stride(0)
-    if gate_base is not None:
-        g2 = _as2d(gate_base)
-        a.G, a.ldg = g2.data_ptr(), g2.stride(0)
+    if base is not None:
+        g2 = _as2d(base)
+        a.G, a.ldg, a.g_dtype = g2.data_ptr(), g2.stride(0), _DT[g2.dtype]
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == Cdim
+        a.P, a.p_mod = pos.data_ptr(), pos.numel() // Cdim
+    a.in_map, a.out_map = _rowmap(in_map), _rowmap(out_map)
     a.mod_div = mod_div
     a.rms = 1 if rms else 0
     a.eps = eps
     _lib.check(_lib.lib().ina_norm_bf16(C.byref(a), _stream()), "norm_bf16")
+    return out if out is not None else out32
+
+
+def patchify(img: torch.Tensor, out: torch.Tensor, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), ps: int = 14) -> torch.Tensor:
+    """img [n, H, W, C] (f32|bf16, C = 3 or 1) -> out bf16 [n * (H/ps) * (W/ps), ldo] im2col rows (k = c*ps*ps + y*ps + x)."""
+    assert img.is_contiguous() and img.dim() == 4 and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    a = _lib.PatchifyArgs()
+    a.img, a.out = img.data_ptr(), out.data_ptr()
+    for i in range(3):
+        a.mean[i], a.inv_std[i] = float(mean[i]), 1.0 / float(std[i])
+    a.n, a.H, a.W, a.C = img.shape
+    assert out.shape[0] == a.n * (a.H // ps) * (a.W // ps)
+    a.ps, a.ldo, a.in_dtype = ps, out.stride(0), _DT[img.dtype]
+    _lib.check(_lib.lib().ina_patchify(C.byref(a), _stream()), "patchify")
     return out
+
+
+def embed3(x: Optional[torch.Tensor], w: Optional[torch.Tensor], bias: Optional[torch.Tensor], out: torch.Tensor,
+           pos: Optional[torch.Tensor] = None, rows: Optional[int] = None, out_map=None, x_div: int = 1) -> torch.Tensor:
+    """out[out_map(r)] = w @ x[r // x_div] + bias + pos[r % len(pos)]  (nn.Linear(3, C); x None = table fill)."""
+    o2 = _as2d(out)
+    a = _lib.Embed3Args()
+    if x is not None:
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == 3 and w is not None
+        a.X = x.data_ptr()
+        if rows is None:
+            rows = (x.numel() // 3) * x_div
+    if w is not None:
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.shape == (o2.shape[1], 3)
+        a.W = w.data_ptr()
+    a.b = _ptr(_f32(bias))
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous()
+        a.P, a.p_mod = pos.data_ptr(), pos.numel() // o2.shape[1]
+    assert rows is not None
+    a.Y, a.ldy, a.out_dtype = o2.data_ptr(), o2.stride(0), _DT[o2.dtype]
+    a.rows, a.C, a.x_div = rows, o2.shape[1], x_div
+    a.out_map = _rowmap(out_map)
+    _lib.check(_lib.lib().ina_embed3(C.byref(a), _stream()), "embed3")
+    return out
+
+
+def head3(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gamma=None, beta=None, eps: float = 1e-5, mode: int = 0,
+          sample: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None, eps_out: Optional[torch.Tensor] = None,
+          coef=(0.0, 0.0, 0.0, 0.0, 0.0), clip: float = 1.0, mod_scale: Optional[torch.Tensor] = None, mod_div: int = 1):
+    """final norm + Linear(C,3) + sampler update (mode 0: write eps_out; 1: DDPM step; 2: Euler step) on f32 samples [rows,3]."""
+    x2 = _as2d(x)
+    a = _lib.Head3Args()
+    a.X, a.ldx, a.x_dtype = x2.data_ptr(), x2.stride(0), _DT[x2.dtype]
+    a.rows, a.C = x2.shape
+    a.gamma, a.beta = _ptr(_f32(gamma)), _ptr(_f32(beta))
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.shape == (3, a.C) and b.dtype == torch.float32
+    a.W, a.b = w.data_ptr(), b.data_ptr()
+    for t in (sample, noise, eps_out):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == a.rows * 3)
+    a.sample, a.noise, a.eps_out = _ptr(sample), _ptr(noise), _ptr(eps_out)
+    for i in range(5):
+        a.coef[i] = float(coef[i])
+    a.clip, a.eps, a.mode = clip, eps, mode
+    if mod_scale is not None:
+        assert mod_scale.dtype == torch.float32 and mod_scale.stride(-1) == 1
+        a.mod_scale, a.mod_ld = mod_scale.data_ptr(), mod_scale.stride(0)
+    a.mod_div = mod_div
+    _lib.check(_lib.lib().ina_head3(C.byref(a), _stream()), "head3")
+
+
+def seqpool_head(x: torch.Tensor, T: int, gamma, beta, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, eps: float = 1e-5):
+    """out[s] = w . mean_t(LayerNorm(x[s*T + t])) + b."""
+    x2 = _as2d(x)
+    a = _lib.SeqpoolArgs()
+    a.X, a.ldx, a.x_dtype = x2.data_ptr(), x2.stride(0), _DT[x2.dtype]
+    a.nseq, a.T, a.C = x2.shape[0] // T, T, x2.shape[1]
+    a.gamma, a.beta, a.w, a.b = _ptr(_f32(gamma)), _ptr(_f32(beta)), _f32(w.reshape(-1)).data_ptr(), _f32(b).data_ptr()
+    assert out.dtype == torch.float32 and out.numel() == a.nseq
+    a.out, a.eps = out.data_ptr(), eps
+    _lib.check(_lib.lib().ina_seqpool_head(C.byref(a), _stream()), "seqpool_head")
+    return out
+
+
+def select_traj(critic: torch.Tensor, sample: torch.Tensor, neg: torch.Tensor, pos: torch.Tensor, k: int = 8, scale: float = 0.25):
+    """critic [B,S], sample [B,S,T,3] -> neg/pos [B,k,T,3] cumulative trajectories of the k lowest / highest critic samples."""
+    B, S, T, _ = sample.shape
+    for t in (critic, sample, neg, pos):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    a = _lib.SelectArgs()
+    a.critic, a.sample, a.neg, a.pos = critic.data_ptr(), sample.data_ptr(), neg.data_ptr(), pos.data_ptr()
+    a.scale, a.B, a.S, a.T, a.k = scale, B, S, T, k
+    _lib.check(_lib.lib().ina_select_traj(C.byref(a), _stream()), "select_traj")

@@ -1,0 +1,65 @@
+"""Runtime plumbing around the HIP library: device check, hipGraph capture of a policy call, per-launch profiling.
+
+The policy engines issue thousands of short kernels per call (16 decoder layers x 11 passes + 2 ViTs); launched one by
+one from Python the call is host-bound (~100 us of interpreter + ctypes work per launch). Every engine call is
+therefore captured once into a hipGraph (torch.cuda.CUDAGraph is the HIP graph API on ROCm; our kernels are launched on
+torch's current stream, which is the capture stream) and replayed: the replay issues the whole launch sequence from the
+driver with no Python in the loop. Inputs live in static device buffers that are overwritten before a replay.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict
+
+import torch
+
+from . import _lib
+
+PROF_KINDS = ("gemm", "attention", "norm", "elementwise")
+
+
+def require_gfx950() -> str:
+    """Fail loudly unless the HIP library is built AND the current device is an MI355X-class gfx950 GPU (no fallback path)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("internnav_amd needs a HIP device (MI355X / gfx950); there is no CPU path")
+    buf = C.create_string_buffer(64)
+    _lib.check(_lib.lib().ina_device_check(buf, 64), "device_check")
+    return buf.value.decode()
+
+
+class GraphedCall:
+    """Capture `fn(**static_inputs)` once and replay it. `fn` must only launch library kernels / torch copies on the current
+    stream and write its results into persistent buffers (all engines in this package do)."""
+
+    def __init__(self, fn: Callable, static_inputs: Dict[str, torch.Tensor], warmup: int = 2):
+        self.inputs = static_inputs
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # also performs the one-time hipFuncSetAttribute calls outside the capture
+                fn(**static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn(**static_inputs)
+
+    def __call__(self, **new_inputs):
+        for k, v in new_inputs.items():
+            self.inputs[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.outputs
+
+
+def prof_enable(on: bool) -> None:
+    _lib.check(_lib.lib().ina_prof_enable(1 if on else 0), "prof_enable")
+
+
+def prof_read() -> Dict[str, dict]:
+    """Totals per kernel class since prof_enable(True): summed event-pair time (ms), launches, algorithmic FLOPs and bytes."""
+    out = {}
+    for k, name in enumerate(PROF_KINDS):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().ina_prof_read(k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "prof_read")
+        out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out

@@ -1,0 +1,221 @@
+"""Seeded synthetic state-dicts (the reference's parameter names and shapes) and synthetic inputs.
+
+No checkpoint exists offline, so parity tests, smoke() and bench.py run on seeded random weights at the
+true architecture shapes ("data": "synthetic" in the bench line). The key tables below are written from the reference
+constructors (cited per function) and are checked against the real modules' `state_dict()` by `oracle/make_golden.py`
+(strict key/shape comparison). Host-side only (torch CPU generators); the engines upload the tensors themselves.
+
+Initialisation is "active" rather than the reference's N(0, 0.02) default: every Linear has unit gain
+(std = fan_in^-0.5), biases / norm affine terms / LayerScale are perturbed, so that every branch of every block
+contributes O(1) to the residual stream and a wrong kernel cannot hide under the tolerance. Each tensor is drawn from
+its own generator seeded by crc32(key) ^ seed (order independent) and rounded to bf16-representable values, so the
+fp32 oracle and the bf16 HIP engine consume bit-identical parameters.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Tuple
+
+import torch
+
+Spec = Dict[str, Tuple[tuple, str]]
+
+
+def _draw(key: str, shape, kind: str, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    r = torch.randn(shape, generator=g, dtype=torch.float32)
+    if kind == "w":  # [out, in, ...] unit-gain linear / conv weight
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        t = r * fan_in ** -0.5
+    elif kind == "w_small":  # projections whose input is not normalised (K/V of raw memory, heads)
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        t = r * 0.5 * fan_in ** -0.5
+    elif kind == "b":
+        t = r * 0.1
+    elif kind == "ln_w":
+        t = 1.0 + 0.1 * r
+    elif kind == "ln_b":
+        t = 0.1 * r
+    elif kind == "emb":
+        t = 0.3 * r
+    elif kind == "gamma":
+        t = 0.5 + 0.1 * r
+    elif kind == "gate":
+        t = 0.5 * r
+    elif kind == "latent":
+        t = r
+    else:
+        raise ValueError(kind)
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def materialize(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
+    return {k: _draw(k, shape, kind, seed) for k, (shape, kind) in spec.items()}
+
+
+# ------------------------------------------------------------------------------------------------------ spec builders
+def _lin(spec: Spec, p: str, out_f: int, in_f: int, bias: bool = True, kind: str = "w"):
+    spec[p + ".weight"] = ((out_f, in_f), kind)
+    if bias:
+        spec[p + ".bias"] = ((out_f,), "b")
+
+
+def _ln(spec: Spec, p: str, d: int, bias: bool = True):
+    spec[p + ".weight"] = ((d,), "ln_w")
+    if bias:
+        spec[p + ".bias"] = ((d,), "ln_b")
+
+
+def _mha(spec: Spec, p: str, d: int):
+    """nn.MultiheadAttention parameters."""
+    spec[p + ".in_proj_weight"] = ((3 * d, d), "w")
+    spec[p + ".in_proj_bias"] = ((3 * d,), "b")
+    _lin(spec, p + ".out_proj", d, d)
+
+
+def dinov2_vits_spec(p: str = "") -> Spec:
+    """DINOv2('vits') (depth_anything_v2/dinov2.py:399-411): 22.06 M parameters."""
+    s: Spec = {}
+    D = 384
+    s[p + "cls_token"] = ((1, 1, D), "emb")
+    s[p + "pos_embed"] = ((1, 37 * 37 + 1, D), "emb")
+    s[p + "mask_token"] = ((1, D), "emb")
+    s[p + "patch_embed.proj.weight"] = ((D, 3, 14, 14), "w")
+    s[p + "patch_embed.proj.bias"] = ((D,), "b")
+    for i in range(12):
+        b = f"{p}blocks.{i}"
+        _ln(s, b + ".norm1", D)
+        _lin(s, b + ".attn.qkv", 3 * D, D)
+        _lin(s, b + ".attn.proj", D, D)
+        s[b + ".ls1.gamma"] = ((D,), "gamma")
+        _ln(s, b + ".norm2", D)
+        _lin(s, b + ".mlp.fc1", 4 * D, D)
+        _lin(s, b + ".mlp.fc2", D, 4 * D)
+        s[b + ".ls2.gamma"] = ((D,), "gamma")
+    _ln(s, p + "norm", D)
+    return s
+
+
+def decoder_layer_spec(p: str, d: int, ffn: int) -> Spec:
+    """nn.TransformerDecoderLayer parameters."""
+    s: Spec = {}
+    _mha(s, p + ".self_attn", d)
+    _mha(s, p + ".multihead_attn", d)
+    _lin(s, p + ".linear1", ffn, d)
+    _lin(s, p + ".linear2", d, ffn)
+    for n in ("norm1", "norm2", "norm3"):
+        _ln(s, f"{p}.{n}", d)
+    return s
+
+
+def encoder_layer_spec(p: str, d: int, ffn: int) -> Spec:
+    s: Spec = {}
+    _mha(s, p + ".self_attn", d)
+    _lin(s, p + ".linear1", ffn, d)
+    _lin(s, p + ".linear2", d, ffn)
+    for n in ("norm1", "norm2"):
+        _ln(s, f"{p}.{n}", d)
+    return s
+
+
+def rgbd_backbone_spec(p: str, memory_size: int, token_dim: int, dat: bool) -> Spec:
+    """RGBDBackbone (navdp_backbone.py:205-246) or, dat=True, DAT_RGBD_Patch_Backbone version>0 (:102-149)."""
+    s: Spec = {}
+    s.update(dinov2_vits_spec(p + "rgb_model."))
+    s.update(dinov2_vits_spec(p + "depth_model."))
+    if dat:
+        s[p + "former_query.weight"] = ((memory_size * 16, 384), "emb")
+        s[p + "former_pe.weight"] = ((memory_size * 2 * 256, 384), "emb")
+    else:
+        s[p + "former_query.position_embedding.weight"] = ((memory_size * 16, 384), "emb")
+        s[p + "former_pe.position_embedding.weight"] = (((memory_size + 1) * 256, 384), "emb")
+    for i in range(2):
+        s.update(decoder_layer_spec(f"{p}former_net.layers.{i}", 384, 2048))
+    _lin(s, p + "project_layer", token_dim, 384)
+    return s
+
+
+NAVDPNET_CFG = dict(image_size=224, memory_size=8, predict_size=24, temporal_depth=16, heads=8, token_dim=384,
+                    num_train_timesteps=10, sample_num=32)
+"""NavDPNet hyper-parameters of BASELINE config #2 (scripts/train/base_train/configs/navdp.py:58-63; DDPM 10 steps navdp_policy.py:119-121)."""
+
+N1_NAVDP_CFG = dict(image_size=224, memory_size=2, predict_size=32, temporal_depth=16, heads=8, token_dim=384,
+                    vlm_token_dim=3584, num_train_timesteps=20, sample_num=32)
+"""NavDP_Policy_DPT_CriticSum_DAT defaults (internvla_n1/navdp.py:17-34) as built by build_navdp (internvla_n1_arch.py:10-15)."""
+
+
+def navdpnet_spec(cfg=NAVDPNET_CFG) -> Spec:
+    """NavDPNet parameters used by the point-goal inference path (navdp_policy.py:67-133); the image/pixel goal encoders
+    and aux heads exist in the reference module but are not on this path and are left at their own initialisation."""
+    D, M, T = cfg["token_dim"], cfg["memory_size"], cfg["predict_size"]
+    s: Spec = {}
+    s.update(rgbd_backbone_spec("rgbd_encoder.", M, D, dat=False))
+    _lin(s, "point_encoder", D, 3)
+    for i in range(cfg["temporal_depth"]):
+        s.update(decoder_layer_spec(f"decoder.layers.{i}", D, 4 * D))
+    _lin(s, "input_embed", D, 3)
+    s["cond_pos_embed.position_embedding.weight"] = ((M * 16 + 4, D), "emb")
+    s["out_pos_embed.position_embedding.weight"] = ((T, D), "emb")
+    _ln(s, "layernorm", D)
+    _lin(s, "action_head", 3, D, kind="w_small")
+    _lin(s, "critic_head", 1, D)
+    return s
+
+
+def n1_navdp_spec(cfg=N1_NAVDP_CFG) -> Spec:
+    """NavDP_Policy_DPT_CriticSum_DAT parameters on the navdp_async inference path (internvla_n1/navdp.py:52-108)."""
+    D, M, T, V = cfg["token_dim"], cfg["memory_size"], cfg["predict_size"], cfg["vlm_token_dim"]
+    s: Spec = {}
+    s.update(rgbd_backbone_spec("rgbd_encoder.", M, D, dat=True))
+    for i in range(cfg["temporal_depth"]):
+        s.update(decoder_layer_spec(f"decoder.layers.{i}", D, 4 * D))
+    _lin(s, "input_embed", D, 3)
+    s["cond_pos_embed"] = ((1, M * 16 + 2, D), "emb")
+    s["out_pos_embed"] = ((1, T, D), "emb")
+    _ln(s, "layernorm", D)
+    _lin(s, "action_head", 3, D, kind="w_small")
+    _lin(s, "vlm_embed_mlp.0", V // 4, V)
+    _lin(s, "vlm_embed_mlp.2", V // 8, V // 4)
+    _lin(s, "vlm_embed_mlp.4", D, V // 8)
+    s["goal_compressor.target_embedding.weight"] = ((1, D), "emb")
+    s["goal_compressor.token_positional_encoding.position_embedding.weight"] = ((5000, D), "emb")
+    s["goal_compressor.query_positional_encoding.position_embedding.weight"] = ((5000, D), "emb")
+    _mha(s, "goal_compressor.cross_attention", D)
+    return s
+
+
+def navdpnet_state_dict(seed: int = 0, cfg=NAVDPNET_CFG):
+    return materialize(navdpnet_spec(cfg), seed)
+
+
+def n1_navdp_state_dict(seed: int = 0, cfg=N1_NAVDP_CFG):
+    return materialize(n1_navdp_spec(cfg), seed)
+
+
+# ------------------------------------------------------------------------------------------------------ synthetic inputs
+def navdpnet_inputs(B: int, seed: int = 0, cfg=NAVDPNET_CFG):
+    """Synthetic config-#2 inputs: point goal, memory_size RGB frames in 0..1, one depth frame in metres
+    (clipped to 5 m), initial noise and the per-step DDPM noise, all from a CPU generator."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    M, T, S, K = cfg["memory_size"], cfg["predict_size"], cfg["sample_num"], cfg["num_train_timesteps"]
+    goal = torch.randn(B, 3, generator=g) * torch.tensor([3.0, 3.0, 0.5])
+    images = torch.rand(B, M, 224, 224, 3, generator=g)
+    depths = torch.rand(B, 1, 224, 224, 1, generator=g) * 5.0
+    x_init = torch.randn(B, S, T, 3, generator=g)
+    step_noise = torch.randn(K, B, S, T, 3, generator=g)
+    return dict(goal=goal, images=images, depths=depths, x_init=x_init, step_noise=step_noise)
+
+
+def n1_navdp_inputs(B: int, seed: int = 0, cfg=N1_NAVDP_CFG):
+    g = torch.Generator().manual_seed(2000 + seed)
+    M, T, S, K = cfg["memory_size"], cfg["predict_size"], cfg["sample_num"], cfg["num_train_timesteps"]
+    vlm = torch.randn(B, 4, cfg["vlm_token_dim"], generator=g).to(torch.bfloat16).float()
+    images = torch.rand(B, M, 224, 224, 3, generator=g)
+    depths = torch.rand(B, M, 224, 224, 1, generator=g) * 5.0
+    x_init = torch.randn(B, S, T, 3, generator=g)
+    step_noise = torch.randn(K, B, S, T, 3, generator=g)
+    return dict(vlm_tokens=vlm, images=images, depths=depths, x_init=x_init, step_noise=step_noise)

@@ -96,7 +96,10 @@ def gold_navdpnet(B=2):
         o_neg, o_pos, o_fin, o_cr, o_rgbd = o_navdp.navdpnet_pointgoal(sd, inp["goal"], inp["images"], inp["depths"],
                                                                      inp["x_init"], inp["step_noise"], cfg, return_all=True)
     d = max((neg - o_neg).abs().max().item(), (pos - o_pos).abs().max().item(), (rgbd - o_rgbd).abs().max().item())
-    return dict(B=B, seed=0, negative=neg, positive=pos, rgbd_embed=rgbd, oracle_max_abs_diff=d)
+    # the reference returns only the ranked trajectories; the final samples and critic values (continuous quantities the
+    # ranking is a discontinuous function of) are stored from the oracle, which the lines above pin to the reference.
+    return dict(B=B, seed=0, negative=neg, positive=pos, rgbd_embed=rgbd, oracle_final=o_fin, oracle_critic=o_cr,
+                oracle_max_abs_diff=d)
 
 
 def gold_n1_navdp(B=2):

@@ -31,9 +31,18 @@ def test_library_exports_every_symbol(built_lib):
 
 
 def test_struct_sizes_match_header(built_lib):
-    """ctypes mirrors must have the C layout (checked against sizes the library reports)."""
+    """ctypes mirrors must have exactly the compiled C layout (ina_struct_size reports sizeof of each argument struct)."""
     from internnav_amd import _lib
 
-    assert ctypes.sizeof(_lib.GemmArgs) == 7 * 8 + 13 * 4 + 4 * 8 + 2 * 4 + (4 if (7 * 8 + 13 * 4) % 8 else 0)
-    assert ctypes.sizeof(_lib.AttnArgs) % 8 == 0
-    assert ctypes.sizeof(_lib.NormArgs) % 8 == 0
+    mirrors = [_lib.GemmArgs, _lib.AttnArgs, _lib.NormArgs, _lib.PatchifyArgs, _lib.Embed3Args, _lib.Head3Args,
+               _lib.SeqpoolArgs, _lib.SelectArgs]
+    for k, m in enumerate(mirrors):
+        assert ctypes.sizeof(m) == _lib.lib().ina_struct_size(k), f"struct {k} ({m.__name__}) layout mismatch"
+    assert _lib.lib().ina_struct_size(len(mirrors)) == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under internnav_amd/ may import it (no CPU fallback on the product path)."""
+    for f in (ROOT / "internnav_amd").rglob("*.py"):
+        src = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"

@@ -1,0 +1,120 @@
+"""GPU parity of the NavDP System-1 engines (internnav_amd.navdp) against the golden outputs of the REAL reference
+modules (tests/golden, produced by oracle/make_golden.py) and against the CPU oracle on further seeded cases.
+
+Tolerance: the engines compute in bf16 on MFMA with fp32 accumulation and an fp32 residual stream; the reference
+fixtures are fp32. BASELINE.json asks for 1e-3 "bf16 tolerance" on waypoints: we check the waypoint error normalised by
+the waypoint range (samples live in [-1, 1]) - mean abs error <= 1e-3 and a max-abs bound that covers bf16 operand
+rounding (2^-9 relative per operand) amplified through 12 ViT + 2 former + 16 decoder layers x 10-20 sampler steps.
+"""
+import pytest
+import torch
+
+from oracle import dinov2 as o_dino
+from oracle import navdp as o_navdp
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stats(out, ref):
+    d = (out.float().cpu() - ref.float().cpu()).abs()
+    return d.mean().item(), d.max().item(), ref.abs().max().item()
+
+
+def _gold(name):
+    from pathlib import Path
+
+    return torch.load(Path(__file__).resolve().parent / "golden" / f"{name}.pt", weights_only=True)
+
+
+def test_dinov2_encoder_vs_reference_fixture(built_lib):
+    from internnav_amd.vit_s import DinoV2Encoder, VitWorkspace
+
+    gold = _gold("dinov2")
+    sd = W.materialize(W.dinov2_vits_spec(), seed=gold["seed"])
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(gold["img_seed"]))
+    enc = DinoV2Encoder(sd, "", DEV)
+    ws = VitWorkspace(2, DEV)
+    out = torch.empty(2 * 256, 384, dtype=torch.bfloat16, device=DEV)
+    enc.forward(img.permute(0, 2, 3, 1).contiguous().to(DEV), ws, out)
+    mean, mx, ref = _stats(out.view(2, 256, 384), gold["tokens"])
+    print(f"dinov2: mean|err| {mean:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert mean < 1.5e-2 and mx < 0.25
+
+
+def test_navdpnet_vs_reference_fixture(built_lib):
+    """BASELINE config #2 path: NavDPNet point-goal, 10 DDPM steps, 32 samples/env, critic ranking - B = 2 envs in one call."""
+    from internnav_amd.navdp import NavDPNet
+
+    gold = _gold("navdpnet")
+    B = gold["B"]
+    sd = W.navdpnet_state_dict(seed=gold["seed"])
+    inp = {k: v.to(DEV) for k, v in W.navdpnet_inputs(B, seed=gold["seed"]).items()}
+    net = NavDPNet(sd, W.NAVDPNET_CFG, DEV, max_envs=B)
+    neg, pos = net.predict_pointgoal_batch_action_vel(inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
+    torch.cuda.synchronize()
+    rg = net.cond[: B * net.Lc].view(B, net.Lc, 384)[:, 4:] .float().cpu() - net.cond_pos[4:].cpu()
+    m, mx, ref = _stats(rg, gold["rgbd_embed"])
+    print(f"rgbd_embed: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert m < 2e-2
+    S, T = net.S, net.T
+    # continuous quantities: the 32 denoised samples per env (waypoint increments in [-1, 1]) and their critic values
+    fin = net.sample[: B * S * T].view(B, S, T, 3)
+    m, mx, ref = _stats(fin, gold["oracle_final"])
+    print(f"final samples: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert m < 1e-3 and mx < 5e-2
+    cr = net.critic[: B * S].view(B, S).float().cpu()
+    m, mx, ref = _stats(cr, gold["oracle_critic"])
+    print(f"critic: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert mx < 5e-2 * max(ref, 1.0)
+    # ranking (discontinuous): wherever the reference's top-8 / bottom-8 boundary is separated by more than twice our
+    # critic error, the selected sets must be identical and the trajectories must match to waypoint tolerance.
+    gc = gold["oracle_critic"]
+    for b in range(B):
+        order = gc[b].argsort()
+        for name, out, idx_ref, gap in (("negative", neg, order[:8], gc[b][order[8]] - gc[b][order[7]]),
+                                        ("positive", pos, order.flip(0)[:8], gc[b][order[-8]] - gc[b][order[-9]])):
+            mine = cr[b].argsort()[:8] if name == "negative" else (-cr[b]).argsort()[:8]
+            if gap > 2 * mx:
+                assert set(mine.tolist()) == set(idx_ref.tolist()), f"env {b} {name}: selected set differs"
+            if torch.equal(mine, idx_ref):
+                m2, mx2, _ = _stats(out[b], gold[name][b])
+                print(f"env {b} {name}: same ranking, trajectory mean|err| {m2:.3e} max|err| {mx2:.3e}")
+                assert m2 < 5e-3 and mx2 < 1e-1  # cumulative sums of 24 waypoints
+    # our own selection is exactly consistent with our own critic values and samples
+    traj = torch.cumsum(fin.float().cpu() / 4.0, dim=2)
+    for b in range(B):
+        assert torch.allclose(neg[b].cpu(), traj[b][cr[b].argsort()[:8]], atol=1e-5)
+        assert torch.allclose(pos[b].cpu(), traj[b][(-cr[b]).argsort()[:8]], atol=1e-5)
+
+
+def test_n1_navdp_head_vs_reference_fixture(built_lib):
+    from internnav_amd.navdp import NavDPPolicyDAT
+
+    gold = _gold("n1_navdp")
+    B = gold["B"]
+    sd = W.n1_navdp_state_dict(seed=gold["seed"])
+    inp = W.n1_navdp_inputs(B, seed=gold["seed"])
+    net = NavDPPolicyDAT(sd, W.N1_NAVDP_CFG, DEV, max_envs=B)
+    out = net.predict_pointgoal_action_async(inp["vlm_tokens"].to(DEV, torch.bfloat16), inp["images"].to(DEV), inp["depths"].to(DEV),
+                                             inp["x_init"].to(DEV), inp["step_noise"].to(DEV))
+    m, mx, ref = _stats(out, gold["trajectories"])
+    print(f"n1 navdp trajectories: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert m < 3e-3 and mx < 1e-1
+
+
+def test_navdpnet_batch_invariance(built_lib):
+    """env b of a B = 3 call == the same env run alone (the reference's batch-1 semantics hold per env in the batched engine)."""
+    from internnav_amd.navdp import NavDPNet
+
+    sd = W.navdpnet_state_dict(seed=5)
+    inp = {k: v.to(DEV) for k, v in W.navdpnet_inputs(3, seed=5).items()}
+    net = NavDPNet(sd, W.NAVDPNET_CFG, DEV, max_envs=3)
+    neg3, pos3 = net.predict_pointgoal_batch_action_vel(inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
+    neg3, pos3 = neg3.clone(), pos3.clone()
+    b = 1
+    neg1, pos1 = net.predict_pointgoal_batch_action_vel(inp["goal"][b:b + 1].contiguous(), inp["images"][b:b + 1].contiguous(),
+                                                        inp["depths"][b:b + 1].contiguous(), inp["x_init"][b:b + 1].contiguous(),
+                                                        inp["step_noise"][:, b:b + 1].contiguous())
+    assert torch.equal(neg3[b], neg1[0]) and torch.equal(pos3[b], pos1[0])

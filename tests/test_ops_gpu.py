@@ -208,11 +208,12 @@ def test_attention_gate_and_accumulate(ops):
     _close(out, ref, atol=2e-2)
 
 
-@pytest.mark.parametrize("rows,C", [(1000, 384), (77, 768), (300, 1280), (50, 3584), (9, 5120), (1, 8)])
+@pytest.mark.parametrize("rows,C", [(1000, 384), (77, 768), (300, 1280), (50, 3584), (9, 5120), (1, 8), (333, 64), (90, 256)])
 @pytest.mark.parametrize("rms", [False, True])
-def test_norm_plain(ops, rows, C, rms):
+@pytest.mark.parametrize("xf32", [False, True])
+def test_norm_plain(ops, rows, C, rms, xf32):
     g = torch.Generator().manual_seed(rows + C)
-    x = _rand((rows, C), g, scale=2.0)
+    x = _rand((rows, C), g, scale=2.0, dtype=torch.float32 if xf32 else torch.bfloat16)
     gamma, beta = torch.randn(C, generator=g).to(_dev()), torch.randn(C, generator=g).to(_dev())
     if rms:
         out = ops.norm(x, gamma=gamma, eps=1e-6, rms=True)
@@ -224,22 +225,136 @@ def test_norm_plain(ops, rows, C, rms):
     _close(out, ref)
 
 
-def test_norm_residual_modulation_gate(ops):
+def test_norm_modulation_gate_base_f32(ops):
+    """NextDiT forms: norm(x) * gamma * (1 + scale[b]) and base + tanh(gate[b]) * norm(x) * gamma, f32 stream in/out."""
     g = torch.Generator().manual_seed(21)
     B, T, C = 6, 32, 384
-    x, r, base = _rand((B * T, C), g), _rand((B * T, C), g), _rand((B * T, C), g)
+    x = _rand((B * T, C), g, dtype=torch.float32)
+    base = _rand((B * T, C), g, dtype=torch.float32)
     gamma = torch.randn(C, generator=g).to(_dev())
     emb = torch.randn(B, 4 * C, generator=g).to(_dev())
-    s = torch.empty_like(x)
-    out = ops.norm(x, gamma=gamma, eps=1e-5, rms=True, residual=r, sum_out=s, mod_scale=emb[:, :C], mod_div=T)
-    xs = x.float() + r.float()
-    _close(s, xs)
-    nrm = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
+    out = ops.norm(x, gamma=gamma, eps=1e-5, rms=True, mod_scale=emb[:, :C], mod_div=T)
+    nrm = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
     _close(out, nrm * (1 + emb[:, :C].repeat_interleave(T, 0)))
-    out2 = ops.norm(x, gamma=gamma, eps=1e-5, rms=True, gate=emb[:, C:2 * C], gate_base=base, mod_div=T)
-    xf = x.float()
-    nrm2 = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma
-    _close(out2, base.float() + torch.tanh(emb[:, C:2 * C]).repeat_interleave(T, 0) * nrm2)
+    out32 = torch.empty_like(x)
+    outb = torch.empty(B * T, C, dtype=torch.bfloat16, device=_dev())
+    ops.norm(x, gamma=gamma, eps=1e-5, rms=True, gate=emb[:, C:2 * C], base=base, mod_div=T, out=outb, out32=out32)
+    ref = base + torch.tanh(emb[:, C:2 * C]).repeat_interleave(T, 0) * nrm
+    _close(out32, ref, rtol=1e-5, atol=1e-5)
+    _close(outb, ref)
+    # in place on the f32 stream (how the engines use it)
+    xin = x.clone()
+    ops.norm(xin, gamma=gamma, eps=1e-5, rms=True, out32=xin)
+    _close(xin, nrm, rtol=1e-5, atol=1e-5)
+
+
+def test_norm_rowmaps_and_pos_table(ops):
+    """final ViT norm: drop the cls token (in_map), scatter frames into a [env, slot] token buffer (out_map), add a pos table."""
+    g = torch.Generator().manual_seed(5)
+    n, T, C, M = 6, 257, 384, 3  # 2 envs x 3 frames
+    x = _rand((n * T, C), g, dtype=torch.float32)
+    gamma, beta = torch.randn(C, generator=g).to(_dev()), torch.randn(C, generator=g).to(_dev())
+    pos = torch.randn(M * 256, C, generator=g).to(_dev())
+    nt = (M + 1) * 256
+    out = torch.zeros(2 * nt, C, dtype=torch.bfloat16, device=_dev())
+    ops.norm(x, gamma, beta, eps=1e-6, out=out, rows=n * 256, in_map=(256, T, 1), out_map=(M * 256, nt, 0), pos=pos)
+    ref = torch.nn.functional.layer_norm(x.view(n, T, C)[:, 1:], (C,), gamma, beta, 1e-6).reshape(2, M * 256, C) + pos
+    _close(out.view(2, nt, C)[:, : M * 256], ref)
+    assert out.view(2, nt, C)[:, M * 256:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("C,dt", [(3, torch.float32), (1, torch.float32), (3, torch.bfloat16)])
+def test_patchify(ops, C, dt):
+    g = torch.Generator().manual_seed(C)
+    n = 3
+    img = torch.rand(n, 224, 224, C, generator=g).to(dt).to(_dev())
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    out = torch.empty(n * 256, 592, dtype=torch.bfloat16, device=_dev())
+    ops.patchify(img, out, mean, std)
+    x = img.float().permute(0, 3, 1, 2)
+    if C == 1:
+        x = x.repeat(1, 3, 1, 1)
+    x = (x - torch.tensor(mean, device=_dev()).view(1, 3, 1, 1)) / torch.tensor(std, device=_dev()).view(1, 3, 1, 1)
+    ref = torch.nn.functional.unfold(x, kernel_size=14, stride=14).transpose(1, 2).reshape(n * 256, 588)
+    _close(out[:, :588], ref, atol=1e-2)
+    assert out[:, 588:].abs().max().item() == 0
+
+
+def test_embed3_and_table_fill(ops):
+    g = torch.Generator().manual_seed(2)
+    rows, C, T = 96, 384, 24
+    x = torch.randn(rows, 3, generator=g).to(_dev())
+    w, b = torch.randn(C, 3, generator=g).to(_dev()), torch.randn(C, generator=g).to(_dev())
+    pos = torch.randn(T, C, generator=g).to(_dev())
+    out = torch.empty(rows, C, dtype=torch.float32, device=_dev())
+    ops.embed3(x, w, b, out=out, pos=pos)
+    ref = x @ w.t() + b + pos.repeat(rows // T, 1)
+    _close(out, ref, rtol=1e-5, atol=1e-5)
+    # scatter: one vector per env written to slot 2 of a [env, 5] bf16 buffer, broadcast fill of slot 0
+    buf = torch.zeros(4 * 5, C, dtype=torch.bfloat16, device=_dev())
+    ops.embed3(x[:4].contiguous(), w, b, out=buf, pos=pos[1:2], rows=4, out_map=(1, 5, 2))
+    ops.embed3(None, None, None, out=buf, pos=pos[3:4], rows=4, out_map=(1, 5, 0))
+    _close(buf.view(4, 5, C)[:, 2], x[:4] @ w.t() + b + pos[1])
+    _close(buf.view(4, 5, C)[:, 0], pos[3].expand(4, C))
+    assert buf.view(4, 5, C)[:, [1, 3, 4]].abs().max().item() == 0
+
+
+def test_head3_ddpm_and_euler(ops):
+    g = torch.Generator().manual_seed(9)
+    rows, C = 200, 384
+    x = _rand((rows, C), g, dtype=torch.float32)
+    gamma, beta = torch.randn(C, generator=g).to(_dev()), torch.randn(C, generator=g).to(_dev())
+    w, b = (torch.randn(3, C, generator=g) * C ** -0.5).to(_dev()), torch.randn(3, generator=g).to(_dev())
+    s0 = torch.randn(rows, 3, generator=g).to(_dev())
+    noise = torch.randn(rows, 3, generator=g).to(_dev())
+    e_ref = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5) @ w.t() + b
+    eps_out = torch.empty(rows, 3, device=_dev())
+    ops.head3(x, w, b, gamma, beta, mode=0, eps_out=eps_out)
+    _close(eps_out, e_ref, rtol=1e-4, atol=1e-4)
+    coef = (1.3, 0.7, 0.4, 0.55, 0.2)
+    s = s0.clone()
+    ops.head3(x, w, b, gamma, beta, mode=1, sample=s, noise=noise, coef=coef, clip=1.0)
+    x0 = ((s0 - coef[1] * e_ref) * coef[0]).clamp(-1, 1)
+    _close(s, coef[2] * x0 + coef[3] * s0 + coef[4] * noise, rtol=1e-4, atol=1e-4)
+    s = s0.clone()
+    ms = torch.randn(rows // 8, C, generator=g).to(_dev())
+    ops.head3(x, w, b, None, None, eps=1e-6, mode=2, sample=s, coef=(-0.1, 0, 0, 0, 0), mod_scale=ms, mod_div=8)
+    e2 = (torch.nn.functional.layer_norm(x, (C,), None, None, 1e-6) * (1 + ms.repeat_interleave(8, 0))) @ w.t() + b
+    _close(s, s0 - 0.1 * e2, rtol=1e-4, atol=1e-4)
+
+
+def test_seqpool_head_and_select_traj(ops):
+    g = torch.Generator().manual_seed(13)
+    B, S, T, C = 3, 32, 24, 384
+    x = _rand((B * S * T, C), g, dtype=torch.float32)
+    gamma, beta = torch.randn(C, generator=g).to(_dev()), torch.randn(C, generator=g).to(_dev())
+    w, b = (torch.randn(1, C, generator=g) * C ** -0.5).to(_dev()), torch.randn(1, generator=g).to(_dev())
+    critic = torch.empty(B * S, device=_dev())
+    ops.seqpool_head(x, T, gamma, beta, w, b, critic)
+    ref = (torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5).view(B * S, T, C).mean(1) @ w.t())[:, 0] + b
+    _close(critic, ref, rtol=1e-4, atol=1e-4)
+    sample = torch.randn(B, S, T, 3, generator=g).to(_dev())
+    neg, pos = torch.empty(B, 8, T, 3, device=_dev()), torch.empty(B, 8, T, 3, device=_dev())
+    cv = critic.view(B, S).contiguous()
+    ops.select_traj(cv, sample, neg, pos)
+    traj = torch.cumsum(sample / 4.0, dim=2)
+    for i in range(B):
+        _close(neg[i], traj[i][cv[i].argsort()[0:8]], rtol=1e-5, atol=1e-5)
+        _close(pos[i], traj[i][(-cv[i]).argsort()[0:8]], rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_batched_broadcast_residual(ops):
+    """patch-embed form: per-frame GEMM writing rows 1.. of a [frame, 257, C] f32 buffer, + a shared [256, C] table."""
+    g = torch.Generator().manual_seed(31)
+    n, K, C = 5, 592, 384
+    a = _rand((n, 256, K), g)
+    w = _rand((C, K), g, scale=K ** -0.5)
+    bias = torch.randn(C, generator=g).to(_dev())
+    pos = torch.randn(256, C, generator=g).to(_dev())
+    x = torch.zeros(n, 257, C, dtype=torch.float32, device=_dev())
+    ops.linear(a, w, bias=bias, residual=pos, out=x[:, 1:, :], batched=True)
+    _close(x[:, 1:], a.float() @ w.float().t() + bias + pos, rtol=1e-4, atol=2e-3)
+    assert x[:, 0].abs().max().item() == 0
 
 
 def test_bad_arguments_fail_loudly(ops):

@@ -1,0 +1,91 @@
+"""CPU: the oracle restatement against the golden fixtures produced by the REAL reference modules (oracle/make_golden.py).
+
+This is what pins the oracle (the reference ships no known-answer vectors of its own). The fixtures hold
+fp32 outputs of the reference's classes run in the build container on the seeded weights/inputs of oracle/weights.py.
+"""
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import dinov2 as o_dino
+from oracle import navdp as o_navdp
+from oracle import weights as W
+from oracle.schedulers import DDPMScheduler, FlowMatchEulerDiscreteScheduler
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def _load(name):
+    return torch.load(GOLD / f"{name}.pt", weights_only=True)
+
+
+def test_dinov2_matches_reference():
+    gold = _load("dinov2")
+    sd = W.materialize(W.dinov2_vits_spec(), seed=gold["seed"])
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(gold["img_seed"]))
+    with torch.no_grad():
+        out = o_dino.forward_tokens(img, sd)
+    assert out.shape == gold["tokens"].shape
+    assert (out - gold["tokens"]).abs().max().item() < 1e-4
+
+
+def test_navdpnet_matches_reference():
+    """NavDPNet.predict_pointgoal_batch_action_vel of the reference (batch-1 calls) == batched oracle, same injected noise."""
+    gold = _load("navdpnet")
+    B = gold["B"]
+    sd = W.navdpnet_state_dict(seed=gold["seed"])
+    inp = W.navdpnet_inputs(B, seed=gold["seed"])
+    with torch.no_grad():
+        neg, pos, fin, critic, rgbd = o_navdp.navdpnet_pointgoal(sd, inp["goal"], inp["images"], inp["depths"], inp["x_init"],
+                                                                 inp["step_noise"], W.NAVDPNET_CFG, return_all=True)
+    assert (rgbd - gold["rgbd_embed"]).abs().max().item() < 1e-4
+    assert (neg - gold["negative"]).abs().max().item() < 1e-4
+    assert (pos - gold["positive"]).abs().max().item() < 1e-4
+
+
+def test_n1_navdp_head_matches_reference():
+    gold = _load("n1_navdp")
+    B = gold["B"]
+    sd = W.n1_navdp_state_dict(seed=gold["seed"])
+    inp = W.n1_navdp_inputs(B, seed=gold["seed"])
+    with torch.no_grad():
+        out = o_navdp.n1_navdp_async(sd, inp["vlm_tokens"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"],
+                                     W.N1_NAVDP_CFG)
+    assert (out - gold["trajectories"]).abs().max().item() < 1e-4
+
+
+def test_ddpm_scheduler_known_properties():
+    """diffusers is absent (parity unpinned): check the restated DDPM against closed-form properties of the algorithm."""
+    for K in (10, 20):
+        s = DDPMScheduler(num_train_timesteps=K)
+        s.set_timesteps(K)
+        assert s.timesteps.tolist() == list(range(K - 1, -1, -1))
+        assert torch.all(s.betas > 0) and torch.all(s.betas <= 0.999)
+        assert abs(float(s.alphas_cumprod[0]) - (1 - float(s.betas[0]))) < 1e-7
+        # t = 0: no noise, x_prev = clipped x0 prediction
+        x = torch.randn(4, 3)
+        e = torch.randn(4, 3)
+        out = s.step(e, 0, x).prev_sample
+        a0 = s.alphas_cumprod[0]
+        assert torch.allclose(out, ((x - (1 - a0).sqrt() * e) / a0.sqrt()).clamp(-1, 1), atol=1e-6)
+        # posterior mean coefficients sum to the DDPM identity when eps is the true noise and no clipping is active
+        x0 = torch.rand(4, 3) * 0.5
+        t = K // 2
+        noise = torch.randn(4, 3)
+        xt = s.add_noise(x0, noise, torch.tensor([t]))
+        _, _, c0, ct, _ = s.coefficients(t)
+        mean = s.step(noise, t, xt, noise=torch.zeros(4, 3)).prev_sample
+        assert torch.allclose(mean, c0 * x0 + ct * xt, atol=1e-5)
+
+
+def test_flow_match_euler_scheduler():
+    import numpy as np
+
+    s = FlowMatchEulerDiscreteScheduler()
+    s.set_timesteps(10, sigmas=np.linspace(1.0, 0.1, 10))
+    assert torch.allclose(s.timesteps, torch.linspace(1000, 100, 10))
+    x = torch.ones(2, 3)
+    for t in s.timesteps:
+        x = s.step(torch.ones(2, 3), t, x).prev_sample
+    assert torch.allclose(x, torch.zeros(2, 3), atol=1e-6)  # integrates v = 1 from sigma 1 to 0
