@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -193,6 +193,18 @@ typedef struct ina_seqpool_args {
     int32_t nseq, T, C, ldx, x_dtype, _pad;
 } ina_seqpool_args;
 int ina_seqpool_head(const ina_seqpool_args* args, void* stream);
+
+/* ---- pool_act: Y[s, :] = act( mean_{t < T} X[s*T + t, :] + P[s % p_mod, :] )   (T = 1: bias + activation)
+ *      reference: masked mean of the caption features + SiLU(temb) (diffusers LuminaCombinedTimestepCaptionEmbedding,
+ *      LuminaRMSNormZero as used by nextdit_traj.py:109-119, 355). */
+typedef struct ina_pool_act_args {
+    const void* X;          /* bf16|f32 (x_dtype) [nseq*T, ldx] */
+    const float* P;         /* f32 [p_mod, C] or NULL */
+    void* Y;                /* bf16|f32 (out_dtype) [nseq, ldy] */
+    int32_t nseq, T, C, ldx, ldy, p_mod;
+    int32_t x_dtype, out_dtype, act, _pad;
+} ina_pool_act_args;
+int ina_pool_act(const ina_pool_act_args* args, void* stream);
 
 /* ---- select_traj: per env, rank the S samples by critic value; neg = the k lowest (ascending), pos = the k highest
  *      (descending); trajectories are cumsum_t(sample * scale).  reference: navdp_policy.py:317-320. */

@@ -97,6 +97,14 @@ class SeqpoolArgs(C.Structure):
     ]
 
 
+class PoolActArgs(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("P", c_void_p), ("Y", c_void_p),
+        ("nseq", c_int32), ("T", c_int32), ("C", c_int32), ("ldx", c_int32), ("ldy", c_int32), ("p_mod", c_int32),
+        ("x_dtype", c_int32), ("out_dtype", c_int32), ("act", c_int32), ("_pad", c_int32),
+    ]
+
+
 class SelectArgs(C.Structure):
     _fields_ = [
         ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
@@ -118,6 +126,7 @@ SYMBOLS = {
     "ina_head3": (C.c_int, [C.POINTER(Head3Args), c_void_p]),
     "ina_seqpool_head": (C.c_int, [C.POINTER(SeqpoolArgs), c_void_p]),
     "ina_select_traj": (C.c_int, [C.POINTER(SelectArgs), c_void_p]),
+    "ina_pool_act": (C.c_int, [C.POINTER(PoolActArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),
     "ina_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -102,7 +102,7 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
 }
 
 /* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify,
- * 4 embed3, 5 head3, 6 seqpool, 7 select */
+ * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act */
 int ina_struct_size(int k) {
     switch (k) {
         case 0: return (int)sizeof(ina_gemm_args);
@@ -113,6 +113,7 @@ int ina_struct_size(int k) {
         case 5: return (int)sizeof(ina_head3_args);
         case 6: return (int)sizeof(ina_seqpool_args);
         case 7: return (int)sizeof(ina_select_args);
+        case 8: return (int)sizeof(ina_pool_act_args);
         default: return -1;
     }
 }
@@ -127,6 +128,7 @@ INA_ENTRY(ina_embed3, ina_embed3_args, ina_launch_embed3)
 INA_ENTRY(ina_head3, ina_head3_args, ina_launch_head3)
 INA_ENTRY(ina_seqpool_head, ina_seqpool_args, ina_launch_seqpool)
 INA_ENTRY(ina_select_traj, ina_select_args, ina_launch_select)
+INA_ENTRY(ina_pool_act, ina_pool_act_args, ina_launch_pool_act)
 #undef INA_ENTRY
 
 }  // extern "C"

@@ -250,7 +250,38 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ pool_act
+__global__ __launch_bounds__(256) void pool_act_kernel(PoolActArgs p) {
+    const long total = (long)p.nseq * p.C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int s = (int)(i / p.C), c = (int)(i % p.C);
+        float a = 0.f;
+        for (int t = 0; t < p.T; ++t) {
+            const size_t o = ((size_t)s * p.T + t) * p.ldx + c;
+            a += p.x_dtype == INA_DT_F32 ? reinterpret_cast<const float*>(p.X)[o] : (float)reinterpret_cast<const bf16*>(p.X)[o];
+        }
+        a /= (float)p.T;
+        if (p.P) a += p.P[(size_t)(s % p.p_mod) * p.C + c];
+        a = ina_act(a, p.act);
+        const size_t o = (size_t)s * p.ldy + c;
+        if (p.out_dtype == INA_DT_F32) reinterpret_cast<float*>(p.Y)[o] = a;
+        else reinterpret_cast<bf16*>(p.Y)[o] = (bf16)a;
+    }
+}
+
 }  // namespace
+
+int ina_launch_pool_act(const PoolActArgs& p_in, hipStream_t stream) {
+    PoolActArgs p = p_in;
+    if (p.p_mod <= 0) p.p_mod = 1;
+    INA_REQUIRE(p.nseq > 0 && p.T > 0 && p.C > 0 && p.X && p.Y, "pool_act: bad arguments nseq=%d T=%d C=%d", p.nseq, p.T, p.C);
+    InaProfScope prof(INA_PROF_ELEMENTWISE, (double)p.nseq * p.T * p.C, (double)p.nseq * p.T * p.C * (p.x_dtype == INA_DT_F32 ? 4.0 : 2.0), stream);
+    const long total = (long)p.nseq * p.C;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pool_act_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int ina_launch_patchify(const PatchifyArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.n > 0 && p.ps > 0 && p.H % p.ps == 0 && p.W % p.ps == 0, "patchify: bad geometry n=%d H=%d W=%d ps=%d", p.n, p.H, p.W, p.ps);

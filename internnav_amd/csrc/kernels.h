@@ -16,6 +16,7 @@ using Embed3Args = ina_embed3_args;
 using Head3Args = ina_head3_args;
 using SeqpoolArgs = ina_seqpool_args;
 using SelectArgs = ina_select_args;
+using PoolActArgs = ina_pool_act_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
@@ -25,3 +26,4 @@ int ina_launch_embed3(const Embed3Args& p, hipStream_t stream);
 int ina_launch_head3(const Head3Args& p, hipStream_t stream);
 int ina_launch_seqpool(const SeqpoolArgs& p, hipStream_t stream);
 int ina_launch_select(const SelectArgs& p, hipStream_t stream);
+int ina_launch_pool_act(const PoolActArgs& p, hipStream_t stream);

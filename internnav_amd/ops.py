@@ -284,3 +284,19 @@ def select_traj(critic: torch.Tensor, sample: torch.Tensor, neg: torch.Tensor, p
     a.critic, a.sample, a.neg, a.pos = critic.data_ptr(), sample.data_ptr(), neg.data_ptr(), pos.data_ptr()
     a.scale, a.B, a.S, a.T, a.k = scale, B, S, T, k
     _lib.check(_lib.lib().ina_select_traj(C.byref(a), _stream()), "select_traj")
+
+
+def pool_act(x: torch.Tensor, out: torch.Tensor, T: int = 1, pos: Optional[torch.Tensor] = None, act=None) -> torch.Tensor:
+    """out[s] = act(mean_t x[s*T + t] + pos[s % len(pos)]); x bf16|f32 [nseq*T, C] -> out bf16|f32 [nseq, C]."""
+    x2, o2 = _as2d(x), _as2d(out)
+    a = _lib.PoolActArgs()
+    a.X, a.ldx, a.x_dtype = x2.data_ptr(), x2.stride(0), _DT[x2.dtype]
+    a.Y, a.ldy, a.out_dtype = o2.data_ptr(), o2.stride(0), _DT[o2.dtype]
+    a.nseq, a.T, a.C = x2.shape[0] // T, T, x2.shape[1]
+    assert o2.shape == (a.nseq, a.C)
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == a.C
+        a.P, a.p_mod = pos.data_ptr(), pos.numel() // a.C
+    a.act = ACT[act]
+    _lib.check(_lib.lib().ina_pool_act(C.byref(a), _stream()), "pool_act")
+    return out

@@ -188,6 +188,70 @@ def n1_navdp_spec(cfg=N1_NAVDP_CFG) -> Spec:
     return s
 
 
+N1_NEXTDIT_CFG = dict(n_query=4, vlm_token_dim=3584, latent_dim=768, dit_dim=384, dit_layers=12, dit_heads=6, dit_ffn=1024,
+                      predict_size=32, sample_num=32, num_inference_steps=10, memory_frames=2)
+"""DualVLN System-1 (`nextdit_async`): NextDiTCrossAttnConfig defaults (nextdit_crossattn_traj.py:12-30) with
+latent_embedding_size 768 (internvla_n1_arch.py:6,22), generate_traj defaults (internvla_n1.py:354-357)."""
+
+
+def n1_nextdit_spec(cfg=N1_NEXTDIT_CFG) -> Spec:
+    """System-1 parameters of InternVLAN1Model for system1 = 'nextdit_async' (internvla_n1_arch.py:127-141)."""
+    V, L, D = cfg["vlm_token_dim"], cfg["latent_dim"], cfg["dit_dim"]
+    s: Spec = {}
+    _lin(s, "cond_projector.0", L, V)
+    _lin(s, "cond_projector.2", L, L)
+    s.update(dinov2_vits_spec("rgb_model."))
+    s["memory_encoder.memory_pos"] = ((512, D), "emb")
+    for i in range(3):
+        s.update(encoder_layer_spec(f"memory_encoder.encoder.layers.{i}", D, 2048))
+    s["rgb_resampler.query_tokens"] = ((32, L), "latent")
+    s["rgb_resampler.query_pos"] = ((32, L), "emb")
+    for i in range(3):
+        s.update(decoder_layer_spec(f"rgb_resampler.decoder.layers.{i}", L, 2048))
+    _lin(s, "action_encoder", D, 3)
+    _lin(s, "action_decoder", 3, D, kind="w_small")
+    p = "traj_dit.model."
+    _lin(s, p + "caption_projection.linear_1", D, L)
+    _lin(s, p + "caption_projection.linear_2", D, D)
+    _lin(s, p + "time_caption_embed.timestep_embedder.linear_1", D, 256)
+    _lin(s, p + "time_caption_embed.timestep_embedder.linear_2", D, D)
+    _ln(s, p + "time_caption_embed.caption_embedder.0", D)
+    _lin(s, p + "time_caption_embed.caption_embedder.1", D, D)
+    for i in range(cfg["dit_layers"]):
+        b = f"{p}layers.{i}"
+        s[b + ".gate"] = ((cfg["dit_heads"],), "gate")
+        for a in ("attn1", "attn2"):
+            _ln(s, f"{b}.{a}.norm_q", D)
+            _ln(s, f"{b}.{a}.norm_k", D)
+            for n in ("to_q", "to_k", "to_v"):
+                _lin(s, f"{b}.{a}.{n}", D, D, bias=False)
+        _lin(s, b + ".attn2.to_out.0", D, D, bias=False)
+        _lin(s, b + ".feed_forward.linear_1", cfg["dit_ffn"], D, bias=False)
+        _lin(s, b + ".feed_forward.linear_2", D, cfg["dit_ffn"], bias=False)
+        _lin(s, b + ".feed_forward.linear_3", cfg["dit_ffn"], D, bias=False)
+        s[b + ".norm1.linear.weight"] = ((4 * D, D), "w_small")
+        s[b + ".norm1.linear.bias"] = ((4 * D,), "b")
+        for n in ("norm1.norm", "ffn_norm1", "norm2", "ffn_norm2", "norm1_context"):
+            _ln(s, f"{b}.{n}", D, bias=False)
+    s[p + "norm_out.linear_1.weight"] = ((D, D), "w_small")
+    s[p + "norm_out.linear_1.bias"] = ((D,), "b")
+    _lin(s, p + "norm_out.linear_2", D, D)
+    return s
+
+
+def n1_nextdit_state_dict(seed: int = 0, cfg=N1_NEXTDIT_CFG):
+    return materialize(n1_nextdit_spec(cfg), seed)
+
+
+def n1_nextdit_inputs(B: int, seed: int = 0, cfg=N1_NEXTDIT_CFG):
+    """traj_latents as produced by generate_latents (bf16 hidden states), 2 look-down frames in 0..1 (bf16 in the reference), init noise."""
+    g = torch.Generator().manual_seed(3000 + seed)
+    lat = torch.randn(B, cfg["n_query"], cfg["vlm_token_dim"], generator=g).to(torch.bfloat16).float()
+    images = torch.rand(B, cfg["memory_frames"], 224, 224, 3, generator=g).to(torch.bfloat16).float()
+    x_init = torch.randn(B, cfg["sample_num"], cfg["predict_size"], 3, generator=g)
+    return dict(traj_latents=lat, images=images, x_init=x_init)
+
+
 def navdpnet_state_dict(seed: int = 0, cfg=NAVDPNET_CFG):
     return materialize(navdpnet_spec(cfg), seed)
 

@@ -85,10 +85,12 @@ class DinoV2Encoder:
         self.grid = img_size // PATCH
         assert self.grid * self.grid == 256, "workspace layout assumes 224x224 frames (16x16 patches)"
 
-    def forward(self, frames: torch.Tensor, ws: VitWorkspace, out: torch.Tensor, out_map=None,
-                pos: Optional[torch.Tensor] = None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)) -> torch.Tensor:
+    def forward(self, frames: torch.Tensor, ws: VitWorkspace, out: Optional[torch.Tensor], out_map=None,
+                pos: Optional[torch.Tensor] = None, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), extra_outputs=()) -> torch.Tensor:
         """frames [n, 224, 224, C] (C = 3, or 1 replicated to 3 channels; f32 or bf16) -> bf16 patch tokens written to
-        `out` rows out_map(i*256 + p) (+ pos[(i*256+p) % len(pos)]); the cls token is dropped as in the reference."""
+        `out` rows out_map(i*256 + p) (+ pos[(i*256+p) % len(pos)]); the cls token is dropped as in the reference.
+        extra_outputs: further (out_bf16 | None, out_f32 | None, out_map, pos) destinations of the same final LayerNorm
+        (e.g. tokens + a positional table as the fp32 stream of the next module)."""
         n = frames.shape[0]
         assert n <= ws.n_max and frames.shape[1] == frames.shape[2] == self.img_size
         T = 257
@@ -107,5 +109,8 @@ class DinoV2Encoder:
             ops.norm(x, b["n2w"], b["n2b"], eps=1e-6, out=h)
             ops.linear(h, b["fc1_w"], bias=b["fc1_b"], act="gelu", out=mlp)
             ops.linear(mlp, b["fc2_w"], bias=b["fc2_b"], colscale=b["ls2"], residual=x, out=x)
-        ops.norm(x, self.norm_w, self.norm_b, eps=1e-6, out=out, rows=n * 256, in_map=(256, T, 1), out_map=out_map, pos=pos)
+        if out is not None:
+            ops.norm(x, self.norm_w, self.norm_b, eps=1e-6, out=out, rows=n * 256, in_map=(256, T, 1), out_map=out_map, pos=pos)
+        for (o16, o32, omap, opos) in extra_outputs:
+            ops.norm(x, self.norm_w, self.norm_b, eps=1e-6, out=o16, out32=o32, rows=n * 256, in_map=(256, T, 1), out_map=omap, pos=opos)
         return out

@@ -139,7 +139,72 @@ def gold_n1_navdp(B=2):
     return dict(B=B, seed=1, trajectories=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
 
 
-UNITS = {"dinov2": gold_dinov2, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_n1_nextdit(B=2):
+    """The reference's System-1 component modules (NextDiTCrossAttn incl. the in-tree LuminaNextDiTBlock wiring, MemoryEncoder,
+    QFormer, DINOv2) driven by a line-by-line transcription of generate_traj's nextdit_async branch (internvla_n1.py:359-432):
+    `InternVLAN1ForCausalLM` itself cannot be constructed here (it subclasses the transformers-4.51 Qwen2.5-VL layout)."""
+    import numpy as np
+    import torch.nn as nn
+
+    from . import nextdit as o_nd
+
+    nd, arch = R.nextdit_module(), R.n1_arch_module()
+    cfg = W.N1_NEXTDIT_CFG
+    sd = W.n1_nextdit_state_dict(seed=4)
+
+    class S1(nn.Module):  # attribute names of InternVLAN1MetaModel.__init__ (internvla_n1_arch.py:127-141)
+        def __init__(self):
+            super().__init__()
+            self.traj_dit = nd.NextDiTCrossAttn(nd.NextDiTCrossAttnConfig(latent_embedding_size=768))
+            self.action_encoder = nn.Linear(3, 384, bias=True)
+            self.pos_encoding = arch.SinusoidalPositionalEncoding(384)
+            self.action_decoder = nn.Linear(384, 3, bias=True)
+            self.cond_projector = nn.Sequential(nn.Linear(3584, 768), nn.GELU(approximate="tanh"), nn.Linear(768, 768))
+            self.rgb_model = R.dinov2_vits()
+            self.memory_encoder = arch.MemoryEncoder()
+            self.rgb_resampler = arch.QFormer()
+
+    m = _load_strict(S1(), sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.", "rgb_resampler.visual_proj."))
+    inp = W.n1_nextdit_inputs(B, seed=4)
+    from .schedulers import FlowMatchEulerDiscreteScheduler
+
+    mean = torch.FloatTensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)
+    std = torch.FloatTensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
+    outs = []
+    with torch.no_grad():
+        for b in range(B):
+            scheduler = FlowMatchEulerDiscreteScheduler()
+            traj_latents = m.cond_projector(inp["traj_latents"][b:b + 1])
+            images_dp = inp["images"][b:b + 1].permute(0, 1, 4, 2, 3)
+            images_dp_norm = (images_dp - mean) / std
+            feat = m.rgb_model.get_intermediate_layers(images_dp_norm.flatten(0, 1))[0].unflatten(dim=0, sizes=(1, -1))
+            memory_feat = m.memory_encoder(feat.flatten(1, 2))
+            memory_feat = torch.cat([feat.flatten(1, 2), memory_feat], dim=-1)
+            memory_tokens = m.rgb_resampler(memory_feat)
+            hidden_states = torch.cat([memory_tokens, traj_latents], dim=1)
+            hidden_states_input = torch.cat([torch.zeros_like(hidden_states), hidden_states], 0)
+            latents = inp["x_init"][b].clone()
+            sigmas = np.linspace(1.0, 1 / 10, 10)
+            scheduler.set_timesteps(10, sigmas=sigmas)
+            hidden_states_input = hidden_states_input.repeat_interleave(32, dim=0)
+            for t in scheduler.timesteps:
+                latent_features = m.action_encoder(latents)
+                pos_ids = torch.arange(latent_features.shape[1]).reshape(1, -1).repeat(1, 1)
+                latent_features += m.pos_encoding(pos_ids)
+                latent_model_input = latent_features.repeat(2, 1, 1)
+                noise_pred = m.traj_dit(x=latent_model_input, timestep=t.unsqueeze(0).expand(latent_model_input.shape[0]).to(torch.long),
+                                        z_latents=hidden_states_input)
+                noise_pred = m.action_decoder(noise_pred)
+                noise_pred_uncond, noise_pred = noise_pred.chunk(2)
+                noise_pred = noise_pred_uncond + 1.0 * (noise_pred - noise_pred_uncond)
+                latents = scheduler.step(noise_pred, t, latents).prev_sample
+            outs.append(latents)
+        ref = torch.stack(outs)
+        mine = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
+    return dict(B=B, seed=4, latents=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
+
+
+UNITS = {"dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

@@ -89,3 +89,16 @@ def test_flow_match_euler_scheduler():
     for t in s.timesteps:
         x = s.step(torch.ones(2, 3), t, x).prev_sample
     assert torch.allclose(x, torch.zeros(2, 3), atol=1e-6)  # integrates v = 1 from sigma 1 to 0
+
+
+def test_n1_nextdit_matches_reference():
+    """generate_traj (nextdit_async) driven through the reference's own NextDiT / MemoryEncoder / QFormer / DINOv2 modules."""
+    from oracle import nextdit as o_nd
+
+    gold = _load("n1_nextdit")
+    B = gold["B"]
+    sd = W.n1_nextdit_state_dict(seed=gold["seed"])
+    inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
+    with torch.no_grad():
+        out = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
+    assert (out - gold["latents"]).abs().max().item() < 1e-4
