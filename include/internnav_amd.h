@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -205,6 +205,54 @@ typedef struct ina_pool_act_args {
     int32_t x_dtype, out_dtype, act, _pad;
 } ina_pool_act_args;
 int ina_pool_act(const ina_pool_act_args* args, void* stream);
+
+/* ---- gather_rows: Y[dst ? dst[r] : r, :] = X[src ? src[r] : r, :]   (bit copy of `row_bytes` per row)
+ *      reference: embed_tokens lookup, masked_scatter of image embeds, latent_queries rows (internvla_n1.py:129-172),
+ *      the ViT window permutation and its inverse (transformers modeling_qwen2_5_vl.py:434-466). */
+typedef struct ina_gather_args {
+    const void* X;
+    void* Y;
+    const int32_t* src;     /* int32 [rows] or NULL */
+    const int32_t* dst;     /* int32 [rows] or NULL */
+    int64_t ldx_bytes, ldy_bytes;
+    int32_t rows, row_bytes; /* row_bytes multiple of 16 */
+} ina_gather_args;
+int ina_gather_rows(const ina_gather_args* args, void* stream);
+
+/* ---- rope: in-place rotary embedding of `heads` heads of width D starting at column `col0` of each row:
+ *      x' = x * cos + rotate_half(x) * sin with per-row tables cos/sin f32 [*, D] (row tab ? tab[r] : r).
+ *      reference: apply_rotary_pos_emb_vision / apply_multimodal_rotary_pos_emb (transformers modeling_qwen2_5_vl.py:160-171,557-599). */
+typedef struct ina_rope_args {
+    void* X;                /* bf16 rows, row stride ldx (elements) */
+    const float* cos;
+    const float* sin;
+    const int32_t* tab;     /* int32 [rows] table row per logical row, or NULL */
+    ina_rowmap map;         /* logical row -> physical row of X */
+    int32_t rows, heads, D, ldx, col0, _pad;
+} ina_rope_args;
+int ina_rope_bf16(const ina_rope_args* args, void* stream);
+
+/* ---- mrope_table: cos/sin [n, D] from the 3-D (t, h, w) position ids of Qwen2.5-VL: frequency f = j % (D/2) uses axis
+ *      axis_of[f] (mrope_section [16, 24, 24] -> 0 x16, 1 x24, 2 x24); angle = pos[axis][i] * inv_freq[f].
+ *      reference: Qwen2_5_VLRotaryEmbedding.forward + mrope interleave (modeling_qwen2_5_vl.py:525-538,582-590); position ids
+ *      from internnav/dataset/rope2d.py:6 (get_rope_index_25). */
+typedef struct ina_mrope_table_args {
+    const int32_t* pos;     /* int32 [3, n] */
+    const float* inv_freq;  /* f32 [D/2] */
+    const int32_t* axis_of; /* int32 [D/2] */
+    float* cos;             /* f32 [n, D] */
+    float* sin;
+    int32_t n, D;
+} ina_mrope_table_args;
+int ina_mrope_table(const ina_mrope_table_args* args, void* stream);
+
+/* ---- argmax_rows: out[r] = argmax_j X[r, j] (first maximum), greedy decoding (HF generate do_sample=False) */
+typedef struct ina_argmax_args {
+    const float* X;         /* f32 [rows, ldx] */
+    int32_t* out;           /* int32 [rows] */
+    int32_t rows, n, ldx, _pad;
+} ina_argmax_args;
+int ina_argmax_rows(const ina_argmax_args* args, void* stream);
 
 /* ---- select_traj: per env, rank the S samples by critic value; neg = the k lowest (ascending), pos = the k highest
  *      (descending); trajectories are cumsum_t(sample * scale).  reference: navdp_policy.py:317-320. */

@@ -105,6 +105,33 @@ class PoolActArgs(C.Structure):
     ]
 
 
+class GatherArgs(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("Y", c_void_p), ("src", c_void_p), ("dst", c_void_p),
+        ("ldx_bytes", c_int64), ("ldy_bytes", c_int64),
+        ("rows", c_int32), ("row_bytes", c_int32),
+    ]
+
+
+class RopeArgs(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("tab", c_void_p),
+        ("map", RowMap),
+        ("rows", c_int32), ("heads", c_int32), ("D", c_int32), ("ldx", c_int32), ("col0", c_int32), ("_pad", c_int32),
+    ]
+
+
+class MropeTableArgs(C.Structure):
+    _fields_ = [
+        ("pos", c_void_p), ("inv_freq", c_void_p), ("axis_of", c_void_p), ("cos", c_void_p), ("sin", c_void_p),
+        ("n", c_int32), ("D", c_int32),
+    ]
+
+
+class ArgmaxArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("out", c_void_p), ("rows", c_int32), ("n", c_int32), ("ldx", c_int32), ("_pad", c_int32)]
+
+
 class SelectArgs(C.Structure):
     _fields_ = [
         ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
@@ -127,6 +154,10 @@ SYMBOLS = {
     "ina_seqpool_head": (C.c_int, [C.POINTER(SeqpoolArgs), c_void_p]),
     "ina_select_traj": (C.c_int, [C.POINTER(SelectArgs), c_void_p]),
     "ina_pool_act": (C.c_int, [C.POINTER(PoolActArgs), c_void_p]),
+    "ina_gather_rows": (C.c_int, [C.POINTER(GatherArgs), c_void_p]),
+    "ina_rope_bf16": (C.c_int, [C.POINTER(RopeArgs), c_void_p]),
+    "ina_mrope_table": (C.c_int, [C.POINTER(MropeTableArgs), c_void_p]),
+    "ina_argmax_rows": (C.c_int, [C.POINTER(ArgmaxArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),
     "ina_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

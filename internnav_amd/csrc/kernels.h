@@ -17,6 +17,10 @@ using Head3Args = ina_head3_args;
 using SeqpoolArgs = ina_seqpool_args;
 using SelectArgs = ina_select_args;
 using PoolActArgs = ina_pool_act_args;
+using GatherArgs = ina_gather_args;
+using RopeArgs = ina_rope_args;
+using MropeTableArgs = ina_mrope_table_args;
+using ArgmaxArgs = ina_argmax_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
@@ -27,3 +31,7 @@ int ina_launch_head3(const Head3Args& p, hipStream_t stream);
 int ina_launch_seqpool(const SeqpoolArgs& p, hipStream_t stream);
 int ina_launch_select(const SelectArgs& p, hipStream_t stream);
 int ina_launch_pool_act(const PoolActArgs& p, hipStream_t stream);
+int ina_launch_gather(const GatherArgs& p, hipStream_t stream);
+int ina_launch_rope(const RopeArgs& p, hipStream_t stream);
+int ina_launch_mrope_table(const MropeTableArgs& p, hipStream_t stream);
+int ina_launch_argmax(const ArgmaxArgs& p, hipStream_t stream);

@@ -300,3 +300,53 @@ def pool_act(x: torch.Tensor, out: torch.Tensor, T: int = 1, pos: Optional[torch
     a.act = ACT[act]
     _lib.check(_lib.lib().ina_pool_act(C.byref(a), _stream()), "pool_act")
     return out
+
+
+def gather_rows(x: torch.Tensor, out: torch.Tensor, src: Optional[torch.Tensor] = None, dst: Optional[torch.Tensor] = None,
+                rows: Optional[int] = None) -> torch.Tensor:
+    """out[dst[r] or r] = x[src[r] or r] (2-D tensors of equal dtype / width, int32 index vectors on the device)."""
+    assert x.dim() == 2 and out.dim() == 2 and x.dtype == out.dtype and x.shape[1] == out.shape[1] and x.stride(1) == 1 and out.stride(1) == 1
+    a = _lib.GatherArgs()
+    es = x.element_size()
+    a.X, a.Y = x.data_ptr(), out.data_ptr()
+    a.ldx_bytes, a.ldy_bytes, a.row_bytes = x.stride(0) * es, out.stride(0) * es, x.shape[1] * es
+    for t in (src, dst):
+        assert t is None or (t.dtype == torch.int32 and t.is_contiguous())
+    a.src, a.dst = _ptr(src), _ptr(dst)
+    a.rows = rows if rows is not None else (src.numel() if src is not None else (dst.numel() if dst is not None else x.shape[0]))
+    _lib.check(_lib.lib().ina_gather_rows(C.byref(a), _stream()), "gather_rows")
+    return out
+
+
+def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, D: int, col0: int = 0, rows: Optional[int] = None,
+         row_map=None, tab: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """in-place rotary embedding on `heads` heads of width D at columns [col0, col0 + heads*D) of bf16 rows x[row_map(r)]."""
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == D
+    a = _lib.RopeArgs()
+    a.X, a.cos, a.sin, a.tab = x.data_ptr(), cos.data_ptr(), sin.data_ptr(), _ptr(tab)
+    a.map = _rowmap(row_map)
+    a.rows = rows if rows is not None else x.shape[0]
+    a.heads, a.D, a.ldx, a.col0 = heads, D, x.stride(0), col0
+    _lib.check(_lib.lib().ina_rope_bf16(C.byref(a), _stream()), "rope_bf16")
+    return x
+
+
+def mrope_table(pos: torch.Tensor, inv_freq: torch.Tensor, axis_of: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor):
+    """pos int32 [3, n] -> cos/sin f32 [n, D] of the multimodal rope (section axis per frequency in axis_of int32 [D/2])."""
+    assert pos.dtype == torch.int32 and pos.is_contiguous() and pos.shape[0] == 3
+    n, D = pos.shape[1], cos.shape[-1]
+    assert cos.is_contiguous() and sin.is_contiguous() and cos.numel() >= n * D and inv_freq.numel() == D // 2 and axis_of.dtype == torch.int32
+    a = _lib.MropeTableArgs()
+    a.pos, a.inv_freq, a.axis_of, a.cos, a.sin = pos.data_ptr(), _f32(inv_freq).data_ptr(), axis_of.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    a.n, a.D = n, D
+    _lib.check(_lib.lib().ina_mrope_table(C.byref(a), _stream()), "mrope_table")
+
+
+def argmax_rows(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[r] = argmax of f32 row r (first maximum), out int32 [rows]."""
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.int32 and out.numel() == x.shape[0]
+    a = _lib.ArgmaxArgs()
+    a.X, a.out, a.rows, a.n, a.ldx = x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0)
+    _lib.check(_lib.lib().ina_argmax_rows(C.byref(a), _stream()), "argmax_rows")
+    return out

@@ -252,6 +252,80 @@ def n1_nextdit_inputs(B: int, seed: int = 0, cfg=N1_NEXTDIT_CFG):
     return dict(traj_latents=lat, images=images, x_init=x_init)
 
 
+QWEN_N1_CFG = dict(v_hidden=1280, v_heads=16, v_inter=3420, v_depth=32, v_fullatt=(7, 15, 23, 31), v_window=112, v_patch=14,
+                   v_out=3584, t_hidden=3584, t_inter=18944, t_heads=28, t_kv_heads=4, t_layers=28, vocab=152064,
+                   rope_theta=1e6, n_query=4, image_token_id=151655, traj_token_id=151667, vision_start_id=151652,
+                   vision_end_id=151653, eos_token_id=151645)
+"""InternVLA-N1 System-2 = Qwen2.5-VL-7B dims (hidden 3584 hard-coded at internvla_n1_arch.py:133, navdp.py:25) with the token ids
+the reference hard-codes (internvla_n1.py:18-19)."""
+
+QWEN_TEST_CFG = dict(QWEN_N1_CFG, v_depth=2, v_fullatt=(1,), t_layers=2, vocab=4096, image_token_id=4001, traj_token_id=4002,
+                     vision_start_id=4003, vision_end_id=4004, eos_token_id=4005)
+"""Parity-test configuration: true widths / head geometry of every layer type (window + full ViT block, GQA decoder layer), reduced
+depth and vocabulary so the fp32 CPU oracle and the transformers modules that pin it run in seconds."""
+
+
+def qwen_spec(cfg) -> Spec:
+    """Qwen2.5-VL parameters under the reference checkpoint's names (transformers 4.51 layout) + model.latent_queries."""
+    s: Spec = {}
+    D, I, O = cfg["v_hidden"], cfg["v_inter"], cfg["v_out"]
+    s["visual.patch_embed.proj.weight"] = ((D, 3, 2, 14, 14), "w")
+    for i in range(cfg["v_depth"]):
+        b = f"visual.blocks.{i}."
+        _ln(s, b + "norm1", D, bias=False)
+        _ln(s, b + "norm2", D, bias=False)
+        _lin(s, b + "attn.qkv", 3 * D, D)
+        _lin(s, b + "attn.proj", D, D)
+        _lin(s, b + "mlp.gate_proj", I, D)
+        _lin(s, b + "mlp.up_proj", I, D)
+        _lin(s, b + "mlp.down_proj", D, I)
+    _ln(s, "visual.merger.ln_q", D, bias=False)
+    _lin(s, "visual.merger.mlp.0", 4 * D, 4 * D)
+    _lin(s, "visual.merger.mlp.2", O, 4 * D)
+    H, TI, nh, nkv = cfg["t_hidden"], cfg["t_inter"], cfg["t_heads"], cfg["t_kv_heads"]
+    hd = H // nh
+    s["model.embed_tokens.weight"] = ((cfg["vocab"], H), "latent")
+    for i in range(cfg["t_layers"]):
+        b = f"model.layers.{i}."
+        _ln(s, b + "input_layernorm", H, bias=False)
+        _ln(s, b + "post_attention_layernorm", H, bias=False)
+        _lin(s, b + "self_attn.q_proj", nh * hd, H)
+        _lin(s, b + "self_attn.k_proj", nkv * hd, H)
+        _lin(s, b + "self_attn.v_proj", nkv * hd, H)
+        _lin(s, b + "self_attn.o_proj", H, nh * hd, bias=False)
+        _lin(s, b + "mlp.gate_proj", TI, H, bias=False)
+        _lin(s, b + "mlp.up_proj", TI, H, bias=False)
+        _lin(s, b + "mlp.down_proj", H, TI, bias=False)
+    _ln(s, "model.norm", H, bias=False)
+    s["model.latent_queries"] = ((1, cfg["n_query"], H), "latent")
+    _lin(s, "lm_head", cfg["vocab"], H, bias=False)
+    return s
+
+
+def qwen_state_dict(seed: int = 0, cfg=QWEN_TEST_CFG):
+    return materialize(qwen_spec(cfg), seed)
+
+
+def qwen_inputs(B: int, n_img: int, seed: int = 0, cfg=QWEN_TEST_CFG, grid=(1, 28, 28), n_text: int = 24, n_tail: int = 8):
+    """Synthetic S2 prompt per env: [text | (<vision_start> <image>*g <vision_end>) * n_img | tail text] with
+    pixel_values ~ N(0,1) [B*n_img*h*w, 1176] already in the HF processor's patch layout (a1 stays on the host)."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    t, h, w = grid
+    per = t * h * w // 4
+    lim = min(cfg["vocab"], cfg["image_token_id"]) - 8
+    rows = []
+    for _ in range(B):
+        ids = torch.randint(0, lim, (n_text,), generator=g).tolist()
+        for _ in range(n_img):
+            ids += [cfg["vision_start_id"]] + [cfg["image_token_id"]] * per + [cfg["vision_end_id"]]
+        ids += torch.randint(0, lim, (n_tail,), generator=g).tolist()
+        rows.append(ids)
+    input_ids = torch.tensor(rows, dtype=torch.long)
+    pixel_values = torch.randn(B * n_img * t * h * w, 1176, generator=g).to(torch.bfloat16).float()
+    grid_thw = torch.tensor([list(grid)] * (B * n_img), dtype=torch.long)
+    return dict(input_ids=input_ids, pixel_values=pixel_values, grid_thw=grid_thw)
+
+
 def navdpnet_state_dict(seed: int = 0, cfg=NAVDPNET_CFG):
     return materialize(navdpnet_spec(cfg), seed)
 

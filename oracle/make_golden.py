@@ -204,7 +204,79 @@ def gold_n1_nextdit(B=2):
     return dict(B=B, seed=4, latents=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
 
 
-UNITS = {"dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_qwen(B=2, n_img=2):
+    """System-2: the installed transformers Qwen2.5-VL vision tower and text model (the reference's un-vendored arithmetic,
+    transformers==4.51.0 pinned / 5.x installed), the reference's vendored get_rope_index_25, and the reference's glue
+    (internvla_n1.py:128-220, 320-347) transcribed onto them: logits of a prefill, greedy tokens, generate_latents."""
+    import importlib.util
+
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLTextConfig, Qwen2_5_VLVisionConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel, Qwen2_5_VLTextModel
+
+    from . import qwen_vl as o_q
+
+    cfg = W.QWEN_TEST_CFG
+    sd = W.qwen_state_dict(seed=6, cfg=cfg)
+    vc = Qwen2_5_VLVisionConfig(depth=cfg["v_depth"], hidden_size=cfg["v_hidden"], intermediate_size=cfg["v_inter"], num_heads=cfg["v_heads"],
+                                out_hidden_size=cfg["v_out"], fullatt_block_indexes=list(cfg["v_fullatt"]), window_size=cfg["v_window"])
+    vc._attn_implementation = "eager"
+    vit = Qwen2_5_VisionTransformerPretrainedModel(vc).float().eval()
+    vit.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    tc = Qwen2_5_VLTextConfig(vocab_size=cfg["vocab"], hidden_size=cfg["t_hidden"], intermediate_size=cfg["t_inter"],
+                              num_hidden_layers=cfg["t_layers"], num_attention_heads=cfg["t_heads"], num_key_value_heads=cfg["t_kv_heads"],
+                              rms_norm_eps=1e-6, rope_parameters={"rope_type": "default", "rope_theta": cfg["rope_theta"], "mrope_section": [16, 24, 24]},
+                              max_position_embeddings=32768, pad_token_id=0)
+    tc._attn_implementation = "eager"
+    llm = Qwen2_5_VLTextModel(tc).float().eval()
+    llm.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.") and k != "model.latent_queries"}, strict=True)
+    spec = importlib.util.spec_from_file_location("ref_rope2d", str(R.REF / "internnav" / "dataset" / "rope2d.py"))
+    rope2d = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rope2d)
+    inp = W.qwen_inputs(B, n_img, seed=6, cfg=cfg)
+    ids, pv, grid = inp["input_ids"], inp["pixel_values"], inp["grid_thw"]
+
+    def ref_rope(i):  # the reference's vendored implementation with the test config's token ids patched in
+        src = (R.REF / "internnav" / "dataset" / "rope2d.py").read_text()
+        src = src.replace("image_token_id = 151655", f"image_token_id = {cfg['image_token_id']}").replace(
+            "vision_start_token_id = 151652", f"vision_start_token_id = {cfg['vision_start_id']}")
+        ns = {}
+        exec(compile(src, "rope2d_patched", "exec"), ns)
+        return ns["get_rope_index_25"](2, i, grid)
+
+    def ref_forward(i):
+        with torch.no_grad():
+            emb = vit(pv, grid_thw=grid).pooler_output
+            x = llm.embed_tokens(i)
+            x = x.masked_scatter((i == cfg["image_token_id"]).unsqueeze(-1).expand_as(x), emb)
+            traj = i == cfg["traj_token_id"]
+            if traj.any():
+                x[traj] = sd["model.latent_queries"].repeat(i.shape[0], 1, 1).view(-1, x.shape[-1])
+            pos, _ = ref_rope(i)
+            h = llm(inputs_embeds=x, position_ids=pos, use_cache=False).last_hidden_state
+            return torch.nn.functional.linear(h, sd["lm_head.weight"]), h, emb, pos
+
+    logits, h, emb, pos = ref_forward(ids)
+    gen = ids.clone()
+    for _ in range(3):
+        lg, _, _, _ = ref_forward(gen)
+        gen = torch.cat([gen, lg[:, -1].argmax(-1)[:, None]], dim=1)
+    ids_q = torch.cat([gen, torch.full((B, cfg["n_query"]), cfg["traj_token_id"], dtype=torch.long)], dim=1)
+    _, hq, _, _ = ref_forward(ids_q)
+    latents = hq[:, -cfg["n_query"]:]
+    with torch.no_grad():
+        o_emb = o_q.vision_tower(pv, grid, sd, cfg)
+        o_pos, _ = o_q.rope_index(ids, grid, cfg["image_token_id"], cfg["vision_start_id"])
+        o_logits, _ = o_q.forward_logits(sd, cfg, ids, pv, grid)
+        o_gen = o_q.generate(sd, cfg, ids, pv, grid, 3)
+        o_lat = o_q.generate_latents(sd, cfg, o_gen, pv, grid)
+    assert torch.equal(o_pos, pos), "rope_index differs from the reference's get_rope_index_25"
+    assert torch.equal(o_gen, gen), "greedy tokens differ"
+    d = max((o_emb - emb).abs().max().item(), (o_logits - logits).abs().max().item(), (o_lat - latents).abs().max().item())
+    return dict(B=B, n_img=n_img, seed=6, image_embeds=emb, position_ids=pos, last_logits=logits[:, -1].clone(),
+                logits_sample=logits[:, ::37].clone(), generated=gen, latents=latents, oracle_max_abs_diff=d)
+
+
+UNITS = {"dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():
