@@ -93,6 +93,7 @@ typedef struct ina_attn_args {
     const int32_t* cu_q;    /* int32 [B+1] varlen offsets or NULL */
     const int32_t* cu_k;
     const float* head_gate; /* f32 [H] or NULL: O *= tanh(gate[h]) */
+    const int32_t* k_len;   /* int32 [B / kv_bdiv] or NULL: valid keys per K/V batch (dense mode; Lk is then the maximum) */
     int32_t accumulate;     /* 1: O += result */
     int32_t _pad;
 } ina_attn_args;

@@ -38,7 +38,7 @@ class AttnArgs(C.Structure):
         ("Lq", c_int32), ("Lk", c_int32), ("D", c_int32),
         ("causal", c_int32), ("kv_start", c_int32), ("kv_bdiv", c_int32),
         ("scale", c_float),
-        ("cu_q", c_void_p), ("cu_k", c_void_p), ("head_gate", c_void_p),
+        ("cu_q", c_void_p), ("cu_k", c_void_p), ("head_gate", c_void_p), ("k_len", c_void_p),
         ("accumulate", c_int32), ("_pad", c_int32),
     ]
 

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     int q_off = 0, k_off = 0, len_q = p.Lq, len_k = p.Lk;
     if (p.cu_q) { q_off = p.cu_q[b]; len_q = p.cu_q[b + 1] - q_off; }
     if (p.cu_k) { k_off = p.cu_k[kb]; len_k = p.cu_k[kb + 1] - k_off; }
+    else if (p.k_len) len_k = min(p.k_len[kb], p.Lk);
     const int qt0 = blockIdx.x * (NW * 16);
     if (qt0 >= len_q) return;
 

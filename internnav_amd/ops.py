@@ -96,7 +96,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
               kv_start: int = 0, kv_bdiv: int = 1, cu_q: Optional[torch.Tensor] = None,
               cu_k: Optional[torch.Tensor] = None, max_q: int = 0, max_k: int = 0,
               head_gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              accumulate: bool = False) -> torch.Tensor:
+              accumulate: bool = False, k_len: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale [+ masks]) v.
 
     Dense: q [B, Lq, H, D], k/v [Bk, Lk, Hkv, D] (arbitrary strides, last dim contiguous; Bk = B / kv_bdiv).
@@ -136,6 +136,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
     a.kv_start, a.kv_bdiv = kv_start, kv_bdiv
     a.scale = float(scale) if scale is not None else float(D) ** -0.5
     a.head_gate = _ptr(_f32(head_gate))
+    if k_len is not None:
+        assert k_len.dtype == torch.int32 and k_len.is_contiguous() and cu_q is None
+        a.k_len = k_len.data_ptr()
     a.accumulate = 1 if accumulate else 0
     _lib.check(_lib.lib().ina_attention_bf16(C.byref(a), _stream()), "attention_bf16")
     return out

@@ -1,0 +1,374 @@
+"""InternVLA-N1 System-2 (Qwen2.5-VL vision tower + 7B LLM + latent trajectory queries) on the gfx950 op library.
+
+Drop-in for the model surface the reference's callers use:
+    model.generate(input_ids, pixel_values, image_grid_thw, max_new_tokens, do_sample=False).sequences
+    model.generate_latents(output_ids, pixel_values, image_grid_thw) -> [B, N_QUERY, 3584]
+(/root/reference/internnav/model/basemodel/internvla_n1/internvla_n1.py:58-220, 320-347; call sites
+internvla_n1_policy.py:169-191, habitat_vln_evaluator.py:418-448), batched over environments (the reference is batch 1).
+
+Arithmetic = transformers Qwen2.5-VL (un-vendored dependency of the reference; restated and pinned in oracle/qwen_vl.py):
+  vision: patch-embed GEMM (K = 1176), window permutation, 32 x {RMSNorm, qkv+bias GEMM, 2-D rope, varlen window / per-image
+          attention (16 heads x 80), proj GEMM + residual, RMSNorm, SwiGLU GEMM pair + bias}, merger (RMSNorm, 5120->5120 GELU ->3584)
+  text:   embedding gather, image-embed scatter, latent_queries rows, m-rope tables from 3-D position ids, 28 x {RMSNorm,
+          fused q|k|v GEMM + bias, m-rope, KV-cache append, causal GQA attention (28q / 4kv x 128), o_proj + residual, RMSNorm,
+          SwiGLU GEMM pair + residual}, final RMSNorm, lm_head on the LAST position only, greedy argmax on the device.
+Work the reference wastes and this engine removes without changing results (SURVEY.md 7 "hard parts"):
+  * lm_head on every prompt position (internvla_n1.py:220) -> last position only (the only row generate() reads);
+  * generate_latents re-runs ViT + the whole prompt (internvla_n1.py:330-344) -> the N_QUERY latent tokens run against the KV
+    cache left by generate(): causal attention makes the prefix K/V identical;
+  * per-token host syncs of HF generate -> a fixed number of decode steps on the device, EOS handled after the fact.
+
+HBM layout (B sequences of S tokens, cache capacity S_max, H = 3584):
+  x f32 [B*S, H] residual stream | h, att bf16 [B*S, H] | qkv bf16 [B*S, 4608] = q(28x128) | k(4x128) | v(4x128)
+  ff bf16 [B*S, 18944] | kv[l] bf16 [B*S_max, 1024] = k | v per cached token | cos/sin f32 [B*S, 128] m-rope tables
+  vision: xv f32 [Np, 1280] | hv/attv bf16 [Np, 1280] | qkvv bf16 [Np, 3840] | ffv bf16 [Np, 3424] (3420 padded) | emb bf16 [Np/4, H]
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------------- host index logic (integers only)
+def vision_window_permutation(grids: Sequence[Tuple[int, int, int]], merge: int = 2, window: int = 112, patch: int = 14):
+    """Window order of the merged 2x2 cells and the window boundaries in patch units (transformers get_window_index)."""
+    win = window // merge // patch
+    idx_all, cu, base = [], [0], 0
+    for t, h, w in grids:
+        gh, gw = h // merge, w // merge
+        idx = np.arange(t * gh * gw).reshape(t, gh, gw)
+        ph, pw = win - gh % win, win - gw % win
+        nh, nw = (gh + ph) // win, (gw + pw) // win
+        pad = np.pad(idx, ((0, 0), (0, ph), (0, pw)), constant_values=-100)
+        pad = pad.reshape(t, nh, win, nw, win).transpose(0, 1, 3, 2, 4).reshape(t, nh * nw, win * win)
+        lens = (pad != -100).sum(-1).reshape(-1)
+        flat = pad.reshape(-1)
+        idx_all.append(flat[flat != -100] + base)
+        for n in lens.tolist():
+            if n:
+                cu.append(cu[-1] + n * merge * merge)
+        base += t * gh * gw
+    return np.concatenate(idx_all), np.asarray(cu, dtype=np.int32)
+
+
+def vision_rope_tables(grids, hd: int = 80, merge: int = 2):
+    """cos/sin [Np, hd] of the 2-D vision rope in pixel_values (block-major) order (transformers rot_pos_emb)."""
+    out = []
+    for t, h, w in grids:
+        hp = np.broadcast_to(np.arange(h)[:, None], (h, w)).reshape(h // merge, merge, w // merge, merge).transpose(0, 2, 1, 3).reshape(-1)
+        wp = np.broadcast_to(np.arange(w)[None, :], (h, w)).reshape(h // merge, merge, w // merge, merge).transpose(0, 2, 1, 3).reshape(-1)
+        out.append(np.tile(np.stack([hp, wp], -1), (t, 1)))
+    pos = torch.from_numpy(np.concatenate(out)).float()
+    dim = hd // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+    rot = (pos.unsqueeze(-1) * inv).flatten(1)
+    emb = torch.cat((rot, rot), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def rope_index(input_ids: np.ndarray, grids, image_token_id: int, vision_start_id: int, merge: int = 2):
+    """3-D (t,h,w) position ids of get_rope_index_25 (reference internnav/dataset/rope2d.py:69-158) for still images, no padding."""
+    B, S = input_ids.shape
+    pos = np.zeros((3, B, S), dtype=np.int64)
+    deltas = np.zeros(B, dtype=np.int64)
+    img = 0
+    for b in range(B):
+        toks = input_ids[b]
+        starts = np.nonzero((toks[:-1] == vision_start_id) & (toks[1:] == image_token_id))[0]
+        chunks, st, nxt = [], 0, 0
+        for s0 in starts:
+            ed = int(s0) + 1
+            t, h, w = grids[img]
+            img += 1
+            gh, gw = h // merge, w // merge
+            text_len = ed - st
+            chunks.append(np.broadcast_to(np.arange(text_len)[None], (3, text_len)) + nxt)
+            ti = np.zeros(t * gh * gw, dtype=np.int64)
+            hi = np.broadcast_to(np.arange(gh)[None, :, None], (t, gh, gw)).reshape(-1)
+            wi = np.broadcast_to(np.arange(gw)[None, None, :], (t, gh, gw)).reshape(-1)
+            vis = np.stack([ti, hi, wi]) + text_len + nxt
+            chunks.append(vis)
+            nxt = int(vis.max()) + 1
+            st = ed + t * gh * gw
+        if st < S:
+            chunks.append(np.broadcast_to(np.arange(S - st)[None], (3, S - st)) + nxt)
+        p = np.concatenate(chunks, axis=1)
+        pos[:, b] = p
+        deltas[b] = int(p.max()) + 1 - S
+    return pos, deltas
+
+
+def _interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    n, k = a.shape
+    return torch.stack([a.view(n // 16, 16, k), b.view(n // 16, 16, k)], dim=1).reshape(2 * n, k).contiguous()
+
+
+def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    return t if t.shape[0] == n else torch.cat([t, t.new_zeros((n - t.shape[0],) + tuple(t.shape[1:]))], 0)
+
+
+class QwenVLEngine:
+    """weights: mapping key -> tensor (a state dict, or a lazy provider that materialises tensors on the device)."""
+
+    def __init__(self, weights, cfg: dict, device="cuda:0", max_seqs: int = 16, max_seq_len: int = 1024, max_patches: int = 16 * 3136):
+        dev = torch.device(device)
+        bf, f32 = torch.bfloat16, torch.float32
+        self.cfg, self.device = cfg, dev
+        self.B_max, self.S_max, self.Np_max = max_seqs, max_seq_len, max_patches
+        D, I = cfg["v_hidden"], cfg["v_inter"]
+        Ip = (I + 15) // 16 * 16
+        self.vD, self.vI, self.vH, self.vhd = D, Ip, cfg["v_heads"], D // cfg["v_heads"]
+        H, TI = cfg["t_hidden"], cfg["t_inter"]
+        self.H, self.TI, self.nh, self.nkv = H, TI, cfg["t_heads"], cfg["t_kv_heads"]
+        self.hd = H // self.nh
+        self.qkv_w = (self.nh + 2 * self.nkv) * self.hd
+        self.kv_w = 2 * self.nkv * self.hd
+        W = weights
+
+        def w(k):
+            return W[k].to(device=dev, dtype=bf).contiguous()
+
+        def f(k):
+            return W[k].to(device=dev, dtype=f32).contiguous()
+
+        # ---- vision tower
+        self.v_patch = W["visual.patch_embed.proj.weight"].to(device=dev, dtype=bf).reshape(D, -1).contiguous()
+        self.v_blocks = []
+        for i in range(cfg["v_depth"]):
+            b = f"visual.blocks.{i}."
+            gw_, uw = _pad_rows(W[b + "mlp.gate_proj.weight"].to(dev).float(), Ip), _pad_rows(W[b + "mlp.up_proj.weight"].to(dev).float(), Ip)
+            gb, ub = _pad_rows(W[b + "mlp.gate_proj.bias"].to(dev).float(), Ip), _pad_rows(W[b + "mlp.up_proj.bias"].to(dev).float(), Ip)
+            dw = W[b + "mlp.down_proj.weight"].to(dev).float()
+            dw = torch.cat([dw, dw.new_zeros(D, Ip - I)], 1) if Ip != I else dw
+            self.v_blocks.append(dict(
+                n1=f(b + "norm1.weight"), n2=f(b + "norm2.weight"), qkv_w=w(b + "attn.qkv.weight"), qkv_b=f(b + "attn.qkv.bias"),
+                proj_w=w(b + "attn.proj.weight"), proj_b=f(b + "attn.proj.bias"),
+                gu_w=_interleave16(gw_, uw).to(bf), gu_b=_interleave16(gb[:, None], ub[:, None]).reshape(-1).contiguous(),
+                down_w=dw.to(bf).contiguous(), down_b=f(b + "mlp.down_proj.bias"), full=i in cfg["v_fullatt"]))
+        self.m_ln = f("visual.merger.ln_q.weight")
+        self.m0 = (w("visual.merger.mlp.0.weight"), f("visual.merger.mlp.0.bias"))
+        self.m2 = (w("visual.merger.mlp.2.weight"), f("visual.merger.mlp.2.bias"))
+        Np = max_patches
+        self.pv_perm = torch.empty(Np, 1176, dtype=bf, device=dev)
+        self.xv = torch.empty(Np, D, dtype=f32, device=dev)
+        self.hv = torch.empty(Np, D, dtype=bf, device=dev)
+        self.attv = torch.empty(Np, D, dtype=bf, device=dev)
+        self.qkvv = torch.empty(Np, 3 * D, dtype=bf, device=dev)
+        self.ffv = torch.empty(Np, Ip, dtype=bf, device=dev)
+        self.mh = torch.empty(Np // 4, 4 * D, dtype=bf, device=dev)
+        self.emb = torch.empty(Np // 4, cfg["v_out"], dtype=bf, device=dev)
+        self.v_cos = torch.empty(Np, self.vhd, dtype=f32, device=dev)
+        self.v_sin = torch.empty(Np, self.vhd, dtype=f32, device=dev)
+        # ---- text model
+        self.embed = w("model.embed_tokens.weight")
+        self.layers = []
+        for i in range(cfg["t_layers"]):
+            b = f"model.layers.{i}."
+            qkvw = torch.cat([W[b + "self_attn.q_proj.weight"].to(dev), W[b + "self_attn.k_proj.weight"].to(dev), W[b + "self_attn.v_proj.weight"].to(dev)], 0)
+            qkvb = torch.cat([W[b + "self_attn.q_proj.bias"].to(dev), W[b + "self_attn.k_proj.bias"].to(dev), W[b + "self_attn.v_proj.bias"].to(dev)], 0)
+            self.layers.append(dict(
+                n1=f(b + "input_layernorm.weight"), n2=f(b + "post_attention_layernorm.weight"),
+                qkv_w=qkvw.to(bf).contiguous(), qkv_b=qkvb.to(f32).contiguous(), o_w=w(b + "self_attn.o_proj.weight"),
+                gu_w=_interleave16(W[b + "mlp.gate_proj.weight"].to(dev), W[b + "mlp.up_proj.weight"].to(dev)).to(bf),
+                down_w=w(b + "mlp.down_proj.weight"),
+                kv=torch.empty(max_seqs * max_seq_len, self.kv_w, dtype=bf, device=dev)))
+        self.norm_w = f("model.norm.weight")
+        self.lm_head = w("lm_head.weight")
+        self.latent_q = W["model.latent_queries"].to(device=dev, dtype=bf).reshape(-1, H).contiguous()
+        rows = max_seqs * max_seq_len
+        self.x_in = torch.empty(rows, H, dtype=bf, device=dev)
+        self.x = torch.empty(rows, H, dtype=f32, device=dev)
+        self.h = torch.empty(rows, H, dtype=bf, device=dev)
+        self.att = torch.empty(rows, H, dtype=bf, device=dev)
+        self.qkv = torch.empty(rows, self.qkv_w, dtype=bf, device=dev)
+        self.ff = torch.empty(rows, TI, dtype=bf, device=dev)
+        self.cos = torch.empty(rows, self.hd, dtype=f32, device=dev)
+        self.sin = torch.empty(rows, self.hd, dtype=f32, device=dev)
+        self.hl = torch.empty(max_seqs * 8, H, dtype=bf, device=dev)
+        self.logits = torch.empty(max_seqs, cfg["vocab"], dtype=f32, device=dev)
+        self.next_tok = torch.empty(max_seqs, dtype=torch.int32, device=dev)
+        half = self.hd // 2
+        self.inv_freq = (1.0 / (cfg["rope_theta"] ** (torch.arange(0, self.hd, 2, dtype=f32) / self.hd))).to(dev)
+        axis = np.concatenate([np.full(16, 0), np.full(24, 1), np.full(24, 2)]).astype(np.int32)  # mrope_section [16, 24, 24]
+        assert axis.size == half
+        self.axis_of = torch.from_numpy(axis).to(dev)
+
+    # ------------------------------------------------------------------------------------------------ vision tower
+    def vision(self, pixel_values: torch.Tensor, grids: List[Tuple[int, int, int]]) -> torch.Tensor:
+        """pixel_values bf16 [Np, 1176] (HF processor patch layout), grids [(t,h,w)] -> image embeds bf16 [Np/4, 3584] in WINDOW order;
+        returns (emb, inv) where inv[k] is the emb row of the k-th image token in sequence order."""
+        dev, D, Hh, hd = self.device, self.vD, self.vH, self.vhd
+        Np = pixel_values.shape[0]
+        assert Np <= self.Np_max and pixel_values.dtype == torch.bfloat16
+        win_idx, cu_win = vision_window_permutation(grids, 2, self.cfg["v_window"], self.cfg["v_patch"])
+        perm = (win_idx[:, None] * 4 + np.arange(4)[None]).reshape(-1).astype(np.int32)
+        cu_full = np.concatenate([[0], np.cumsum([t * h * w for t, h, w in grids])]).astype(np.int32)
+        cos, sin = vision_rope_tables(grids, hd)
+        perm_t = torch.from_numpy(perm).to(dev)
+        self.v_cos[:Np].copy_(cos[perm].to(dev))
+        self.v_sin[:Np].copy_(sin[perm].to(dev))
+        cu_win_t, cu_full_t = torch.from_numpy(cu_win).to(dev), torch.from_numpy(cu_full).to(dev)
+        max_win, max_full = int(np.diff(cu_win).max()), int(np.diff(cu_full).max())
+        xp, x, h, att, qkv, ff = self.pv_perm[:Np], self.xv[:Np], self.hv[:Np], self.attv[:Np], self.qkvv[:Np], self.ffv[:Np]
+        ops.gather_rows(pixel_values, xp, src=perm_t)
+        ops.linear(xp, self.v_patch, out=x)
+        q3 = qkv.view(Np, 3, Hh, hd)
+        for blk in self.v_blocks:
+            ops.norm(x, blk["n1"], None, eps=1e-6, rms=True, out=h)
+            ops.linear(h, blk["qkv_w"], bias=blk["qkv_b"], out=qkv)
+            ops.rope(qkv, self.v_cos, self.v_sin, heads=2 * Hh, D=hd, col0=0, rows=Np)
+            cu, mx = (cu_full_t, max_full) if blk["full"] else (cu_win_t, max_win)
+            ops.attention(q3[:, 0], q3[:, 1], q3[:, 2], cu_q=cu, cu_k=cu, max_q=mx, max_k=mx, out=att.view(Np, Hh, hd))
+            ops.linear(att, blk["proj_w"], bias=blk["proj_b"], residual=x, out=x)
+            ops.norm(x, blk["n2"], None, eps=1e-6, rms=True, out=h)
+            ops.linear(h, blk["gu_w"], bias=blk["gu_b"], act="silu", glu=True, out=ff)
+            ops.linear(ff, blk["down_w"], bias=blk["down_b"], residual=x, out=x)
+        ops.norm(x, self.m_ln, None, eps=1e-6, rms=True, out=h)
+        ops.linear(h.view(Np // 4, 4 * D), self.m0[0], bias=self.m0[1], act="gelu", out=self.mh[: Np // 4])
+        ops.linear(self.mh[: Np // 4], self.m2[0], bias=self.m2[1], out=self.emb[: Np // 4])
+        inv = np.argsort(win_idx).astype(np.int32)
+        return self.emb[: Np // 4], inv
+
+    # ------------------------------------------------------------------------------------------------ text model
+    def _layers(self, B: int, S: int, pos0: int, first_from_bf16: bool, k_len: Optional[torch.Tensor] = None, Lk: Optional[int] = None):
+        """28 decoder layers on rows [B*S] whose tokens sit at cache positions pos0 .. pos0+S-1 of each sequence (or, with k_len,
+        at the per-sequence positions k_len[b]-S .. k_len[b]-1 given by self._cache_rows)."""
+        H, nh, nkv, hd, Smax = self.H, self.nh, self.nkv, self.hd, self.S_max
+        rows = B * S
+        x, h, att, qkv, ff = self.x[:rows], self.h[:rows], self.att[:rows], self.qkv[:rows], self.ff[:rows]
+        Lk = pos0 + S if Lk is None else Lk
+        q4 = qkv[:, : nh * hd].view(B, S, nh, hd)
+        for li, L in enumerate(self.layers):
+            src = self.x_in[:rows] if (li == 0 and first_from_bf16) else x
+            ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
+            ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
+            ops.rope(qkv, self.cos, self.sin, heads=nh + nkv, D=hd, col0=0, rows=rows)
+            ops.gather_rows(qkv[:, nh * hd:], L["kv"], dst=self._cache_rows[:rows])
+            kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[:B, :Lk]
+            ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=k_len)
+            ops.linear(att, L["o_w"], residual=src, out=x)
+            ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
+            ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
+            ops.linear(ff, L["down_w"], residual=x, out=x)
+
+    def _set_positions(self, B: int, S: int, pos3: np.ndarray, pos0):
+        """upload 3-D position ids [3, B*S] -> m-rope tables; cache row of every token (b * S_max + pos0[b] + s)."""
+        dev = self.device
+        p = torch.from_numpy(np.ascontiguousarray(pos3.reshape(3, B * S)).astype(np.int32)).to(dev)
+        ops.mrope_table(p, self.inv_freq, self.axis_of, self.cos, self.sin)
+        pos0 = np.broadcast_to(np.asarray(pos0, dtype=np.int64).reshape(-1, 1), (B, 1))
+        rows = (np.arange(B)[:, None] * self.S_max + pos0 + np.arange(S)[None]).reshape(-1).astype(np.int32)
+        self._cache_rows = torch.from_numpy(rows).to(dev)
+
+    def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor], image_grid_thw) -> dict:
+        """Embed + scatter + 28 layers over the whole prompt (B equal-length sequences); fills the KV cache; returns the state."""
+        cfg, dev, H = self.cfg, self.device, self.H
+        ids = input_ids.cpu().numpy().astype(np.int64)
+        B, S = ids.shape
+        assert B <= self.B_max and S <= self.S_max
+        grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
+        flat = ids.reshape(-1)
+        ops.gather_rows(self.embed, self.x_in, src=torch.from_numpy(flat.astype(np.int32)).to(dev))
+        img_pos = np.nonzero(flat == cfg["image_token_id"])[0].astype(np.int32)
+        if pixel_values is not None and len(grids):
+            emb, inv = self.vision(pixel_values, grids)
+            assert img_pos.size == inv.size, f"Image features and image tokens do not match: tokens: {img_pos.size}, features {inv.size}"
+            ops.gather_rows(emb, self.x_in, src=torch.from_numpy(inv).to(dev), dst=torch.from_numpy(img_pos).to(dev))
+        traj_pos = np.nonzero(flat == cfg["traj_token_id"])[0].astype(np.int32)
+        if traj_pos.size:
+            nq = self.latent_q.shape[0]
+            srcq = (np.arange(traj_pos.size) % nq).astype(np.int32)
+            ops.gather_rows(self.latent_q, self.x_in, src=torch.from_numpy(srcq).to(dev), dst=torch.from_numpy(traj_pos).to(dev))
+        pos3, deltas = rope_index(ids, grids, cfg["image_token_id"], cfg["vision_start_id"])
+        self._set_positions(B, S, pos3, 0)
+        self._layers(B, S, 0, first_from_bf16=True)
+        return dict(B=B, S=S, next_pos=pos3[:, :, -1].max(axis=0) + 1)
+
+    def _last_logits(self, B: int, S: int, row_in_seq: int):
+        """final RMSNorm + lm_head on ONE row per sequence, greedy argmax on the device."""
+        ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
+        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B])
+        ops.argmax_rows(self.logits[:B], self.next_tok[:B])
+
+    def decode(self, state: dict, n_steps: int) -> torch.Tensor:
+        """n greedy steps after prefill (or after a previous decode); returns int32 [B, n] generated tokens (device)."""
+        B, S = state["B"], state["S"]
+        out = torch.empty(B, n_steps, dtype=torch.int32, device=self.device)
+        if "cur" not in state:
+            self._last_logits(B, S, S - 1)
+            state["cur"] = S
+        for j in range(n_steps):
+            out[:, j].copy_(self.next_tok[:B])
+            if j == n_steps - 1:
+                break
+            cur = state["cur"]
+            assert cur < self.S_max
+            ops.gather_rows(self.embed, self.x_in, src=self.next_tok[:B], rows=B)
+            p = np.broadcast_to(state["next_pos"][None, :, None], (3, B, 1))
+            self._set_positions(B, 1, p, cur)
+            self._layers(B, 1, cur, first_from_bf16=True)
+            self._last_logits(B, 1, 0)
+            state["cur"] = cur + 1
+            state["next_pos"] = state["next_pos"] + 1
+        state["last_tok"] = out[:, -1]
+        return out
+
+    def latents(self, state: dict, tail_tokens: Optional[torch.Tensor], seq_lens: Optional[np.ndarray] = None) -> torch.Tensor:
+        """N_QUERY latent trajectory queries against the cached prefix (generate_latents without the re-run).
+        tail_tokens int32 [B, m]: tokens to run in front of the queries because their K/V are not cached yet (the last sampled
+        token). seq_lens [B]: number of cached tokens to keep per sequence (prompt + answer up to where it ended); the m + N_QUERY
+        new tokens are placed right behind them, K/V cached beyond that point (post-EOS decode steps) are ignored / overwritten."""
+        cfg, B, H = self.cfg, state["B"], self.H
+        nq = self.latent_q.shape[0]
+        m = 0 if tail_tokens is None else tail_tokens.shape[1]
+        rows = B * (m + nq)
+        cur = state.get("cur", state["S"])
+        assert cur + m + nq <= self.S_max
+        x3 = self.x_in[:rows].view(B, m + nq, H)
+        if m:
+            tmp = self.hl[: B * m]
+            ops.gather_rows(self.embed, tmp, src=tail_tokens.reshape(-1).contiguous(), rows=B * m)
+            x3[:, :m].copy_(tmp.view(B, m, H))
+        x3[:, m:].copy_(self.latent_q.view(1, nq, H).expand(B, nq, H))
+        if seq_lens is None:
+            p = state["next_pos"][None, :, None] + np.arange(m + nq)[None, None, :]
+            self._set_positions(B, m + nq, np.broadcast_to(p, (3, B, m + nq)), cur)
+            self._layers(B, m + nq, cur, first_from_bf16=True)
+        else:
+            seq_lens = np.asarray(seq_lens, dtype=np.int64)
+            start_pos = state["next_pos"] - (cur - seq_lens)          # text positions advance by one per cached token
+            p = start_pos[None, :, None] + np.arange(m + nq)[None, None, :]
+            self._set_positions(B, m + nq, np.broadcast_to(p, (3, B, m + nq)), seq_lens)
+            k_len = torch.from_numpy((seq_lens + m + nq).astype(np.int32)).to(self.device)
+            self._layers(B, m + nq, 0, first_from_bf16=True, k_len=k_len, Lk=int(seq_lens.max()) + m + nq)
+        out = torch.empty(B, nq, H, dtype=torch.bfloat16, device=self.device)
+        ops.norm(self.x[:rows], self.norm_w, None, eps=1e-6, rms=True, out=out.view(B * nq, H), rows=B * nq, in_map=(nq, m + nq, m))
+        return out
+
+    # ------------------------------------------------------------------------------------------------ HF-style surface
+    def generate(self, input_ids, pixel_values=None, image_grid_thw=None, max_new_tokens: int = 8, eos_token_id=None, **_):
+        """greedy generate: returns sequences int64 [B, S + n] (a row that reached EOS keeps EOS), n = max_new_tokens."""
+        state = self.prefill(input_ids, pixel_values, image_grid_thw)
+        toks = self.decode(state, max_new_tokens).cpu().long()
+        eos = self.cfg["eos_token_id"] if eos_token_id is None else eos_token_id
+        for b in range(toks.shape[0]):
+            hit = (toks[b] == eos).nonzero()
+            if hit.numel():
+                toks[b, int(hit[0]) + 1:] = eos
+        self._state = state
+        return torch.cat([input_ids.cpu().long(), toks], dim=1)
+
+    def generate_latents(self, output_ids, pixel_values=None, image_grid_thw=None):
+        """reference signature (internvla_n1.py:320): full prefill over output_ids + N_QUERY latent queries (no cache reuse)."""
+        cfg = self.cfg
+        nq = self.latent_q.shape[0]
+        ids = torch.cat([output_ids.cpu().long(), torch.full((output_ids.shape[0], nq), cfg["traj_token_id"], dtype=torch.long)], dim=1)
+        st = self.prefill(ids, pixel_values, image_grid_thw)
+        B, S = st["B"], st["S"]
+        out = torch.empty(B, nq, self.H, dtype=torch.bfloat16, device=self.device)
+        ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=out.view(B * nq, self.H), rows=B * nq, in_map=(nq, S, S - nq))
+        return out

@@ -102,3 +102,22 @@ def test_n1_nextdit_matches_reference():
     with torch.no_grad():
         out = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
     assert (out - gold["latents"]).abs().max().item() < 1e-4
+
+
+def test_qwen_s2_matches_transformers_and_reference_rope_index():
+    """System-2 oracle vs the fixture from the installed transformers Qwen2.5-VL modules + the reference's get_rope_index_25."""
+    from oracle import qwen_vl as o_q
+
+    gold = _load("qwen")
+    cfg = W.QWEN_TEST_CFG
+    sd = W.qwen_state_dict(seed=gold["seed"], cfg=cfg)
+    inp = W.qwen_inputs(gold["B"], gold["n_img"], seed=gold["seed"], cfg=cfg)
+    with torch.no_grad():
+        pos, _ = o_q.rope_index(inp["input_ids"], inp["grid_thw"], cfg["image_token_id"], cfg["vision_start_id"])
+        assert torch.equal(pos, gold["position_ids"])
+        emb = o_q.vision_tower(inp["pixel_values"], inp["grid_thw"], sd, cfg)
+        assert (emb - gold["image_embeds"]).abs().max().item() < 1e-3
+        logits, _ = o_q.forward_logits(sd, cfg, inp["input_ids"], inp["pixel_values"], inp["grid_thw"])
+        assert (logits[:, -1] - gold["last_logits"]).abs().max().item() < 1e-3
+        lat = o_q.generate_latents(sd, cfg, gold["generated"], inp["pixel_values"], inp["grid_thw"])
+        assert (lat - gold["latents"]).abs().max().item() < 1e-3
