@@ -113,7 +113,7 @@ def main():
 
     gathered = None
     if world > 1:
-        gathered = torch.empty(world, B, 8, cfg["predict_size"], 3, device=dev)
+        gathered = torch.empty(world * B, 8, cfg["predict_size"], 3, device=dev)
 
     def step():
         # fresh sampler noise every policy step (drawn on the device into the static buffers the graph reads)

@@ -1,0 +1,61 @@
+"""Data-parallel harness: one process per GPU, episodes sharded by rank, tiny collectives only.
+
+Mirrors the reference's distributed evaluation: rank/world discovery and init
+(internnav/utils/dist.py:193-243, backend "nccl" = RCCL on ROCm; gloo for the CPU tests), episode striding
+`episodes[rank::world_size]` (internnav/env/habitat_env.py:72), padded all_gather of per-episode metrics
+(internnav/evaluator/distributed_base.py:96-135), plus the per-step all_gather of per-env action outputs over xGMI that
+BASELINE.json's north_star adds. There is no collective inside the model: weights are replicated (16.6 GB bf16 of 288 GB HBM).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str = "nccl", device=None):
+    """env:// bootstrap (torchrun / srun export RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT). Returns (rank, local_rank, world)."""
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        dist.barrier()
+    return rank, local, world
+
+
+def shard_episodes(episodes: Sequence, rank: int, world: int) -> List:
+    """rank r owns episodes r, r + world, r + 2*world, ... (habitat_env.py:72)."""
+    return list(episodes[rank::world])
+
+
+def all_gather_actions(actions: torch.Tensor) -> torch.Tensor:
+    """per-step exchange of the per-env action outputs: [envs_per_rank, ...] -> [world, envs_per_rank, ...] on every rank
+    (<= 17 KB per rank, latency bound; one ncclAllGather over the xGMI mesh)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return actions.unsqueeze(0)
+    world = dist.get_world_size()
+    a = actions.contiguous()
+    out = torch.empty((world * a.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)  # concatenated form (gloo + RCCL)
+    dist.all_gather_into_tensor(out, a)
+    return out.view((world,) + tuple(a.shape))
+
+
+def all_gather_metrics(local: torch.Tensor) -> torch.Tensor:
+    """variable-length per-episode metric vectors -> concatenation over ranks, padded exchange like distributed_base.py:96-135."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    mx = max(lens)
+    pad = torch.zeros(mx, dtype=local.dtype, device=local.device)
+    pad[: local.numel()] = local.reshape(-1)
+    got = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(got, pad)
+    return torch.cat([g[:l] for g, l in zip(got, lens)])

@@ -1,0 +1,374 @@
+"""Drop-in model / policy surface of InternVLA-N1 on the MI355X engines.
+
+Mirrors, with the same names, arguments and return types, what the reference's callers use:
+  * `InternVLAN1ForCausalLM`  <- internnav/model/basemodel/internvla_n1/internvla_n1.py:39 : `.eval()`, `.device`,
+        `.generate(**inputs, max_new_tokens, do_sample=False, ...).sequences`, `.generate_latents(output_ids, pixel_values,
+        image_grid_thw)`, `.generate_traj(traj_latents, images_dp, depths_dp)`
+        (call sites habitat_vln_evaluator.py:418-459, internvla_n1_policy.py:169-203, internvla_n1_agent_realworld.py:221-256)
+  * `InternVLAN1Net`          <- internnav/model/basemodel/internvla_n1/internvla_n1_policy.py:26 : `reset`, `step_no_infer`,
+        `s2_step`, `s1_step_latent`
+  * host post-processing `traj_to_actions`, `chunk_token`, `split_and_clean`, `S1Output`, `S2Output`, `S2Input`
+        <- internnav/model/utils/vln_utils.py:19-175 (numpy / python; stays on the host in the reference too).
+The tokenizer / image processor (a1 in SURVEY.md 8a: HF `AutoProcessor`, third-party, host side) is injected; the kernel
+boundary starts at `input_ids` / `pixel_values` / `image_grid_thw`.
+
+Unlike the reference (one env per call) every method here also accepts a batch of environments; batch-1 calls keep the
+reference's exact shapes (e.g. generate_traj returns [32*B, T, 3]).
+"""
+from __future__ import annotations
+
+import copy
+import itertools
+import re
+from collections import OrderedDict
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import synthetic
+from .navdp import NavDPPolicyDAT
+from .nextdit import NextDiTSystem1
+from .qwen_vl import QwenVLEngine
+
+
+# ------------------------------------------------------------------------------------------------------ vln_utils mirror
+def split_and_clean(text: str) -> List[str]:
+    """vln_utils.py:19-33: split on <image>, drop newlines / empty parts."""
+    out = []
+    for part in re.split(r"(<image>)", text):
+        if part == "<image>":
+            out.append(part)
+        else:
+            c = part.replace("\n", "").strip()
+            if c:
+                out.append(c)
+    return out
+
+
+def chunk_token(dp_actions) -> List[int]:
+    """vln_utils.py:36-60: per-waypoint discretisation (0 stop, 1 forward, 2 left, 3 right)."""
+    out = []
+    for xyyaw in dp_actions:
+        x, yaw = float(xyyaw[0]), float(xyyaw[-1])
+        if x < 0.05 and abs(yaw) < 0.05:
+            out.append(0)
+        elif abs(x / 0.25) >= abs(yaw * 12 / np.pi):
+            out.append(1)
+        else:
+            out.append(3 if yaw < 0 else 2)
+    return out
+
+
+def traj_to_actions(dp_actions, use_discrate_action: bool = True):
+    """vln_utils.py:63-136. dp_actions [S, T, 3] (x4-scaled increments): un-normalise IN PLACE (the reference mutates its input,
+    :129), cumulative sum, mean over the S samples, greedy pure-pursuit discretisation (0.25 m steps, 15 degree turns, lookahead 4)."""
+    dp_actions[:, :, :2] /= 4.0
+    d = dp_actions.float().cpu().numpy() if isinstance(dp_actions, torch.Tensor) else np.asarray(dp_actions, dtype=np.float64)
+    B, T = d.shape[:2]
+    xy = np.zeros((B, T + 1, 2))
+    xy[:, 1:] = np.cumsum(d[:, :, :2], axis=1)
+    trajectory = xy.mean(axis=0)
+    if not use_discrate_action:
+        return trajectory
+    actions: List[int] = []
+    yaw, pos, goal = 0.0, trajectory[0], trajectory[-1]
+    turn = np.deg2rad(15)
+
+    def norm_angle(a):
+        return (a + np.pi) % (2 * np.pi) - np.pi
+
+    while np.linalg.norm(pos - goal) > 0.2:
+        nearest = int(np.argmin(np.linalg.norm(trajectory - pos, axis=1)))
+        target = trajectory[min(nearest + 4, len(trajectory) - 1)]
+        tdir = target - pos
+        if np.linalg.norm(tdir) < 1e-6:
+            break
+        n_turns = int(round(norm_angle(np.arctan2(tdir[1], tdir[0]) - yaw) / turn))
+        if n_turns > 0:
+            actions += [2] * n_turns
+        elif n_turns < 0:
+            actions += [3] * (-n_turns)
+        yaw = norm_angle(yaw + n_turns * turn)
+        nxt = pos + 0.25 * np.array([np.cos(yaw), np.sin(yaw)])
+        if np.linalg.norm(nxt - goal) > np.linalg.norm(pos - goal):
+            break
+        actions.append(1)
+        pos = nxt
+    return actions
+
+
+@dataclass
+class S2Input:
+    idx: Optional[int] = -1
+    instruction: Optional[str] = None
+    rgb: Optional[np.ndarray] = None
+    depth: Optional[np.ndarray] = None
+    pose: Optional[Any] = None
+    look_down: Optional[bool] = False
+    should_infer: Optional[bool] = False
+
+
+@dataclass
+class S2Output:
+    idx: Optional[int] = -1
+    is_infering: Optional[bool] = False
+    output_action: Optional[Any] = None
+    output_trajectory: Optional[np.ndarray] = None
+    output_pixel: Optional[np.ndarray] = None
+    output_latent: Optional[torch.Tensor] = None
+    rgb_memory: Optional[np.ndarray] = None
+    depth_memory: Optional[np.ndarray] = None
+
+    def validate(self) -> bool:
+        return sum(x is not None for x in (self.output_action, self.output_pixel, self.output_latent)) > 0 and self.idx >= 0
+
+
+@dataclass
+class S1Output:
+    idx: Optional[List[int]] = None
+    vis_image: Optional[np.ndarray] = None
+
+
+# ------------------------------------------------------------------------------------------------------ model facade
+class InternVLAN1ForCausalLM:
+    """HF-style model object backed by the HIP engines (no nn.Module, no CPU fallback)."""
+
+    def __init__(self, weights, qwen_cfg: dict, system1: str = "nextdit_async", s1_cfg: Optional[dict] = None,
+                 device="cuda:0", max_envs: int = 16, max_seq_len: int = 2048, max_patches: Optional[int] = None):
+        self.device = torch.device(device)
+        self.config = SimpleNamespace(system1=system1, n_query=qwen_cfg["n_query"], hidden_size=qwen_cfg["t_hidden"],
+                                      image_token_id=qwen_cfg["image_token_id"])
+        self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=max_envs, max_seq_len=max_seq_len,
+                                 max_patches=max_patches or max_envs * 10 * 784)
+        if "nextdit" in system1:
+            self.s1 = NextDiTSystem1(_Prefixed(weights, "model."), s1_cfg or synthetic.N1_NEXTDIT_CFG, device, max_envs)
+        elif "navdp" in system1:
+            self.s1 = NavDPPolicyDAT(_Prefixed(weights, "model.navdp."), s1_cfg or synthetic.N1_NAVDP_CFG, device, max_envs)
+        else:
+            raise NotImplementedError(system1)
+        self._noise_gen = torch.Generator(device=self.device).manual_seed(0)
+
+    # ---- construction
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=torch.bfloat16, attn_implementation: str = "flash_attention_2", device_map=None, **kw):
+        """reference call: InternVLAN1ForCausalLM.from_pretrained(path, torch_dtype=bf16, attn_implementation=..., device_map={"": dev}).
+        Loads every *.safetensors shard under `path` (HF checkpoint layout); config.json supplies system1 / n_query."""
+        import json
+        from pathlib import Path
+
+        from safetensors import safe_open
+
+        p = Path(path)
+        files = sorted(p.glob("*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {p}: InternVLA-N1 checkpoints are HF safetensors shards")
+        cfgj = json.loads((p / "config.json").read_text()) if (p / "config.json").exists() else {}
+        device = (device_map or {"": "cuda:0"})[""]
+        weights = {}
+        for f in files:
+            with safe_open(str(f), framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    weights[k] = sf.get_tensor(k)
+        qcfg = dict(synthetic.QWEN_N1_CFG, n_query=cfgj.get("n_query", 4))
+        return cls(weights, qcfg, system1=cfgj.get("system1", "nextdit_async"), device=device, **kw)
+
+    def eval(self):
+        return self
+
+    def get_n_query(self):
+        return self.config.n_query
+
+    def get_system1_type(self):
+        return self.config.system1
+
+    # ---- System 2
+    def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, attention_mask=None, max_new_tokens: int = 128,
+                 do_sample: bool = False, use_cache: bool = True, past_key_values=None, return_dict_in_generate: bool = False,
+                 decode_chunk: int = 8, eos_token_id=None, **_):
+        """greedy decoding (do_sample=False is the only mode the reference uses, internvla_n1_policy.py:169-176). Decodes in chunks of
+        `decode_chunk` device-side steps and stops once every sequence has emitted EOS. Sequences are right-filled with EOS."""
+        assert not do_sample, "the reference only decodes greedily"
+        eos = self.qwen.cfg["eos_token_id"] if eos_token_id is None else eos_token_id
+        pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None else None
+        state = self.qwen.prefill(input_ids, pv, image_grid_thw)
+        chunks, n = [], 0
+        while n < max_new_tokens:
+            k = min(decode_chunk, max_new_tokens - n)
+            t = self.qwen.decode(state, k + 1 if n else k)  # later chunks re-emit the pending token first
+            t = t[:, 1:] if n else t
+            chunks.append(t.cpu().long())
+            n += k
+            if bool((torch.cat(chunks, dim=1) == eos).any(dim=1).all()):
+                break
+        toks = torch.cat(chunks, dim=1)
+        lens = []
+        for b in range(toks.shape[0]):
+            hit = (toks[b] == eos).nonzero()
+            e = int(hit[0]) + 1 if hit.numel() else toks.shape[1]
+            toks[b, e:] = eos
+            lens.append(e)
+        self._gen = dict(state=state, tokens=toks, lens=np.asarray(lens), prompt_len=input_ids.shape[1])
+        seqs = torch.cat([input_ids.cpu().long(), toks], dim=1).to(self.device)
+        return SimpleNamespace(sequences=seqs) if return_dict_in_generate else seqs
+
+    def generate_latents(self, output_ids, pixel_values, image_grid_thw):
+        """[B, N_QUERY, 3584] hidden states of the latent trajectory queries (internvla_n1.py:320-347). When called right after
+        generate() on its own output (the reference's only usage, internvla_n1_policy.py:191) the KV cache is reused: the queries
+        are placed behind each sequence's last kept token; otherwise the full prompt is re-run."""
+        g = getattr(self, "_gen", None)
+        if g is not None and output_ids.shape[1] == g["prompt_len"] + g["tokens"].shape[1] and \
+                torch.equal(output_ids[:, g["prompt_len"]:].cpu().long(), g["tokens"]):
+            S, lens, toks = g["prompt_len"], g["lens"], g["tokens"]
+            last = torch.stack([toks[b, lens[b] - 1] for b in range(toks.shape[0])]).to(self.device, torch.int32).view(-1, 1)
+            return self.qwen.latents(g["state"], last.contiguous(), seq_lens=S + lens - 1)
+        pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None else None
+        return self.qwen.generate_latents(output_ids, pv, image_grid_thw)
+
+    # ---- System 1
+    def generate_traj(self, traj_latents, images_dp, depths_dp=None, predict_step_nums: int = 32, guidance_scale: float = 1.0,
+                      num_inference_steps: int = 10, num_sample_trajs: int = 32, noise: Optional[dict] = None):
+        """[32*B, T, 3] sampled trajectories (internvla_n1.py:349-441). `noise` = dict(x_init[, step_noise]) makes the sampler
+        reproducible / checkable; by default it is drawn on the device like the reference's randn_tensor / torch.randn."""
+        B = traj_latents.shape[0]
+        s1 = self.s1
+        S, T = s1.S, s1.T
+        x_init = noise["x_init"] if noise else torch.randn(B, S, T, 3, device=self.device, generator=self._noise_gen)
+        lat = traj_latents.to(self.device, torch.bfloat16)
+        if isinstance(s1, NextDiTSystem1):
+            assert guidance_scale == 1.0 and num_inference_steps == s1.cfg["num_inference_steps"] and predict_step_nums == T
+            out = s1.generate_traj(lat, images_dp.to(self.device), x_init)
+        else:
+            K = s1.cfg["num_train_timesteps"]
+            sn = noise["step_noise"] if noise else torch.randn(K, B, S, T, 3, device=self.device, generator=self._noise_gen)
+            out = s1.predict_pointgoal_action_async(lat, images_dp.to(self.device), depths_dp.to(self.device), x_init, sn)
+        return out.reshape(B * S, T, 3).clone()
+
+
+class _Prefixed:
+    """view of a weight mapping under a key prefix (checkpoints carry the System-1 modules under `model.`)."""
+
+    def __init__(self, base, prefix):
+        self.base, self.prefix = base, prefix
+
+    def __getitem__(self, k):
+        return self.base[self.prefix + k]
+
+    def get(self, k, default=None):
+        try:
+            return self.base[self.prefix + k]
+        except KeyError:
+            return default
+
+    def __contains__(self, k):
+        try:
+            self.base[self.prefix + k]
+            return True
+        except KeyError:
+            return False
+
+
+# ------------------------------------------------------------------------------------------------------ policy wrapper
+class InternVLAN1Net:
+    """`InternVLAN1Net` of the reference (internvla_n1_policy.py:26-215) for ONE environment's episode state; the batched agent
+    (internnav_amd/agent.py) holds one instance per env that share a single model and batches their model calls."""
+
+    PROMPT = ("You are an autonomous navigation assistant. Your task is to <instruction>. Where should you go next to stay on track? "
+              "Please output the next waypoint's coordinates in the image. Please output STOP when you have successfully completed the task.")
+    CONJUNCTION = "you can see "
+    ACTIONS2IDX = OrderedDict({"STOP": [0], "↑": [1], "←": [2], "→": [3], "↓": [5]})
+
+    def __init__(self, model: InternVLAN1ForCausalLM, processor, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
+                 continuous_traj: bool = True):
+        self.model, self.processor = model, processor
+        self.num_history, self.resize_w, self.resize_h, self.continuous_traj = num_history, resize_w, resize_h, continuous_traj
+        self.device = model.device
+        self.reset()
+
+    def eval(self):
+        return self
+
+    def reset(self):
+        self.rgb_list, self.depth_list, self.pose_list = [], [], []
+        self.episode_idx = 0
+        self.conversation_history = []
+        self.llm_output = ""
+        self.input_images = []
+
+    def parse_actions(self, output: str) -> List[int]:
+        regex = re.compile("|".join(re.escape(a) for a in self.ACTIONS2IDX))
+        return list(itertools.chain.from_iterable(self.ACTIONS2IDX[m] for m in regex.findall(output)))
+
+    def _to_image(self, rgb, resize: bool):
+        from PIL import Image
+
+        image = Image.fromarray(rgb).convert("RGB")
+        return image.resize((self.resize_w, self.resize_h)) if resize else image
+
+    def step_no_infer(self, rgb, depth, pose):
+        self.rgb_list.append(self._to_image(rgb, True))
+        self.episode_idx += 1
+
+    def build_s2_inputs(self, rgb, instruction: str, look_down: bool = False):
+        """steps 1-2 of s2_step (internvla_n1_policy.py:110-165): history sampling, prompt, chat template, processor call."""
+        image = self._to_image(rgb, not look_down)
+        if not look_down:
+            self.rgb_list.append(image)
+            self.conversation_history = []
+            text = self.PROMPT.replace("<instruction>.", instruction)
+            if self.episode_idx == 0:
+                history_id = []
+            else:
+                history_id = np.unique(np.linspace(0, self.episode_idx - 1, self.num_history, dtype=np.int32)).tolist()
+                text += f" These are your historical observations: {('<image>' + chr(10)) * len(history_id)}."
+            self.input_images = [self.rgb_list[i] for i in sorted(history_id)] + self.rgb_list[-1:]
+            img_id = 0
+            self.episode_idx += 1
+        else:
+            self.input_images.append(image)
+            img_id = -1
+            assert self.llm_output != "", "Last llm_output should not be empty when look down"
+            text = ""
+            self.conversation_history.append({"role": "assistant", "content": [{"type": "text", "text": self.llm_output}]})
+        text += f" {self.CONJUNCTION}<image>."
+        content = []
+        for part in split_and_clean(text):
+            if part == "<image>":
+                content.append({"type": "image", "image": self.input_images[img_id]})
+                img_id += 1
+            else:
+                content.append({"type": "text", "text": part})
+        self.conversation_history.append({"role": "user", "content": content})
+        chat = self.processor.apply_chat_template(self.conversation_history, tokenize=False, add_generation_prompt=True)
+        return self.processor(text=[chat], images=self.input_images, return_tensors="pt")
+
+    def finish_s2(self, inputs, output_ids, latents_fn) -> S2Output:
+        """steps 3-4 of s2_step (internvla_n1_policy.py:177-197): decode text, pixel goal -> latents, else discrete actions."""
+        self.llm_output = self.processor.tokenizer.decode(output_ids[0][inputs["input_ids"].shape[1]:], skip_special_tokens=True)
+        out = S2Output()
+        if re.search(r"\d", self.llm_output):
+            coord = [int(c) for c in re.findall(r"\d+", self.llm_output)]
+            out.output_pixel = np.array([int(coord[1]), int(coord[0])]) if len(coord) >= 2 else np.array([0, int(coord[0])])
+            out.output_latent = latents_fn()
+        else:
+            out.output_action = self.parse_actions(self.llm_output)
+        return out
+
+    def s2_step(self, rgb, depth, pose, instruction, intrinsic, look_down: bool = False) -> S2Output:
+        inputs = self.build_s2_inputs(rgb, instruction, look_down)
+        ids = self.model.generate(input_ids=inputs["input_ids"], pixel_values=inputs["pixel_values"], image_grid_thw=inputs["image_grid_thw"],
+                                  max_new_tokens=128, do_sample=False, use_cache=True, past_key_values=None, return_dict_in_generate=True).sequences
+        return self.finish_s2(inputs, ids, lambda: self.model.generate_latents(ids, inputs["pixel_values"], inputs["image_grid_thw"]))
+
+    def s1_step_latent(self, rgb, depth, latent) -> S1Output:
+        dp_actions = self.model.generate_traj(traj_latents=latent, images_dp=rgb, depths_dp=depth)
+        return self.actions_from_traj(dp_actions)
+
+    def actions_from_traj(self, dp_actions) -> S1Output:
+        if self.continuous_traj:
+            action_list = traj_to_actions(dp_actions)
+        else:
+            action_list = chunk_token(dp_actions[np.random.choice(dp_actions.shape[0])])
+        return S1Output(idx=[x for x in action_list if x != 0][:4])

@@ -276,7 +276,28 @@ def gold_qwen(B=2, n_img=2):
                 logits_sample=logits[:, ::37].clone(), generated=gen, latents=latents, oracle_max_abs_diff=d)
 
 
-UNITS = {"dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_vln_utils():
+    """The reference's own host post-processing (internnav/model/utils/vln_utils.py) on seeded trajectories: the integer action
+    lists are the known answers for internnav_amd.policy.traj_to_actions / chunk_token / split_and_clean (bit-exact)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_vln_utils", str(R.REF / "internnav" / "model" / "utils" / "vln_utils.py"))
+    vu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vu)
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for i in range(12):
+        base = torch.tensor([[1.2 - 0.15 * i, 0.35 * ((i % 5) - 2), 0.1 * ((i % 3) - 1)]]) * (1 + 0.2 * (i % 4))
+        traj = (base.view(1, 1, 3) * torch.linspace(1.0, 0.3, 32).view(1, 32, 1) + 0.05 * torch.randn(32, 32, 3, generator=g)).contiguous()
+        inp = traj.clone()
+        acts = vu.traj_to_actions(inp)
+        chunks = vu.chunk_token(traj[0] / 4.0)
+        cases.append(dict(traj=traj, actions=[int(a) for a in acts], mutated=inp, chunk=[int(a) for a in chunks]))
+    texts = ["go to <image>\n the door. you can see <image>.", "<image><image> a \n b", "no image here"]
+    return dict(cases=cases, texts=texts, split=[vu.split_and_clean(t) for t in texts], oracle_max_abs_diff=0.0)
+
+
+UNITS = {"vln_utils": gold_vln_utils, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

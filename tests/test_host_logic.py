@@ -1,0 +1,161 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no HIP compute calls): integer/index logic, the host
+post-processing mirrored from the reference's vln_utils, the batched agent state machine, and the data-parallel helpers."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def test_vln_utils_mirror_is_bit_exact_vs_reference():
+    from internnav_amd.policy import chunk_token, split_and_clean, traj_to_actions
+
+    g = torch.load(GOLD / "vln_utils.pt", weights_only=True)
+    for c in g["cases"]:
+        t = c["traj"].clone()
+        assert traj_to_actions(t) == c["actions"]
+        assert torch.equal(t, c["mutated"])  # the reference un-normalises its input in place (vln_utils.py:129): contract kept
+        assert chunk_token(c["traj"][0] / 4.0) == c["chunk"]
+    assert [split_and_clean(t) for t in g["texts"]] == g["split"]
+
+
+def test_rope_index_and_window_permutation_match_fixture_and_oracle():
+    from internnav_amd import synthetic
+    from internnav_amd.qwen_vl import rope_index, vision_window_permutation
+    from oracle import qwen_vl as o_q
+
+    gold = torch.load(GOLD / "qwen.pt", weights_only=True)
+    cfg = synthetic.QWEN_TEST_CFG
+    inp = synthetic.qwen_inputs(gold["B"], gold["n_img"], seed=gold["seed"], cfg=cfg)
+    grids = [tuple(g) for g in inp["grid_thw"].tolist()]
+    pos, deltas = rope_index(inp["input_ids"].numpy(), grids, cfg["image_token_id"], cfg["vision_start_id"])
+    assert np.array_equal(pos, gold["position_ids"].numpy())
+    # ragged / odd grids incl. the 476x644 look-down frame (34x46 patches) and a tiny 2x2-cell image
+    for gs in ([(1, 28, 28)], [(1, 34, 46), (1, 28, 28)], [(1, 4, 4)], [(1, 16, 16), (1, 18, 30), (1, 28, 28)]):
+        wi, cu = vision_window_permutation(gs)
+        owi, ocu = o_q.vision_window_index(gs)
+        assert np.array_equal(wi, owi.numpy()) and np.array_equal(cu, ocu.numpy())
+        assert sorted(wi.tolist()) == list(range(len(wi)))  # a permutation
+    # text-only prompt: plain arange on all three axes
+    ids = np.arange(12)[None]
+    p, d = rope_index(ids, [], cfg["image_token_id"], cfg["vision_start_id"])
+    assert np.array_equal(p, np.broadcast_to(np.arange(12), (3, 1, 12))) and d[0] == 0
+
+
+class _StubModel:
+    device = torch.device("cpu")
+
+
+class _StubPolicy:
+    """deterministic stand-in for InternVLAN1Net: scripted S2 answers, fixed S1 action lists."""
+
+    def __init__(self, script, s1):
+        self.model = _StubModel()
+        self.script, self.s1, self.calls = list(script), s1, []
+
+    def reset(self):
+        self.calls.append("reset")
+
+    def step_no_infer(self, rgb, depth, pose):
+        self.calls.append("no_infer")
+
+
+def _agent(mode, script, s1_idx):
+    from internnav_amd.agent import InternVLAN1Agent
+    from internnav_amd.policy import S1Output, S2Output
+
+    pol = _StubPolicy(script, s1_idx)
+    ag = InternVLAN1Agent({"model_settings": {"infer_mode": mode}}, policy_factory=lambda: pol)
+
+    def run_s2(jobs):
+        for e, o in jobs:
+            kind = pol.script.pop(0)
+            pol.calls.append(("s2", kind, e.look_down))
+            so = S2Output(idx=e.episode_step, rgb_memory=o["rgb"], depth_memory=o["depth"])
+            if kind == "latent":
+                so.output_pixel, so.output_latent = np.array([1, 2]), torch.zeros(1, 4, 8)
+            else:
+                so.output_action = list(kind)
+            e.s2_output = so
+
+    def run_s1(jobs):
+        for e, _ in jobs:
+            pol.calls.append("s1")
+            e.s1_output = S1Output(idx=list(pol.s1))
+
+    ag._run_s2, ag._run_s1 = run_s2, run_s1
+    return ag, pol
+
+
+OBS = [{"rgb": np.zeros((4, 4, 3), np.uint8), "depth": np.zeros((4, 4, 1), np.float32), "instruction": "go"}]
+
+
+def test_agent_partial_async_cadence():
+    """1 S2 (pixel goal) then S1 every 4 actions, S2 again after sys2_max_forward_step = 8 executed steps (agent :210-241, :338-350)."""
+    ag, pol = _agent("partial_async", ["latent", "latent"], [1, 1, 2, 1])
+    ag.reset()
+    acts = [ag.step(OBS)[0]["action"][0] for _ in range(10)]
+    assert acts == [1, 1, 2, 1, 1, 1, 2, 1, 1, 1]
+    kinds = [c if isinstance(c, str) else c[0] for c in pol.calls]
+    assert kinds.count("s2") == 2 and kinds.count("s1") == 3
+    assert [i for i, k in enumerate(kinds) if k == "s2"][1] > [i for i, k in enumerate(kinds) if k == "s1"][1]
+
+
+def test_agent_discrete_actions_and_look_down_turn():
+    """S2 answering arrows: actions are queued; a look-down (5) returns -1 and forces S2 on the next frame with look_down=True (:284-292)."""
+    ag, pol = _agent("sync", [[1, 5, 2], [3], [0]], [1])
+    ag.reset()
+    out = [ag.step(OBS)[0] for _ in range(4)]
+    assert [o["action"] for o in out] == [[1], [-1], [3], [0]]
+    assert all(o["ideal_flag"] is True for o in out)
+    s2 = [c for c in pol.calls if isinstance(c, tuple)]
+    assert [c[2] for c in s2] == [False, True, False]
+    import json
+
+    json.dumps(out)  # served over HTTP by the reference's AgentServer
+
+
+def test_agent_is_batched_and_resets_single_envs():
+    ag, pol = _agent("sync", [[1, 1], [2, 2], [3]], [1])
+    obs2 = OBS * 2
+    a = ag.step(obs2)
+    assert [x["action"] for x in a] == [[1], [2]]
+    ag.reset([1])
+    a = ag.step(obs2)
+    assert [x["action"] for x in a] == [[1], [3]]  # env 1 restarted its episode -> S2 again; env 0 continues its queue
+
+
+def _dist_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from internnav_amd import dist as D
+
+    r, _, w = D.init_distributed("gloo")
+    eps = D.shard_episodes(list(range(11)), r, w)
+    acts = torch.full((3, 4), float(r))
+    g = D.all_gather_actions(acts)
+    m = D.all_gather_metrics(torch.tensor([float(e) for e in eps]))
+    q.put((r, eps, g.tolist(), sorted(m.tolist())))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_helpers_gloo_world2():
+    """N > 1 path on CPU: episode striding like habitat_env.py:72, per-step action all_gather, padded metric all_gather."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+    assert res[0][1] == [0, 2, 4, 6, 8, 10] and res[1][1] == [1, 3, 5, 7, 9]
+    for r in res:
+        assert r[2] == [[[0.0] * 4] * 3, [[1.0] * 4] * 3]
+        assert r[3] == [float(i) for i in range(11)]
