@@ -198,30 +198,32 @@ class QwenVLEngine:
         self.axis_of = torch.from_numpy(axis).to(dev)
 
     # ------------------------------------------------------------------------------------------------ vision tower
-    def vision(self, pixel_values: torch.Tensor, grids: List[Tuple[int, int, int]]) -> torch.Tensor:
-        """pixel_values bf16 [Np, 1176] (HF processor patch layout), grids [(t,h,w)] -> image embeds bf16 [Np/4, 3584] in WINDOW order;
-        returns (emb, inv) where inv[k] is the emb row of the k-th image token in sequence order."""
-        dev, D, Hh, hd = self.device, self.vD, self.vH, self.vhd
-        Np = pixel_values.shape[0]
-        assert Np <= self.Np_max and pixel_values.dtype == torch.bfloat16
+    def plan_vision(self, grids: List[Tuple[int, int, int]]) -> dict:
+        """host side of the vision tower for a list of image grids: window permutation, cu_seqlens, rope tables (uploaded once)."""
+        dev, hd = self.device, self.vhd
         win_idx, cu_win = vision_window_permutation(grids, 2, self.cfg["v_window"], self.cfg["v_patch"])
         perm = (win_idx[:, None] * 4 + np.arange(4)[None]).reshape(-1).astype(np.int32)
         cu_full = np.concatenate([[0], np.cumsum([t * h * w for t, h, w in grids])]).astype(np.int32)
         cos, sin = vision_rope_tables(grids, hd)
-        perm_t = torch.from_numpy(perm).to(dev)
-        self.v_cos[:Np].copy_(cos[perm].to(dev))
-        self.v_sin[:Np].copy_(sin[perm].to(dev))
-        cu_win_t, cu_full_t = torch.from_numpy(cu_win).to(dev), torch.from_numpy(cu_full).to(dev)
-        max_win, max_full = int(np.diff(cu_win).max()), int(np.diff(cu_full).max())
+        Np = int(cu_full[-1])
+        assert Np <= self.Np_max, f"{Np} patches exceed the engine's max_patches={self.Np_max}"
+        return dict(Np=Np, perm=torch.from_numpy(perm).to(dev), cos=cos[perm].contiguous().to(dev), sin=sin[perm].contiguous().to(dev),
+                    cu_win=torch.from_numpy(cu_win).to(dev), cu_full=torch.from_numpy(cu_full).to(dev),
+                    max_win=int(np.diff(cu_win).max()), max_full=int(np.diff(cu_full).max()), inv=np.argsort(win_idx).astype(np.int32))
+
+    def run_vision(self, vp: dict, pixel_values: torch.Tensor) -> torch.Tensor:
+        """launch sequence of the vision tower (graph capturable): pixel_values bf16 [Np, 1176] -> embeds bf16 [Np/4, 3584], WINDOW order."""
+        D, Hh, hd, Np = self.vD, self.vH, self.vhd, vp["Np"]
+        assert pixel_values.shape[0] == Np and pixel_values.dtype == torch.bfloat16
         xp, x, h, att, qkv, ff = self.pv_perm[:Np], self.xv[:Np], self.hv[:Np], self.attv[:Np], self.qkvv[:Np], self.ffv[:Np]
-        ops.gather_rows(pixel_values, xp, src=perm_t)
+        ops.gather_rows(pixel_values, xp, src=vp["perm"])
         ops.linear(xp, self.v_patch, out=x)
         q3 = qkv.view(Np, 3, Hh, hd)
         for blk in self.v_blocks:
             ops.norm(x, blk["n1"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, blk["qkv_w"], bias=blk["qkv_b"], out=qkv)
-            ops.rope(qkv, self.v_cos, self.v_sin, heads=2 * Hh, D=hd, col0=0, rows=Np)
-            cu, mx = (cu_full_t, max_full) if blk["full"] else (cu_win_t, max_win)
+            ops.rope(qkv, vp["cos"], vp["sin"], heads=2 * Hh, D=hd, col0=0, rows=Np)
+            cu, mx = (vp["cu_full"], vp["max_full"]) if blk["full"] else (vp["cu_win"], vp["max_win"])
             ops.attention(q3[:, 0], q3[:, 1], q3[:, 2], cu_q=cu, cu_k=cu, max_q=mx, max_k=mx, out=att.view(Np, Hh, hd))
             ops.linear(att, blk["proj_w"], bias=blk["proj_b"], residual=x, out=x)
             ops.norm(x, blk["n2"], None, eps=1e-6, rms=True, out=h)
@@ -230,63 +232,47 @@ class QwenVLEngine:
         ops.norm(x, self.m_ln, None, eps=1e-6, rms=True, out=h)
         ops.linear(h.view(Np // 4, 4 * D), self.m0[0], bias=self.m0[1], act="gelu", out=self.mh[: Np // 4])
         ops.linear(self.mh[: Np // 4], self.m2[0], bias=self.m2[1], out=self.emb[: Np // 4])
-        inv = np.argsort(win_idx).astype(np.int32)
-        return self.emb[: Np // 4], inv
+        return self.emb[: Np // 4]
+
+    def vision(self, pixel_values: torch.Tensor, grids: List[Tuple[int, int, int]]):
+        """pixel_values bf16 [Np, 1176] (HF processor patch layout) -> (embeds in WINDOW order, inv) with inv[k] = embed row of the
+        k-th image token in sequence order."""
+        vp = self.plan_vision(grids)
+        return self.run_vision(vp, pixel_values), vp["inv"]
 
     # ------------------------------------------------------------------------------------------------ text model
-    def _layers(self, B: int, S: int, pos0: int, first_from_bf16: bool, k_len: Optional[torch.Tensor] = None, Lk: Optional[int] = None):
-        """28 decoder layers on rows [B*S] whose tokens sit at cache positions pos0 .. pos0+S-1 of each sequence (or, with k_len,
-        at the per-sequence positions k_len[b]-S .. k_len[b]-1 given by self._cache_rows)."""
+    def _phase(self, B: int, S: int, pos3: np.ndarray, cache_pos0, k_len: Optional[np.ndarray] = None) -> dict:
+        """host side of one pass of the decoder stack over B x S new tokens: 3-D position ids, cache rows, key lengths."""
+        dev = self.device
+        pos0 = np.broadcast_to(np.asarray(cache_pos0, dtype=np.int64).reshape(-1, 1), (B, 1))
+        rows = (np.arange(B)[:, None] * self.S_max + pos0 + np.arange(S)[None]).reshape(-1).astype(np.int32)
+        assert int(pos0.max()) + S <= self.S_max, "KV cache capacity (max_seq_len) exceeded"
+        ph = dict(B=B, S=S, pos=torch.from_numpy(np.ascontiguousarray(np.broadcast_to(pos3, (3, B, S)).reshape(3, B * S)).astype(np.int32)).to(dev),
+                  rows=torch.from_numpy(rows).to(dev), Lk=int(pos0.max()) + S, k_len=None)
+        if k_len is not None:
+            ph["k_len"] = torch.from_numpy(np.asarray(k_len, dtype=np.int32)).to(dev)
+        return ph
+
+    def _layers(self, ph: dict):
+        """28 decoder layers over the phase's rows (x_in holds their bf16 input embeddings); K/V land at ph['rows'] of the cache."""
         H, nh, nkv, hd, Smax = self.H, self.nh, self.nkv, self.hd, self.S_max
+        B, S = ph["B"], ph["S"]
         rows = B * S
         x, h, att, qkv, ff = self.x[:rows], self.h[:rows], self.att[:rows], self.qkv[:rows], self.ff[:rows]
-        Lk = pos0 + S if Lk is None else Lk
+        ops.mrope_table(ph["pos"], self.inv_freq, self.axis_of, self.cos, self.sin)
         q4 = qkv[:, : nh * hd].view(B, S, nh, hd)
         for li, L in enumerate(self.layers):
-            src = self.x_in[:rows] if (li == 0 and first_from_bf16) else x
+            src = self.x_in[:rows] if li == 0 else x
             ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
             ops.rope(qkv, self.cos, self.sin, heads=nh + nkv, D=hd, col0=0, rows=rows)
-            ops.gather_rows(qkv[:, nh * hd:], L["kv"], dst=self._cache_rows[:rows])
-            kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[:B, :Lk]
-            ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=k_len)
+            ops.gather_rows(qkv[:, nh * hd:], L["kv"], dst=ph["rows"])
+            kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[:B, : ph["Lk"]]
+            ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
             ops.linear(att, L["o_w"], residual=src, out=x)
             ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
             ops.linear(ff, L["down_w"], residual=x, out=x)
-
-    def _set_positions(self, B: int, S: int, pos3: np.ndarray, pos0):
-        """upload 3-D position ids [3, B*S] -> m-rope tables; cache row of every token (b * S_max + pos0[b] + s)."""
-        dev = self.device
-        p = torch.from_numpy(np.ascontiguousarray(pos3.reshape(3, B * S)).astype(np.int32)).to(dev)
-        ops.mrope_table(p, self.inv_freq, self.axis_of, self.cos, self.sin)
-        pos0 = np.broadcast_to(np.asarray(pos0, dtype=np.int64).reshape(-1, 1), (B, 1))
-        rows = (np.arange(B)[:, None] * self.S_max + pos0 + np.arange(S)[None]).reshape(-1).astype(np.int32)
-        self._cache_rows = torch.from_numpy(rows).to(dev)
-
-    def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor], image_grid_thw) -> dict:
-        """Embed + scatter + 28 layers over the whole prompt (B equal-length sequences); fills the KV cache; returns the state."""
-        cfg, dev, H = self.cfg, self.device, self.H
-        ids = input_ids.cpu().numpy().astype(np.int64)
-        B, S = ids.shape
-        assert B <= self.B_max and S <= self.S_max
-        grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
-        flat = ids.reshape(-1)
-        ops.gather_rows(self.embed, self.x_in, src=torch.from_numpy(flat.astype(np.int32)).to(dev))
-        img_pos = np.nonzero(flat == cfg["image_token_id"])[0].astype(np.int32)
-        if pixel_values is not None and len(grids):
-            emb, inv = self.vision(pixel_values, grids)
-            assert img_pos.size == inv.size, f"Image features and image tokens do not match: tokens: {img_pos.size}, features {inv.size}"
-            ops.gather_rows(emb, self.x_in, src=torch.from_numpy(inv).to(dev), dst=torch.from_numpy(img_pos).to(dev))
-        traj_pos = np.nonzero(flat == cfg["traj_token_id"])[0].astype(np.int32)
-        if traj_pos.size:
-            nq = self.latent_q.shape[0]
-            srcq = (np.arange(traj_pos.size) % nq).astype(np.int32)
-            ops.gather_rows(self.latent_q, self.x_in, src=torch.from_numpy(srcq).to(dev), dst=torch.from_numpy(traj_pos).to(dev))
-        pos3, deltas = rope_index(ids, grids, cfg["image_token_id"], cfg["vision_start_id"])
-        self._set_positions(B, S, pos3, 0)
-        self._layers(B, S, 0, first_from_bf16=True)
-        return dict(B=B, S=S, next_pos=pos3[:, :, -1].max(axis=0) + 1)
 
     def _last_logits(self, B: int, S: int, row_in_seq: int):
         """final RMSNorm + lm_head on ONE row per sequence, greedy argmax on the device."""
@@ -294,8 +280,93 @@ class QwenVLEngine:
         ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B])
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
+    # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)
+    def plan(self, input_ids, image_grid_thw, n_decode: int = 0, with_latents: bool = False) -> dict:
+        """Host-side plan of one S2 call for B equal-length prompts: embedding / scatter indices, vision plan, position ids and cache
+        rows of the prefill, of every decode step and of the latent-query pass (fixed-length answers of n_decode tokens)."""
+        cfg, dev = self.cfg, self.device
+        ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
+        B, S = ids.shape
+        assert B <= self.B_max and S <= self.S_max
+        grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
+        flat = ids.reshape(-1)
+        P = dict(B=B, S=S, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None)
+        img_pos = np.nonzero(flat == cfg["image_token_id"])[0].astype(np.int32)
+        if grids:
+            vp = self.plan_vision(grids)
+            assert img_pos.size == vp["inv"].size, f"Image features and image tokens do not match: tokens: {img_pos.size}, features {vp['inv'].size}"
+            P["vision"], P["img_src"], P["img_dst"] = vp, torch.from_numpy(vp["inv"]).to(dev), torch.from_numpy(img_pos).to(dev)
+        traj_pos = np.nonzero(flat == cfg["traj_token_id"])[0].astype(np.int32)
+        if traj_pos.size:
+            nq = self.latent_q.shape[0]
+            P["traj_src"] = torch.from_numpy((np.arange(traj_pos.size) % nq).astype(np.int32)).to(dev)
+            P["traj_dst"] = torch.from_numpy(traj_pos).to(dev)
+        pos3, _ = rope_index(ids, grids, cfg["image_token_id"], cfg["vision_start_id"])
+        P["prefill"] = self._phase(B, S, pos3, 0)
+        nxt = pos3[:, :, -1].max(axis=0) + 1                      # text position of the first generated token, per sequence
+        P["next_pos"] = nxt
+        P["decode"] = [self._phase(B, 1, (nxt + j)[None, :, None], S + j) for j in range(max(n_decode - 1, 0))]
+        if with_latents:
+            nq = self.latent_q.shape[0]
+            cur = S + max(n_decode - 1, 0)                        # cached tokens after the decode steps
+            m = 1 if n_decode > 0 else 0                          # the last sampled token has no K/V yet
+            p = (nxt + (cur - S))[None, :, None] + np.arange(m + nq)[None, None, :]
+            P["latents"] = self._phase(B, m + nq, p, cur)
+            P["lat_m"] = m
+        return P
+
+    def run_prefill(self, P: dict, pixel_values: Optional[torch.Tensor]):
+        ops.gather_rows(self.embed, self.x_in, src=P["ids"])
+        if P["vision"] is not None:
+            emb = self.run_vision(P["vision"], pixel_values)
+            ops.gather_rows(emb, self.x_in, src=P["img_src"], dst=P["img_dst"])
+        if "traj_src" in P:
+            ops.gather_rows(self.latent_q, self.x_in, src=P["traj_src"], dst=P["traj_dst"])
+        self._layers(P["prefill"])
+
+    def run_decode(self, P: dict, tokens_out: torch.Tensor):
+        """n_decode greedy tokens: the first from the prompt's last position, then n_decode - 1 single-token passes."""
+        B, S, n = P["B"], P["S"], P["n_decode"]
+        if n == 0:
+            return
+        self._last_logits(B, S, S - 1)
+        for j in range(n):
+            tokens_out[:, j].copy_(self.next_tok[:B])
+            if j == n - 1:
+                break
+            ops.gather_rows(self.embed, self.x_in, src=self.next_tok[:B], rows=B)
+            self._layers(P["decode"][j])
+            self._last_logits(B, 1, 0)
+
+    def run_latents(self, P: dict, out: torch.Tensor):
+        """N_QUERY latent queries (behind the last sampled token) against the KV cache -> out bf16 [B, N_QUERY, H]."""
+        B, H, m = P["B"], self.H, P["lat_m"]
+        nq = self.latent_q.shape[0]
+        x3 = self.x_in[: B * (m + nq)].view(B, m + nq, H)
+        if m:
+            tmp = self.hl[:B]
+            ops.gather_rows(self.embed, tmp, src=self.next_tok[:B], rows=B)
+            x3[:, 0].copy_(tmp)
+        x3[:, m:].copy_(self.latent_q.view(1, nq, H).expand(B, nq, H))
+        self._layers(P["latents"])
+        ops.norm(self.x[: B * (m + nq)], self.norm_w, None, eps=1e-6, rms=True, out=out.view(B * nq, H), rows=B * nq, in_map=(nq, m + nq, m))
+
+    def run_s2(self, P: dict, pixel_values, tokens_out: torch.Tensor, latents_out: Optional[torch.Tensor]):
+        """whole System-2 call as one launch sequence: ViT + prefill + n_decode greedy tokens (+ latent queries)."""
+        self.run_prefill(P, pixel_values)
+        self.run_decode(P, tokens_out)
+        if latents_out is not None:
+            self.run_latents(P, latents_out)
+
+    # ---- eager, stateful API (used by the policy layer: answers have data-dependent lengths)
+    def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor], image_grid_thw) -> dict:
+        P = self.plan(input_ids, image_grid_thw)
+        self.run_prefill(P, pixel_values)
+        return dict(B=P["B"], S=P["S"], next_pos=P["next_pos"].copy())
+
     def decode(self, state: dict, n_steps: int) -> torch.Tensor:
-        """n greedy steps after prefill (or after a previous decode); returns int32 [B, n] generated tokens (device)."""
+        """n greedy steps after prefill (or after a previous decode); returns int32 [B, n] generated tokens (device). The last
+        returned token is sampled but not yet run through the layers (its K/V are not cached)."""
         B, S = state["B"], state["S"]
         out = torch.empty(B, n_steps, dtype=torch.int32, device=self.device)
         if "cur" not in state:
@@ -306,15 +377,11 @@ class QwenVLEngine:
             if j == n_steps - 1:
                 break
             cur = state["cur"]
-            assert cur < self.S_max
             ops.gather_rows(self.embed, self.x_in, src=self.next_tok[:B], rows=B)
-            p = np.broadcast_to(state["next_pos"][None, :, None], (3, B, 1))
-            self._set_positions(B, 1, p, cur)
-            self._layers(B, 1, cur, first_from_bf16=True)
+            self._layers(self._phase(B, 1, state["next_pos"][None, :, None], cur))
             self._last_logits(B, 1, 0)
             state["cur"] = cur + 1
             state["next_pos"] = state["next_pos"] + 1
-        state["last_tok"] = out[:, -1]
         return out
 
     def latents(self, state: dict, tail_tokens: Optional[torch.Tensor], seq_lens: Optional[np.ndarray] = None) -> torch.Tensor:
@@ -322,12 +389,11 @@ class QwenVLEngine:
         tail_tokens int32 [B, m]: tokens to run in front of the queries because their K/V are not cached yet (the last sampled
         token). seq_lens [B]: number of cached tokens to keep per sequence (prompt + answer up to where it ended); the m + N_QUERY
         new tokens are placed right behind them, K/V cached beyond that point (post-EOS decode steps) are ignored / overwritten."""
-        cfg, B, H = self.cfg, state["B"], self.H
+        B, H = state["B"], self.H
         nq = self.latent_q.shape[0]
         m = 0 if tail_tokens is None else tail_tokens.shape[1]
         rows = B * (m + nq)
         cur = state.get("cur", state["S"])
-        assert cur + m + nq <= self.S_max
         x3 = self.x_in[:rows].view(B, m + nq, H)
         if m:
             tmp = self.hl[: B * m]
@@ -336,15 +402,13 @@ class QwenVLEngine:
         x3[:, m:].copy_(self.latent_q.view(1, nq, H).expand(B, nq, H))
         if seq_lens is None:
             p = state["next_pos"][None, :, None] + np.arange(m + nq)[None, None, :]
-            self._set_positions(B, m + nq, np.broadcast_to(p, (3, B, m + nq)), cur)
-            self._layers(B, m + nq, cur, first_from_bf16=True)
+            ph = self._phase(B, m + nq, p, cur)
         else:
             seq_lens = np.asarray(seq_lens, dtype=np.int64)
             start_pos = state["next_pos"] - (cur - seq_lens)          # text positions advance by one per cached token
             p = start_pos[None, :, None] + np.arange(m + nq)[None, None, :]
-            self._set_positions(B, m + nq, np.broadcast_to(p, (3, B, m + nq)), seq_lens)
-            k_len = torch.from_numpy((seq_lens + m + nq).astype(np.int32)).to(self.device)
-            self._layers(B, m + nq, 0, first_from_bf16=True, k_len=k_len, Lk=int(seq_lens.max()) + m + nq)
+            ph = self._phase(B, m + nq, p, seq_lens, k_len=seq_lens + m + nq)
+        self._layers(ph)
         out = torch.empty(B, nq, H, dtype=torch.bfloat16, device=self.device)
         ops.norm(self.x[:rows], self.norm_w, None, eps=1e-6, rms=True, out=out.view(B * nq, H), rows=B * nq, in_map=(nq, m + nq, m))
         return out
@@ -367,8 +431,9 @@ class QwenVLEngine:
         cfg = self.cfg
         nq = self.latent_q.shape[0]
         ids = torch.cat([output_ids.cpu().long(), torch.full((output_ids.shape[0], nq), cfg["traj_token_id"], dtype=torch.long)], dim=1)
-        st = self.prefill(ids, pixel_values, image_grid_thw)
-        B, S = st["B"], st["S"]
+        P = self.plan(ids, image_grid_thw)
+        self.run_prefill(P, pixel_values)
+        B, S = P["B"], P["S"]
         out = torch.empty(B, nq, self.H, dtype=torch.bfloat16, device=self.device)
         ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=out.view(B * nq, self.H), rows=B * nq, in_map=(nq, S, S - nq))
         return out

@@ -53,6 +53,40 @@ def _draw(key: str, shape, kind: str, seed: int) -> torch.Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+class LazyDeviceWeights:
+    """Mapping key -> tensor that draws each parameter directly on the device when it is first read (bf16-representable values,
+    same scale rules as `_draw`, a per-key device generator). Used by bench.py for the 7B-parameter System-2: the state dict
+    never exists on the host (15 GB), and each tensor is released as soon as the engine has repacked it."""
+
+    _SCALE = {"b": 0.1, "ln_b": 0.1, "emb": 0.3, "gate": 0.5, "latent": 1.0}
+
+    def __init__(self, spec: Spec, device, seed: int = 0, prefixes=("",)):
+        self.spec, self.device, self.seed = spec, torch.device(device), seed
+
+    def __contains__(self, key):
+        return key in self.spec
+
+    def keys(self):
+        return self.spec.keys()
+
+    def __getitem__(self, key: str) -> torch.Tensor:
+        shape, kind = self.spec[key]
+        g = torch.Generator(device=self.device).manual_seed((zlib.crc32(key.encode()) ^ (self.seed * 0x9E3779B1)) & 0x7FFFFFFF)
+        r = torch.randn(shape, generator=g, dtype=torch.float32, device=self.device)
+        if kind in ("w", "w_small"):
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            r.mul_((0.5 if kind == "w_small" else 1.0) * fan_in ** -0.5)
+        elif kind == "ln_w":
+            r.mul_(0.1).add_(1.0)
+        elif kind == "gamma":
+            r.mul_(0.1).add_(0.5)
+        else:
+            r.mul_(self._SCALE[kind])
+        return r.to(torch.bfloat16)
+
+
 def materialize(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
     return {k: _draw(k, shape, kind, seed) for k, (shape, kind) in spec.items()}
 
@@ -236,6 +270,14 @@ def n1_nextdit_spec(cfg=N1_NEXTDIT_CFG) -> Spec:
     s[p + "norm_out.linear_1.weight"] = ((D, D), "w_small")
     s[p + "norm_out.linear_1.bias"] = ((D,), "b")
     _lin(s, p + "norm_out.linear_2", D, D)
+    return s
+
+
+def n1_full_spec(qwen_cfg=None, system1: str = "nextdit_async") -> Spec:
+    """every parameter of an InternVLA-N1 checkpoint: Qwen2.5-VL (visual.*, model.*, lm_head) + the System-1 modules under `model.`."""
+    s = qwen_spec(qwen_cfg or QWEN_N1_CFG)
+    s1 = n1_nextdit_spec() if "nextdit" in system1 else {("navdp." + k): v for k, v in n1_navdp_spec().items()}
+    s.update({"model." + k: v for k, v in s1.items()})
     return s
 
 

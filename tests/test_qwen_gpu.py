@@ -94,3 +94,48 @@ def test_generate_surface(setup):
     seqs = eng.generate(inp["input_ids"], inp["pixel_values"].to(DEV, torch.bfloat16), inp["grid_thw"], max_new_tokens=3)
     assert seqs.shape == gold["generated"].shape and seqs.dtype == torch.long
     assert torch.equal(seqs[:, : inp["input_ids"].shape[1]], inp["input_ids"])
+
+
+def test_planned_launch_sequence_equals_eager_and_is_graph_capturable(setup):
+    """plan() + run_s2() (host work up front, pure launch sequence) == the eager stateful API, eagerly and replayed from a hipGraph."""
+    gold, cfg, inp, eng = setup
+    pv = inp["pixel_values"].to(DEV, torch.bfloat16)
+    B, S = inp["input_ids"].shape
+    state = eng.prefill(inp["input_ids"], pv, inp["grid_thw"])
+    toks_ref = eng.decode(state, 3).clone()
+    lat_ref = eng.latents(state, toks_ref[:, -1:].contiguous()).clone()
+    P = eng.plan(inp["input_ids"], inp["grid_thw"], n_decode=3, with_latents=True)
+    toks = torch.zeros(B, 3, dtype=torch.int32, device=DEV)
+    lat = torch.zeros(B, cfg["n_query"], cfg["t_hidden"], dtype=torch.bfloat16, device=DEV)
+    eng.run_s2(P, pv, toks, lat)
+    assert torch.equal(toks, toks_ref) and torch.equal(lat, lat_ref)
+    from internnav_amd.runtime import GraphedCall
+
+    toks.zero_()
+    lat.zero_()
+    g = GraphedCall(lambda pixel_values: eng.run_s2(P, pixel_values, toks, lat), {"pixel_values": pv})
+    toks.zero_()
+    lat.zero_()
+    g()
+    torch.cuda.synchronize()
+    assert torch.equal(toks, toks_ref) and torch.equal(lat, lat_ref)
+
+
+def test_facade_generate_then_latents_reuses_cache(setup):
+    """InternVLAN1ForCausalLM surface: generate(...).sequences then generate_latents(output_ids, ...) as the reference's policy calls them."""
+    from internnav_amd.policy import InternVLAN1ForCausalLM
+    from internnav_amd import synthetic
+
+    gold, cfg, inp, eng = setup
+    spec = synthetic.n1_full_spec(cfg)
+    sd = synthetic.materialize({k: v for k, v in spec.items()}, seed=gold["seed"])
+    m = InternVLAN1ForCausalLM(sd, cfg, "nextdit_async", device=DEV, max_envs=gold["B"], max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+    out = m.generate(input_ids=inp["input_ids"], pixel_values=inp["pixel_values"], image_grid_thw=inp["grid_thw"], max_new_tokens=3,
+                     do_sample=False, use_cache=True, past_key_values=None, return_dict_in_generate=True, eos_token_id=-1).sequences
+    assert torch.equal(out.cpu(), gold["generated"])
+    lat = m.generate_latents(out, inp["pixel_values"], inp["grid_thw"])
+    d = (lat.float().cpu() - gold["latents"]).abs()
+    assert d.mean() < 1e-2 * gold["latents"].pow(2).mean().sqrt()
+    img = torch.rand(gold["B"], 2, 224, 224, 3, generator=torch.Generator().manual_seed(1))
+    traj = m.generate_traj(lat, img.to(DEV))
+    assert traj.shape == (32 * gold["B"], 32, 3) and torch.isfinite(traj).all()
