@@ -1,21 +1,26 @@
 #!/usr/bin/env python
 """Benchmark of the MI355X policy engine: policy steps / sec / node (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 64] [--workload navdp_s1]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--envs 64] [--workload n1_dual|navdp_s1]
   N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Workload at N = 1 (config.workload):  "navdp_s1_b64" = BASELINE config #2 - NavDP System-1 only: NavDPNet diffusion
-trajectory head, 10 DDPM steps x 32 samples + critic ranking, batch = 64 envs per GPU, 8 RGB frames + 1 depth frame of
-224x224 per env, seeded random weights at the true architecture shapes, synthetic frames. One bench "step" = one
-policy step of every env of the rank (one `predict_pointgoal_batch_action_vel` over 64 envs) = 64 policy steps.
-Episodes are independent, so ranks shard envs with no data-path exchange ("scaling": "weak", per-GPU work fixed); the
-only collective is the all_gather of the per-env action outputs over RCCL/xGMI (north_star) once per step.
+Workloads (config.workload):
+  n1_dual_b64 (default) - the configuration BASELINE.json's metric is quoted on: InternVLA-N1 full dual system (ViT + Qwen2.5-VL-7B
+      System-2 @ 1 Hz + NextDiT System-1 @ 10 Hz), 64 parallel episodes per GPU (512 per 8-GPU node), 4 x RGB frames (392x392 after
+      the HF processor = 784 patches each) + 64-token instruction -> S = 920 prompt tokens, 8 greedy answer tokens + 4 latent queries
+      per System-2 call, 2 look-down frames of 224x224 + 32 samples x 10 flow-matching steps per System-1 call. One bench step = ONE
+      policy step of every env of the rank: System-1 for all 64 envs, System-2 for the 6-7 envs whose plan expires this step
+      (every env exactly once per 10 steps), i.e. 64 policy steps at the nominal 1 : 10 cadence.
+  navdp_s1_b64 - BASELINE config #2: NavDP System-1 only (NavDPNet, 10 DDPM steps x 32 samples + critic ranking, 8 RGB + 1 depth frame).
+Weights are seeded random at the true architecture shapes (7.6 B + 0.68 B + S1 parameters, drawn on the device; no checkpoint is
+available offline), inputs synthetic and resident in HBM before the timed region. Episodes are independent, so ranks shard envs
+with no data-path exchange ("scaling": "weak"); the only collective is the all_gather of per-env actions over RCCL/xGMI per step.
 
-Timed region: inputs resident in HBM, W warm-up steps, then exactly K steps bracketed by barrier + device synchronise,
-max over ranks. The step replays one hipGraph of the whole call (+ device-side noise draw + the all_gather when N > 1).
-After the timed region rank 0 runs ONE instrumented eager pass with per-launch HIP events (ina_prof_*) to attribute
-time and algorithmic FLOPs to kernel classes for the "roofline" object, and (N = 1 only) times the CPU oracle on a
-bounded sample for "cpu_baseline".
+Timed region: W warm-up steps, then exactly K steps bracketed by barrier + device synchronise, max over ranks. Each engine call
+replays one hipGraph (System-1 over 64 envs; System-2 over a 6- or 7-env micro-batch incl. ViT, prefill, decode, latent queries);
+noise draw, micro-batch gather/scatter, D2H of the trajectories and the host post-processing (traj_to_actions) are inside the step.
+After the timed region rank 0 runs ONE instrumented eager pass with per-launch HIP events (ina_prof_*) to attribute time and
+algorithmic FLOPs to kernel classes for the "roofline" object, and (N = 1 only) times the CPU oracle on a bounded sample.
 """
 from __future__ import annotations
 
@@ -26,6 +31,7 @@ import sys
 import time
 from pathlib import Path
 
+import numpy as np
 import torch
 
 ROOT = Path(__file__).resolve().parent
@@ -40,31 +46,207 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=64, help="environments per GPU")
-    ap.add_argument("--workload", default="navdp_s1")
+    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, seed=0):
-    """The reference PyTorch path on the host cores: the CPU oracle (a port of the reference's NavDPNet inference, pinned
-    against the reference modules) timed on a BOUNDED sample: one env, one full policy step, fp32, batch-1 as the reference runs."""
-    from internnav_amd import synthetic
-    from oracle import navdp as o_navdp  # cpu_baseline leg only
+# ------------------------------------------------------------------------------------------------------------ workloads
+class NavDPS1:
+    """BASELINE config #2."""
 
-    cores = min(64, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    sd = synthetic.navdpnet_state_dict(seed)
-    inp = synthetic.navdpnet_inputs(1, seed)
-    with torch.no_grad():
-        t0 = time.time()
-        o_navdp.navdpnet_pointgoal(sd, inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"], cfg)
-        dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "policy steps/s", "cores": cores, "kind": "port",
-            "sample": "1 env x 1 policy step (9 ViT-S frames + 10 DDPM steps x 32 samples + critic), fp32 torch CPU, batch-1 as the reference executes",
-            "seconds": round(dt, 2)}
+    def __init__(self, a, dev, rank):
+        from internnav_amd import flops, synthetic
+        from internnav_amd.navdp import NavDPNet
+
+        self.cfg = cfg = synthetic.NAVDPNET_CFG
+        self.B = B = a.envs
+        self.name = f"navdp_s1_b{B}"
+        self.desc = {"policy": "NavDPNet (BASELINE config #2: NavDP System-1 only)", "samples_per_env": cfg["sample_num"],
+                     "ddpm_steps": cfg["num_train_timesteps"], "frames_per_env": f"{cfg['memory_size']} rgb + 1 depth @224x224"}
+        self.net = NavDPNet(synthetic.navdpnet_state_dict(seed=0), cfg, dev, max_envs=B)
+        self.g = g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
+        self.inp = dict(
+            goal=torch.randn(B, 3, device=dev, generator=g) * 3.0,
+            images=torch.rand(B, cfg["memory_size"], 224, 224, 3, device=dev, generator=g),
+            depths=torch.rand(B, 1, 224, 224, 1, device=dev, generator=g) * 5.0,
+            x_init=torch.randn(B, cfg["sample_num"], cfg["predict_size"], 3, device=dev, generator=g),
+            step_noise=torch.randn(cfg["num_train_timesteps"], B, cfg["sample_num"], cfg["predict_size"], 3, device=dev, generator=g))
+        self.f_alg = flops.navdpnet_flops_per_env(cfg)["total"]
+        self.graph = None
+        self.action_shape = (B, 8, cfg["predict_size"], 3)
+
+    def _call(self, goal, images, depths, x_init, step_noise):
+        return self.net.predict_pointgoal_batch_action_vel(goal, images, depths, x_init, step_noise)
+
+    def capture(self):
+        from internnav_amd import runtime
+
+        self.graph = runtime.GraphedCall(self._call, self.inp)
+
+    def step(self, i):
+        self.inp["x_init"].normal_(generator=self.g)
+        self.inp["step_noise"].normal_(generator=self.g)
+        neg, pos = self.graph() if self.graph else self._call(**self.inp)
+        return pos
+
+    def instrumented(self):
+        self._call(**self.inp)
+
+    def cpu_baseline(self):
+        from internnav_amd import synthetic
+        from oracle import navdp as o_navdp  # cpu_baseline leg only
+
+        cores = min(64, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        sd = synthetic.navdpnet_state_dict(0)
+        inp = synthetic.navdpnet_inputs(1, 0)
+        with torch.no_grad():
+            t0 = time.time()
+            o_navdp.navdpnet_pointgoal(sd, inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"], self.cfg)
+            dt = time.time() - t0
+        return {"value": round(1.0 / dt, 4), "unit": "policy steps/s", "cores": cores, "kind": "port", "seconds": round(dt, 2),
+                "sample": "1 env x 1 policy step (9 ViT-S frames + 10 DDPM steps x 32 samples + critic), fp32 torch CPU, batch-1 as the reference executes"}
 
 
+class N1Dual:
+    """InternVLA-N1 full dual system at the nominal cadence (the configuration the BASELINE metric is quoted on)."""
+
+    N_IMG, GRID, N_INSTR, N_DECODE, CADENCE = 4, (1, 28, 28), 64, 8, 10
+
+    def __init__(self, a, dev, rank):
+        from internnav_amd import flops, synthetic
+        from internnav_amd.policy import InternVLAN1ForCausalLM, traj_to_actions
+
+        self.traj_to_actions = traj_to_actions
+        self.dev, self.B = dev, a.envs
+        B = self.B
+        self.name = f"n1_dual_b{B}"
+        qcfg, scfg = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_CFG
+        self.qcfg, self.scfg = qcfg, scfg
+        per = self.GRID[1] * self.GRID[2]
+        # prompt layout (HF chat template shape): 34 template tokens | 64 instruction tokens | 4 x (<vs> 196 x <img> <ve>) | 30 tail tokens
+        self.S = 34 + self.N_INSTR + self.N_IMG * (per // 4 + 2) + 30
+        self.mb = [B // self.CADENCE + (1 if j < B % self.CADENCE else 0) for j in range(self.CADENCE)]   # micro-batch sizes, sum = B
+        self.mb_start = np.concatenate([[0], np.cumsum(self.mb)])
+        mmax = max(self.mb)
+        spec = synthetic.n1_full_spec(qcfg, "nextdit_async")
+        weights = synthetic.LazyDeviceWeights(spec, dev, seed=0)
+        self.model = InternVLAN1ForCausalLM(weights, qcfg, "nextdit_async", scfg, device=dev, max_envs=B, max_seq_len=1024,
+                                            max_patches=mmax * self.N_IMG * per, max_s2_seqs=mmax)
+        g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
+        lim = qcfg["image_token_id"] - 16
+        ids = torch.randint(0, lim, (B, self.S), device=dev, generator=g)
+        o = 34 + self.N_INSTR
+        for k in range(self.N_IMG):
+            ids[:, o] = qcfg["vision_start_id"]
+            ids[:, o + 1:o + 1 + per // 4] = qcfg["image_token_id"]
+            ids[:, o + 1 + per // 4] = qcfg["vision_end_id"]
+            o += per // 4 + 2
+        self.ids = ids
+        self.pixel_values = torch.randn(B, self.N_IMG * per, 1176, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
+        self.grid = torch.tensor([list(self.GRID)] * self.N_IMG)
+        self.images_dp = torch.rand(B, 2, 224, 224, 3, device=dev, generator=g).to(torch.bfloat16)
+        self.latent_table = torch.randn(B, qcfg["n_query"], qcfg["t_hidden"], device=dev, generator=g).to(torch.bfloat16)
+        self.x_init = torch.randn(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev, generator=g)
+        self.desc = {"policy": "InternVLA-N1 dual system (Qwen2.5-VL-7B S2 + NextDiT-async S1), nominal cadence 1 S2 : 10 S1",
+                     "s2": f"{self.N_IMG} frames x 784 patches + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
+                     "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps", "s2_microbatches_per_10_steps": self.mb}
+        f2 = flops.s2_call_flops(self.S, [self.GRID] * self.N_IMG, self.N_DECODE, qcfg)
+        f1 = flops.nextdit_s1_flops_per_env(scfg)
+        self.f_alg = f1["total"] + f2["total"] / self.CADENCE
+        self.f_parts = {"s1_per_env": f1["total"], "s2_per_call": f2["total"]}
+        # static S2 buffers per micro-batch size
+        q = self.model.qwen
+        self.s2 = {}
+        for m in sorted(set(self.mb)):
+            P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True)
+            self.s2[m] = dict(P=P, pv=torch.empty(m * self.N_IMG * per, 1176, dtype=torch.bfloat16, device=dev),
+                              toks=torch.zeros(m, self.N_DECODE, dtype=torch.int32, device=dev),
+                              lat=torch.zeros(m, qcfg["n_query"], qcfg["t_hidden"], dtype=torch.bfloat16, device=dev), graph=None)
+        self.s1_graph = None
+        self.action_shape = (B, 4)
+        self.actions = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+
+    def _s2_call(self, m):
+        s = self.s2[m]
+        self.model.qwen.run_s2(s["P"], s["pv"], s["toks"], s["lat"])
+
+    def _s1_call(self):
+        return self.model.s1.generate_traj(self.latent_table, self.images_dp, self.x_init)
+
+    def capture(self):
+        from internnav_amd import runtime
+
+        for m, s in self.s2.items():
+            s["pv"].copy_(self.pixel_values[:m].reshape(-1, 1176))
+            s["graph"] = runtime.GraphedCall(lambda m=m: self._s2_call(m), {})
+        self.s1_graph = runtime.GraphedCall(lambda: self._s1_call(), {})
+
+    def step(self, i):
+        j = i % self.CADENCE
+        m, lo = self.mb[j], int(self.mb_start[j])
+        s = self.s2[m]
+        # System-2 for the envs whose plan expires this step: gather their prompt / frames, run, scatter the latents back
+        s["P"]["ids"].copy_(self.ids[lo:lo + m].reshape(-1).to(torch.int32))
+        s["pv"].copy_(self.pixel_values[lo:lo + m].reshape(-1, 1176))
+        s["graph"]() if s["graph"] else self._s2_call(m)
+        self.latent_table[lo:lo + m].copy_(s["lat"])
+        # System-1 for every env
+        self.x_init.normal_(generator=self.g)
+        traj = self.s1_graph() if self.s1_graph else self._s1_call()
+        t = traj.cpu()                                        # [B, 32, 32, 3] -> host post-processing of the reference (vln_utils)
+        acts = np.zeros((self.B, 4), dtype=np.int32)
+        for b in range(self.B):
+            al = [x for x in self.traj_to_actions(t[b]) if x != 0][:4]
+            acts[b, :len(al)] = al
+        self.actions.copy_(torch.from_numpy(acts))
+        return self.actions
+
+    def instrumented(self):
+        m = max(self.mb)
+        self._s2_call(m)
+        self._s1_call()
+        return m
+
+    def cpu_baseline(self):
+        """reference PyTorch path on the host cores = the CPU oracle, on a bounded sample of one env's policy step: the complete
+        System-1 call, and for System-2 two ViT blocks (1 window + 1 full) on 3136 patches and two decoder layers on S = 920 tokens at
+        the true widths, scaled linearly to the 32 / 28 layers of one call; combined at the 1 : 10 cadence."""
+        from internnav_amd import synthetic
+        from oracle import nextdit as o_nd  # cpu_baseline leg only
+        from oracle import qwen_vl as o_q
+
+        cores = min(64, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        with torch.no_grad():
+            sd = synthetic.n1_nextdit_state_dict(0)
+            inp = synthetic.n1_nextdit_inputs(1, 0)
+            t0 = time.time()
+            o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
+            t_s1 = time.time() - t0
+            cfg = dict(self.qcfg, v_depth=2, v_fullatt=(1,), t_layers=2, vocab=8)
+            spec = {k: v for k, v in synthetic.qwen_spec(cfg).items()}
+            sdq = synthetic.materialize(spec, 0)
+            pv = torch.randn(self.N_IMG * 784, 1176)
+            t0 = time.time()
+            o_q.vision_tower(pv, [self.GRID] * self.N_IMG, sdq, cfg)
+            t_vit = (time.time() - t0) * self.qcfg["v_depth"] / 2
+            x = torch.randn(1, self.S, self.qcfg["t_hidden"])
+            pos = torch.arange(self.S).view(1, 1, -1).expand(3, 1, -1)
+            t0 = time.time()
+            o_q.decoder_stack(x, pos, sdq, cfg)
+            t_llm = (time.time() - t0) * self.qcfg["t_layers"] / 2
+        t_s2 = t_vit + t_llm          # prefill only: decode + latent queries add < 2 % of the FLOPs
+        t_step = t_s1 + t_s2 / self.CADENCE
+        return {"value": round(1.0 / t_step, 4), "unit": "policy steps/s", "cores": cores, "kind": "port",
+                "seconds": {"s1_call": round(t_s1, 2), "s2_vit_scaled": round(t_vit, 2), "s2_prefill_scaled": round(t_llm, 2)},
+                "sample": "1 env: full System-1 call + (2 of 32 ViT blocks on 3136 patches and 2 of 28 decoder layers on S=920, scaled linearly) "
+                          "combined at 1 S2 : 10 S1; fp32 torch CPU, batch-1 as the reference executes"}
+
+
+# ------------------------------------------------------------------------------------------------------------ driver
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -73,56 +255,25 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    from internnav_amd import flops, runtime, synthetic
-    from internnav_amd.navdp import NavDPNet
+    from internnav_amd import runtime
 
     arch = runtime.require_gfx950()
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-    assert a.workload == "navdp_s1", "only the NavDP System-1 workload (BASELINE config #2) is benchmarked in this round"
-    cfg = synthetic.NAVDPNET_CFG
-    B = a.envs
-    sd = synthetic.navdpnet_state_dict(seed=0)
-    net = NavDPNet(sd, cfg, dev, max_envs=B)
-    del sd
-    # synthetic inputs generated on the device (seed = 1000*rank): frames in 0..1, depth in metres, point goals
-    g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
-    inp = dict(
-        goal=torch.randn(B, 3, device=dev, generator=g) * 3.0,
-        images=torch.rand(B, cfg["memory_size"], 224, 224, 3, device=dev, generator=g),
-        depths=torch.rand(B, 1, 224, 224, 1, device=dev, generator=g) * 5.0,
-        x_init=torch.randn(B, cfg["sample_num"], cfg["predict_size"], 3, device=dev, generator=g),
-        step_noise=torch.randn(cfg["num_train_timesteps"], B, cfg["sample_num"], cfg["predict_size"], 3, device=dev, generator=g),
-    )
+    wl = (N1Dual if a.workload == "n1_dual" else NavDPS1)(a, dev, rank)
+    if not a.no_graph:
+        wl.capture()
+    gathered = torch.empty((world * wl.action_shape[0],) + tuple(wl.action_shape[1:]), device=dev,
+                           dtype=torch.int32 if a.workload == "n1_dual" else torch.float32) if world > 1 else None
 
-    def call(goal, images, depths, x_init, step_noise):
-        return net.predict_pointgoal_batch_action_vel(goal, images, depths, x_init, step_noise)
-
-    if a.no_graph:
-        def run():
-            return call(**inp)
-    else:
-        graphed = runtime.GraphedCall(call, inp)
-
-        def run():
-            return graphed()
-
-    gathered = None
-    if world > 1:
-        gathered = torch.empty(world * B, 8, cfg["predict_size"], 3, device=dev)
-
-    def step():
-        # fresh sampler noise every policy step (drawn on the device into the static buffers the graph reads)
-        inp["x_init"].normal_(generator=g)
-        inp["step_noise"].normal_(generator=g)
-        neg, pos = run()
+    def step(i):
+        out = wl.step(i)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, pos)  # per-env action outputs to every rank (RCCL over xGMI)
-        return pos
+            dist.all_gather_into_tensor(gathered, out)  # per-env action outputs to every rank (RCCL over xGMI)
 
     def sync():
         torch.cuda.synchronize()
@@ -130,53 +281,52 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    for i in range(a.warmup):
+        step(i)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for i in range(a.steps):
+        step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    value = world * B * a.steps / dt
+    value = world * wl.B * a.steps / dt
 
     if rank == 0:
         # ---- roofline: one instrumented eager pass, HIP events around every launch on the launch stream
-        f_alg = flops.navdpnet_flops_per_env(cfg)
         runtime.prof_enable(True)
-        call(**inp)
+        extra = wl.instrumented()
         torch.cuda.synchronize()
         prof = runtime.prof_read()
         runtime.prof_enable(False)
         gm = prof["gemm"]
-        kernel_ms = {k: round(v["ms"], 3) for k, v in prof.items()}
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-        step_tflops = (value / world) * f_alg["total"] / 1e12
+        step_tflops = (value / world) * wl.f_alg / 1e12
         roofline = {
             "bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all tile configs)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": None,
-            "launches_per_step": gm["launches"], "avg_launch_us": round(gm["ms"] * 1e3 / max(gm["launches"], 1), 2),
-            "gemm_flops_per_step": gm["flops"], "kernel_class_ms_per_step": kernel_ms,
-            "whole_step": {"algorithmic_tflop_per_env_step": round(f_alg["total"] / 1e12, 4),
+            "instrumented_pass": {"what": "one System-1 call over all envs" + (f" + one System-2 call over {extra} envs" if extra else ""),
+                                  "gemm_launches": gm["launches"], "gemm_avg_launch_us": round(gm["ms"] * 1e3 / max(gm["launches"], 1), 2),
+                                  "gemm_tflop": round(gm["flops"] / 1e12, 3),
+                                  "kernel_class_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+                                  "kernel_class_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) for k, v in prof.items()}},
+            "whole_step": {"algorithmic_tflop_per_env_step": round(wl.f_alg / 1e12, 4),
                            "achieved_tflops_per_gpu": round(step_tflops, 1), "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
         }
         line = {
             "metric": "policy steps/sec/node", "value": round(value, 2), "unit": "policy steps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"navdp_s1_b{B}", "policy": "NavDPNet (BASELINE config #2: NavDP System-1 only)",
-                       "envs_per_gpu": B, "samples_per_env": cfg["sample_num"], "ddpm_steps": cfg["num_train_timesteps"],
-                       "frames_per_env": f"{cfg['memory_size']} rgb + 1 depth @224x224", "parallelism": f"dp{world}",
-                       "launch": "eager" if a.no_graph else "hipGraph replay", "device": arch},
+            "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}",
+                            "launch": "eager" if a.no_graph else "hipGraph replay", "device": arch}, **wl.desc),
             "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

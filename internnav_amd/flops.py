@@ -57,3 +57,56 @@ def n1_navdp_flops_per_env(cfg, n_query: int = 4) -> dict:
     denoise = K * denoiser_pass_flops(S, T, Lc, causal=True, d=D, depth=depth)
     total = vit + former + goal + cond_kv + denoise
     return dict(vit=vit, former=former, goal=goal, cond_kv=cond_kv, denoise=denoise, total=total)
+
+
+# ---------------------------------------------------------------------------------------------------- InternVLA-N1 dual system
+def qwen_vit_flops(grids, cfg) -> float:
+    """Qwen2.5-VL vision tower on a list of (t, h, w) patch grids: patch embed, window / per-image attention, SwiGLU, merger."""
+    D, I, O, hd = cfg["v_hidden"], cfg["v_inter"], cfg["v_out"], cfg["v_hidden"] // cfg["v_heads"]
+    from .qwen_vl import vision_window_permutation
+
+    total = 0.0
+    for g in grids:
+        n = g[0] * g[1] * g[2]
+        _, cu = vision_window_permutation([g], 2, cfg["v_window"], cfg["v_patch"])
+        win_keys = float(((cu[1:] - cu[:-1]).astype("float64") ** 2).sum())   # sum over windows of len^2
+        n_full = len(cfg["v_fullatt"])
+        lin = 2 * n * D * 3 * D + 2 * n * D * D + 3 * 2 * n * D * I
+        attn = 4 * D * (n_full * float(n) * n + (cfg["v_depth"] - n_full) * win_keys)
+        total += 2 * n * 1176 * D + cfg["v_depth"] * lin + attn + 2 * (n // 4) * (4 * D) * (4 * D) + 2 * (n // 4) * (4 * D) * O
+    return total
+
+
+def llm_flops(new_tokens: int, ctx_start: int, cfg, lm_head_rows: int = 0) -> float:
+    """decoder stack over `new_tokens` tokens per sequence appended at context length ctx_start (causal), + lm_head rows."""
+    H, TI, nh, nkv = cfg["t_hidden"], cfg["t_inter"], cfg["t_heads"], cfg["t_kv_heads"]
+    hd = H // nh
+    lin = 2 * new_tokens * (H * (nh + 2 * nkv) * hd + H * H + 3 * H * TI)
+    keys = sum(ctx_start + i + 1 for i in range(new_tokens))
+    attn = 4 * keys * H
+    return cfg["t_layers"] * (lin + attn) + 2 * lm_head_rows * H * cfg["vocab"]
+
+
+def s2_call_flops(S: int, grids, n_decode: int, cfg) -> dict:
+    """one System-2 call per env (pixel-goal answer): ViT + prefill + n_decode greedy tokens + N_QUERY latent queries on the cache
+    (16.46 TFLOP for 4 frames, S = 920, n_dec = 8)."""
+    vit = qwen_vit_flops(grids, cfg)
+    prefill = llm_flops(S, 0, cfg, lm_head_rows=1)
+    decode = sum(llm_flops(1, S + j, cfg, lm_head_rows=1) for j in range(max(n_decode - 1, 0)))
+    lat = llm_flops(1 + cfg["n_query"], S + max(n_decode - 1, 0), cfg)
+    return dict(vit=vit, prefill=prefill, decode=decode, latents=lat, total=vit + prefill + decode + lat)
+
+
+def nextdit_s1_flops_per_env(cfg) -> dict:
+    """generate_traj, nextdit_async (DualVLN): 2 ViT-S frames, MemoryEncoder, QFormer, cond K/V once, 10 x 12-layer DiT on 32 x 32 tokens."""
+    D, L, S, T, nl, ffn = cfg["dit_dim"], cfg["latent_dim"], cfg["sample_num"], cfg["predict_size"], cfg["dit_layers"], cfg["dit_ffn"]
+    nm, Lz, nq = cfg["memory_frames"] * 256, 32 + cfg["n_query"], cfg["n_query"]
+    vit = cfg["memory_frames"] * vit_s_flops()
+    mem = 3 * (2 * nm * D * 3 * D + 4 * nm * nm * D + 2 * nm * D * D + 2 * 2 * nm * D * 2048)
+    qf = 3 * (2 * 32 * L * 3 * L + 4 * 32 * 32 * L + 2 * 32 * L * L + 2 * 32 * L * L + 2 * nm * L * 2 * L + 4 * 32 * nm * L + 2 * 32 * L * L + 2 * 2 * 32 * L * 2048)
+    cond = 2 * nq * (cfg["vlm_token_dim"] * L + L * L) + 2 * Lz * (L * D + D * D) + nl * 2 * Lz * D * 2 * D
+    rows = S * T
+    per_layer = 2 * rows * D * 4 * D + 4 * rows * T * D + 4 * rows * Lz * D + 2 * rows * D * D + 3 * 2 * rows * D * ffn
+    dit = cfg["num_inference_steps"] * (nl * per_layer + 2 * 2 * rows * 3 * D)
+    total = vit + mem + qf + cond + dit
+    return dict(vit=vit, memory_encoder=mem, qformer=qf, cond=cond, dit=dit, total=total)

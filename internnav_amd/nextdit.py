@@ -103,8 +103,8 @@ class NextDiTSystem1:
         half = 128
         freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=f32) / half)
         tfreq = torch.cat([torch.cos(ts[:, None] * freqs[None]), torch.sin(ts[:, None] * freqs[None])], dim=-1)  # [n, 256]
-        te1w, te1b = sd[p + "time_caption_embed.timestep_embedder.linear_1.weight"].float(), sd[p + "time_caption_embed.timestep_embedder.linear_1.bias"].float()
-        te2w, te2b = sd[p + "time_caption_embed.timestep_embedder.linear_2.weight"].float(), sd[p + "time_caption_embed.timestep_embedder.linear_2.bias"].float()
+        te1w, te1b = sd[p + "time_caption_embed.timestep_embedder.linear_1.weight"].float().cpu(), sd[p + "time_caption_embed.timestep_embedder.linear_1.bias"].float().cpu()
+        te2w, te2b = sd[p + "time_caption_embed.timestep_embedder.linear_2.weight"].float().cpu(), sd[p + "time_caption_embed.timestep_embedder.linear_2.bias"].float().cpu()
         h = tfreq @ te1w.t() + te1b
         self.time_emb = ((h * torch.sigmoid(h)) @ te2w.t() + te2b).to(dev).contiguous()  # [n, 384] input independent (host, fp32)
         mods_w, mods_b = [], []

@@ -137,12 +137,14 @@ class InternVLAN1ForCausalLM:
     """HF-style model object backed by the HIP engines (no nn.Module, no CPU fallback)."""
 
     def __init__(self, weights, qwen_cfg: dict, system1: str = "nextdit_async", s1_cfg: Optional[dict] = None,
-                 device="cuda:0", max_envs: int = 16, max_seq_len: int = 2048, max_patches: Optional[int] = None):
+                 device="cuda:0", max_envs: int = 16, max_seq_len: int = 2048, max_patches: Optional[int] = None,
+                 max_s2_seqs: Optional[int] = None):
         self.device = torch.device(device)
         self.config = SimpleNamespace(system1=system1, n_query=qwen_cfg["n_query"], hidden_size=qwen_cfg["t_hidden"],
                                       image_token_id=qwen_cfg["image_token_id"])
-        self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=max_envs, max_seq_len=max_seq_len,
-                                 max_patches=max_patches or max_envs * 10 * 784)
+        n_s2 = max_s2_seqs or max_envs   # System-2 runs on micro-batches of the envs whose plan expired (agent / bench schedule)
+        self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=n_s2, max_seq_len=max_seq_len,
+                                 max_patches=max_patches or n_s2 * 10 * 784)
         if "nextdit" in system1:
             self.s1 = NextDiTSystem1(_Prefixed(weights, "model."), s1_cfg or synthetic.N1_NEXTDIT_CFG, device, max_envs)
         elif "navdp" in system1:
