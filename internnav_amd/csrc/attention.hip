@@ -182,8 +182,181 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ decode (few query tokens, long KV)
+// Token-by-token decoding has Lq = 1 (or 1 + N_QUERY for the latent queries): one (sequence, head) pair is a single 16-row MFMA tile
+// with one live row, and 196 one-wave workgroups cannot stream the KV cache at HBM rate. Two changes:
+//   * GQA packing: the G = H / Hkv query heads that share one KV head (and their Lq positions) become the ROWS of the tile
+//     (row R -> head kh*G + R / Lq, position R % Lq), so the K/V of a KV head are read once instead of G times;
+//   * split-KV: grid.x slices the keys in chunks of DEC_CHUNK; each one-wave workgroup writes an un-normalised partial
+//     (O, running max m, running sum l) to a workspace, a second kernel merges the slices (flash-decoding).
+constexpr int DEC_CHUNK = 64;
+
+template <int DP, int DV>
+__global__ __launch_bounds__(64) void attn_decode_split_kernel(AttnArgs p, float* __restrict__ ws, int nsplit, int rtiles) {
+    constexpr int KVB = 64, KS_LD = DP + 8, VT_LD = KVB + 8, KCPR = DP / 8, VCPR = DV / 8, NKK = DP / 32, NST = KVB / 16, NSB = KVB / 32, NDT = DV / 16;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[KVB * KS_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Vt[DV * VT_LD];
+    const int lane = threadIdx.x, g = lane >> 4, lq = lane & 15;
+    const int split = blockIdx.x, kh = blockIdx.y / rtiles, rt = blockIdx.y % rtiles, b = blockIdx.z;
+    const int G = p.H / p.Hkv;
+    const int R = rt * 16 + lq;                    // packed row of this lane
+    const bool live = R < G * p.Lq;
+    const int head = kh * G + (live ? R / p.Lq : 0), qpos = live ? R % p.Lq : 0;
+    int len_k = p.Lk;
+    if (p.k_len) len_k = min(p.k_len[b], p.Lk);
+    const int kv0 = split * DEC_CHUNK;
+    float* out = ws + ((((size_t)b * p.Hkv + kh) * rtiles + rt) * nsplit + split) * (size_t)(16 * (DV + 2));
+    const bf16* __restrict__ Q = reinterpret_cast<const bf16*>(p.Q) + (size_t)b * p.q_bs + (size_t)qpos * p.q_rs + (size_t)head * p.q_hs;
+    const bf16* __restrict__ K = reinterpret_cast<const bf16*>(p.K) + (size_t)b * p.k_bs + (size_t)kh * p.k_hs;
+    const bf16* __restrict__ V = reinterpret_cast<const bf16*>(p.V) + (size_t)b * p.v_bs + (size_t)kh * p.v_hs;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc_o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) acc_o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (kv0 < len_k) {
+        bf16x8 qf[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            int d = kk * 32 + g * 8;
+            qf[kk] = (live && d < p.D) ? *reinterpret_cast<const bf16x8*>(Q + d) : zero8;
+        }
+        for (int q = lane; q < KVB * KCPR; q += 64) {
+            int row = q / KCPR, c = q % KCPR, kv = kv0 + row;
+            bf16x8 v = (kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
+            *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = v;
+        }
+        for (int q = lane; q < KVB * VCPR; q += 64) {
+            int row = q / VCPR, c = q % VCPR, kv = kv0 + row;
+            bf16x8 v = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
+            int pos = vt_pos(row);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + pos] = v[i];
+        }
+        __syncthreads();
+        f32x4 s[NST];
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(t * 16 + lq) * KS_LD + kk * 32 + g * 8]);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        const float sc = p.scale * 1.4426950408889634f;
+        const int causal_shift = len_k - p.Lq;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int kv = kv0 + t * 16 + g * 4 + r;
+                bool ok = live && (kv < len_k) && (!p.causal || kv <= qpos + causal_shift);
+                float v = ok ? s[t][r] * sc : -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        m_run = mx;
+        const float m_use = (mx == -INFINITY) ? 0.f : mx;
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = exp2f(s[t][r] - m_use);
+                s[t][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = rs;
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (bf16)s[2 * sb][r];
+                pf[4 + r] = (bf16)s[2 * sb + 1][r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NDT; ++nt) {
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + sb * 32 + g * 8]);
+                acc_o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc_o[nt], 0, 0, 0);
+            }
+        }
+    }
+    // partial: row lq -> [DV] un-normalised O (exp2 domain), then m, l
+    float* orow = out + (size_t)lq * (DV + 2);
+#pragma unroll
+    for (int nt = 0; nt < NDT; ++nt) *reinterpret_cast<f32x4*>(orow + nt * 16 + g * 4) = acc_o[nt];
+    if (g == 0) { orow[DV] = m_run; orow[DV + 1] = l_run; }
+}
+
+template <int DV>
+__global__ __launch_bounds__(64) void attn_decode_combine_kernel(AttnArgs p, const float* __restrict__ ws, int nsplit, int rtiles) {
+    // one wave per packed row: lanes cover the DV columns (DV <= 128 -> 2 per lane)
+    const int lane = threadIdx.x;
+    const int R = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
+    const int G = p.H / p.Hkv;
+    const int rt = R / 16, lq = R % 16;
+    const int head = kh * G + R / p.Lq, qpos = R % p.Lq;
+    const float* base = ws + (((size_t)b * p.Hkv + kh) * rtiles + rt) * nsplit * (size_t)(16 * (DV + 2)) + (size_t)lq * (DV + 2);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, base[(size_t)s * 16 * (DV + 2) + DV]);
+    const float m_use = (m == -INFINITY) ? 0.f : m;
+    float l = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float* q = base + (size_t)s * 16 * (DV + 2);
+        const float ms = q[DV];
+        if (ms == -INFINITY) continue;
+        const float w = exp2f(ms - m_use);
+        l += q[DV + 1] * w;
+        if (lane < DV) o0 += q[lane] * w;
+        if (lane + 64 < DV) o1 += q[lane + 64] * w;
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    bf16* O = reinterpret_cast<bf16*>(p.O) + (size_t)b * p.o_bs + (size_t)qpos * p.o_rs + (size_t)head * p.o_hs;
+    if (lane < p.D) O[lane] = (bf16)(o0 * inv);
+    if (lane + 64 < p.D) O[lane + 64] = (bf16)(o1 * inv);
+}
+
+float* g_dec_ws = nullptr;
+size_t g_dec_ws_bytes = 0;
+
+template <int DP, int DV>
+int launch_decode(const AttnArgs& p, hipStream_t stream) {
+    const int G = p.H / p.Hkv;
+    const int rtiles = (G * p.Lq + 15) / 16;
+    const int nsplit = (p.Lk + DEC_CHUNK - 1) / DEC_CHUNK;
+    const size_t bytes = (size_t)p.B * p.Hkv * rtiles * nsplit * 16 * (DV + 2) * sizeof(float);
+    if (bytes > g_dec_ws_bytes) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &st);
+        INA_REQUIRE(st == hipStreamCaptureStatusNone, "attention(decode): workspace of %zu bytes needed during graph capture: run the shape once eagerly first", bytes);
+        INA_HIP_CHECK(hipDeviceSynchronize());
+        if (g_dec_ws) INA_HIP_CHECK(hipFree(g_dec_ws));
+        const size_t want = bytes < (size_t)(32u << 20) ? (size_t)(32u << 20) : bytes * 2;
+        INA_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_dec_ws), want));
+        g_dec_ws_bytes = want;
+    }
+    const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)p.Lk;
+    InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
+                      2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)p.B * p.Hkv * p.Lk), stream);
+    hipLaunchKernelGGL((attn_decode_split_kernel<DP, DV>), dim3(nsplit, p.Hkv * rtiles, p.B), dim3(64), 0, stream, p, g_dec_ws, nsplit, rtiles);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<DV>), dim3(G * p.Lq, p.Hkv, p.B), dim3(64), 0, stream, p, g_dec_ws, nsplit, rtiles);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <int DP, int DV>
 int launch_d(const AttnArgs& p, hipStream_t stream) {
+    // decode shape: few query tokens against a long dense KV (GQA-packed split-KV path)
+    if (!p.cu_q && !p.cu_k && p.kv_bdiv == 1 && p.kv_start == 0 && !p.accumulate && !p.head_gate && p.Lk >= 256 &&
+        (p.H / p.Hkv) * p.Lq <= 48 && p.Lq <= 8 && DV <= 128)
+        return launch_decode<DP, DV>(p, stream);
     // short query sequences: fewer waves per workgroup; short key sequences: 32-key blocks
     const bool small_k = p.Lk <= 48;
     int nw = (p.Lq <= 16) ? 1 : (p.Lq <= 32 ? 2 : 4);

@@ -235,6 +235,8 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
     INA_REQUIRE(!p.R || p.ldr % 4 == 0, "gemm: ldr must be a multiple of 4");
     INA_REQUIRE(!p.glu || (p.N % 32 == 0), "gemm: GLU mode needs N %% 32 == 0");
     // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
+    // skinny M: HBM-bound weight streaming with split-K (gemm_skinny.hip) instead of an under-filled tile grid
+    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) return ina_launch_gemm_skinny(p, stream);
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     int cfg = p.force_cfg;
     if (cfg <= 0) {

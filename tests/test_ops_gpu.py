@@ -365,3 +365,54 @@ def test_bad_arguments_fail_loudly(ops):
     q = torch.zeros(1, 4, 2, 40, dtype=torch.bfloat16, device=_dev())
     with pytest.raises(RuntimeError, match="unsupported head dim"):
         ops.attention(q, q, q)
+
+
+SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", SKINNY)
+def test_gemm_skinny_split_k(ops, M, N, K):
+    """M <= 64 goes through the weight-streaming split-K kernel (+ epilogue kernel): all epilogue terms, bf16 and f32 outputs."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    bias, cs = torch.randn(N, generator=g).to(_dev()), torch.randn(N, generator=g).to(_dev())
+    res = torch.randn(M, N, generator=g).to(_dev())
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + bias) * cs + res
+    out = ops.linear(x, w, bias=bias, act="gelu", colscale=cs, residual=res, out_dtype=torch.float32)
+    _close(out, ref, rtol=2e-3, atol=5e-3)
+    out_b = ops.linear(x, w, bias=bias)
+    _close(out_b, x.float() @ w.float().t() + bias)
+    same = ops.linear(x, w, bias=bias, force_cfg=3 if N >= 128 else 4)  # tiled kernel on the same problem
+    _close(same, out_b.float(), rtol=1.0 / 64, atol=3e-2)
+
+
+def test_gemm_skinny_glu(ops):
+    g = torch.Generator().manual_seed(66)
+    M, K, I = 7, 3584, 2048
+    x = _rand((M, K), g)
+    wg, wu = _rand((I, K), g, scale=K ** -0.5), _rand((I, K), g, scale=K ** -0.5)
+    w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+    out = ops.linear(x, w, act="silu", glu=True)
+    ref = torch.nn.functional.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t())
+    _close(out, ref)
+
+
+DECODE = [
+    # B, Lq, Lk, H, Hkv, D, causal
+    (7, 1, 927, 28, 4, 128, True), (7, 5, 932, 28, 4, 128, True), (3, 1, 300, 28, 4, 128, False), (2, 2, 513, 8, 8, 64, True),
+    (4, 1, 1024, 16, 16, 80, True), (1, 6, 256, 28, 4, 128, True),
+]
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,Hkv,D,causal", DECODE)
+def test_attention_decode_gqa_split_kv(ops, B, Lq, Lk, H, Hkv, D, causal):
+    g = torch.Generator().manual_seed(B * 100 + Lq + Lk)
+    q, k, v = _rand((B, Lq, H, D), g), _rand((B, Lk, Hkv, D), g), _rand((B, Lk, Hkv, D), g)
+    out = ops.attention(q, k, v, causal=causal)
+    _close(out, _ref_attn(q, k, v, D ** -0.5, causal), atol=1.5e-2)
+    # per-sequence key lengths (ragged answers): keys beyond k_len[b] are ignored, causal offset follows k_len
+    lens = torch.tensor([Lk - 3 * (i % 4) for i in range(B)], dtype=torch.int32)
+    out2 = ops.attention(q, k, v, causal=causal, k_len=lens.to(_dev()))
+    for b in range(B):
+        n = int(lens[b])
+        _close(out2[b:b + 1], _ref_attn(q[b:b + 1], k[b:b + 1, :n], v[b:b + 1, :n], D ** -0.5, causal), atol=1.5e-2)
