@@ -16,6 +16,7 @@
 // act(gate)*up to N/2 columns (Qwen SwiGLU, LuminaFeedForward).
 #include "common.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -128,77 +129,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds rows m = ..+ (lane&15), columns n = ..+ (lane>>4)*4 + {0..3}
-    const int out_bf16 = (p.out_dtype == INA_DT_BF16);
-    const float* __restrict__ bias = p.bias;
-    const float* __restrict__ colscale = p.colscale;
-    const float* __restrict__ rowscale = p.rowscale;
-    const size_t cbatch = (size_t)blockIdx.y * p.strideC;
-#pragma unroll
-    for (int i = 0; i < C::FM; ++i) {
-        const int m = m0 + wm * C::TM + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const float rs = rowscale ? rowscale[m / p.rowscale_div] : 1.0f;
-        if (!p.glu) {
-#pragma unroll
-            for (int j = 0; j < C::FN; ++j) {
-                const int n = n0 + wn * C::TN + j * 16 + (lane >> 4) * 4;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r];
-                    if (bias) x += bias[n + r];
-                    x = ina_act(x, p.act);
-                    if (colscale) x *= colscale[n + r];
-                    v[r] = x * rs;
-                }
-                if (p.R) {
-                    const size_t ro = (size_t)blockIdx.y * p.strideR + (size_t)m * p.ldr + n;
-                    if (p.res_dtype == INA_DT_BF16) {
-                        bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.R) + ro);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                    } else {
-                        f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                    }
-                }
-                const size_t co = cbatch + (size_t)m * p.ldc + n;
-                if (out_bf16) {
-                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = o;
-                } else {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = o;
-                }
-            }
-        } else {
-            // GLU: W rows are interleaved in 16-row blocks [gate16 | up16]; output column block = pair index
-#pragma unroll
-            for (int j = 0; j < C::FN; j += 2) {
-                const int n = n0 + wn * C::TN + j * 16 + (lane >> 4) * 4;  // gate column in interleaved space
-                if (n >= p.N) continue;
-                const int no = ((n0 + wn * C::TN + j * 16) >> 1) + (lane >> 4) * 4;  // output column
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float g = acc[i][j][r], u = acc[i][j + 1][r];
-                    if (bias) { g += bias[n + r]; u += bias[n + 16 + r]; }
-                    v[r] = ina_act(g, p.act) * u * rs;
-                }
-                const size_t co = cbatch + (size_t)m * p.ldc + no;
-                if (out_bf16) {
-                    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = o;
-                } else {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = o;
-                }
-            }
-        }
-    }
+    gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
@@ -245,12 +176,17 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         else if (p.N <= 64) cfg = 5;
         else cfg = 2;
     }
+    if (p.force_cfg <= 0 && cfg == 1 && p.K % 64 == 0) cfg = 11;   // large problem, K multiple of 64: LDS-DMA staged kernel
     switch (cfg) {
         case 1: return launch_cfg<128, 128, 64, 2, 2>(p, stream);
         case 2: return launch_cfg<64, 128, 64, 2, 2>(p, stream);   // wave tile 32x64
         case 3: return launch_cfg<64, 128, 64, 1, 4>(p, stream);   // wave tile 64x32 (skinny M)
         case 4: return launch_cfg<64, 64, 64, 2, 2>(p, stream);    // wave tile 32x32
         case 5: return launch_cfg<128, 64, 64, 2, 2>(p, stream);   // wave tile 64x32 (narrow N)
+        case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
+        case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
+        case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
+        case 11: case 12: case 13: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

@@ -1,0 +1,133 @@
+// Large-K bf16 MFMA GEMM for gfx950 with direct-to-LDS staging:  C[M,N] = epilogue( A[M,K] . W[N,K]^T ),  K % 64 == 0.
+//
+// Same tile / wave / MFMA geometry and the same fused epilogue as gemm.hip, but the global->LDS path is the CDNA4 LDS-DMA
+// (`global_load_lds_dwordx4`: 16 B per lane, 1 KiB per wave-instruction, no VGPR round trip, no ds_write pass):
+//   * each stage holds A[BM][64] and W[BN][64] bf16 as plain 128-byte rows; a wave-instruction fills 8 consecutive rows;
+//   * the DMA writes lane-linearly, so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane that lands on
+//     physical 16-byte chunk cp of row r fetches logical chunk cp ^ (r & 7) (all 8 lanes of a row still cover one 128-byte line),
+//     and the MFMA fragment reads apply the same involution (ds_read_b128 of chunk c ^ (r & 7));
+//   * 2 stages, one barrier per K tile: tile t+1's DMA is issued right after the barrier that publishes tile t and stays in
+//     flight under the 32 MFMAs per wave of tile t (`s_waitcnt vmcnt(0)` only just before the next barrier).
+// Rows beyond M / N are clamped to the last valid row (their accumulators are never stored) - the DMA has no predication.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace {
+
+template <int BM, int BN, int WM, int WN>
+struct GldsCfg {
+    static constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
+    static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;   // 1 KiB wave-instructions per wave per stage
+    static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * BK * sizeof(bf16);
+};
+
+__device__ __forceinline__ void glds16(const bf16* src, bf16* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p) {
+    using C = GldsCfg<BM, BN, WM, WN>;
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    bf16* As = reinterpret_cast<bf16*>(smem_raw);          // [2][BM][64]
+    bf16* Bs = As + 2 * BM * 64;                           // [2][BN][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (size_t)blockIdx.y * p.strideA;
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (size_t)blockIdx.y * p.strideW;
+
+    // per-lane source pointers of this lane's DMA slots (k0 = 0); slot s of a wave covers tile rows (wave*INST + s)*8 .. +7
+    const bf16* asrc[C::A_INST];
+    const bf16* bsrc[C::B_INST];
+    const int drow = lane >> 3, dcp = lane & 7;
+#pragma unroll
+    for (int s = 0; s < C::A_INST; ++s) {
+        const int row = (wave * C::A_INST + s) * 8 + drow;
+        const int gm = min(m0 + row, p.M - 1);
+        asrc[s] = A + (size_t)gm * p.lda + ((dcp ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int s = 0; s < C::B_INST; ++s) {
+        const int row = (wave * C::B_INST + s) * 8 + drow;
+        const int gn = min(n0 + row, p.N - 1);
+        bsrc[s] = W + (size_t)gn * p.ldw + ((dcp ^ (row & 7)) << 3);
+    }
+    auto stage = [&](int buf, int k0) {
+        bf16* as = As + buf * BM * 64 + wave * C::A_INST * 512;
+        bf16* bs = Bs + buf * BN * 64 + wave * C::B_INST * 512;
+#pragma unroll
+        for (int s = 0; s < C::A_INST; ++s) glds16(asrc[s] + k0, as + s * 512);
+#pragma unroll
+        for (int s = 0; s < C::B_INST; ++s) glds16(bsrc[s] + k0, bs + s * 512);
+    };
+
+    f32x4 acc[C::FM][C::FN];
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+    stage(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of tile t has landed
+        __syncthreads();                                     // ... everyone's has, and everyone is done reading buf ^ 1
+        if (t + 1 < nk) stage(buf ^ 1, (t + 1) * 64);
+        const bf16* as = As + buf * BM * 64 + (wm * C::TM + frow) * 64;
+        const bf16* bs = Bs + buf * BN * 64 + (wn * C::TN + frow) * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = ((kk * 4 + g) ^ sw) << 3;
+            bf16x8 fa[C::FM], fb[C::FN];
+#pragma unroll
+            for (int i = 0; i < C::FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(as + i * 16 * 64 + chunk);
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 16 * 64 + chunk);
+#pragma unroll
+            for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_glds(const GemmArgs& p, hipStream_t stream) {
+    using C = GldsCfg<BM, BN, WM, WN>;
+    static bool attr_done = false;
+    auto kern = gemm_bf16_glds_kernel<BM, BN, WM, WN>;
+    if (!attr_done) {
+        INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
+    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
+                      (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, p);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// cfg 11: 128x128 / 4 waves, cfg 12: 256x128 / 8 waves, cfg 13: 128x256 / 8 waves
+int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
+    INA_REQUIRE(p.K % 64 == 0, "gemm(glds): K=%d must be a multiple of 64", p.K);
+    switch (cfg) {
+        case 11: return launch_glds<128, 128, 2, 2>(p, stream);
+        case 12: return launch_glds<256, 128, 4, 2>(p, stream);
+        case 13: return launch_glds<128, 256, 2, 4>(p, stream);
+        default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
+    }
+}

@@ -23,6 +23,7 @@ using MropeTableArgs = ina_mrope_table_args;
 using ArgmaxArgs = ina_argmax_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
+int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
 int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming split-K path
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
 int ina_launch_norm(const NormArgs& p, hipStream_t stream);

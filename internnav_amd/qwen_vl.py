@@ -21,7 +21,7 @@ Work the reference wastes and this engine removes without changing results (SURV
 HBM layout (B sequences of S tokens, cache capacity S_max, H = 3584):
   x f32 [B*S, H] residual stream | h, att bf16 [B*S, H] | qkv bf16 [B*S, 4608] = q(28x128) | k(4x128) | v(4x128)
   ff bf16 [B*S, 18944] | kv[l] bf16 [B*S_max, 1024] = k | v per cached token | cos/sin f32 [B*S, 128] m-rope tables
-  vision: xv f32 [Np, 1280] | hv/attv bf16 [Np, 1280] | qkvv bf16 [Np, 3840] | ffv bf16 [Np, 3424] (3420 padded) | emb bf16 [Np/4, H]
+  vision: xv f32 [Np, 1280] | hv/attv bf16 [Np, 1280] | qkvv bf16 [Np, 3840] | ffv bf16 [Np, 3456] (3420 zero-padded) | emb bf16 [Np/4, H]
 """
 from __future__ import annotations
 
@@ -120,7 +120,7 @@ class QwenVLEngine:
         self.cfg, self.device = cfg, dev
         self.B_max, self.S_max, self.Np_max = max_seqs, max_seq_len, max_patches
         D, I = cfg["v_hidden"], cfg["v_inter"]
-        Ip = (I + 15) // 16 * 16
+        Ip = (I + 63) // 64 * 64   # SwiGLU width padded with zero rows/cols: GLU tiles need N % 32 == 0, the LDS-DMA GEMM K % 64 == 0
         self.vD, self.vI, self.vH, self.vhd = D, Ip, cfg["v_heads"], D // cfg["v_heads"]
         H, TI = cfg["t_hidden"], cfg["t_inter"]
         self.H, self.TI, self.nh, self.nkv = H, TI, cfg["t_heads"], cfg["t_kv_heads"]

@@ -367,6 +367,19 @@ def test_bad_arguments_fail_loudly(ops):
         ops.attention(q, q, q)
 
 
+@pytest.mark.parametrize("cfg", [11, 12, 13])
+@pytest.mark.parametrize("M,N,K", [(300, 260, 320), (1000, 1280, 3456), (257, 4608, 3584), (130, 132, 64)])
+def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
+    """LDS-DMA staged kernels: ragged M/N edges (clamped rows), swizzled LDS, every epilogue term."""
+    g = torch.Generator().manual_seed(cfg + M)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    bias = torch.randn(N, generator=g).to(_dev())
+    res = torch.randn(M, N, generator=g).to(_dev())
+    out = ops.linear(x, w, bias=bias, act="gelu_tanh", residual=res, out_dtype=torch.float32, force_cfg=cfg)
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + bias, approximate="tanh") + res
+    _close(out, ref, rtol=2e-3, atol=5e-3)
+
+
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]
 
 
