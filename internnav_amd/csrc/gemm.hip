@@ -129,7 +129,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_nt_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
+    // LDS-transposed epilogue (gemm_epilogue.h) when the wave tile is 64 columns wide and C / R rows are 16-byte aligned
+    bool staged = false;
+    if constexpr (C::TN == 64 && C::LDS_BYTES >= size_t(WM * WN) * C::FM * 4096) {
+        const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
+        staged = ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
+                 (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0));
+        if (staged) {
+            // (the K loop ends with a barrier: every wave is done with the stage buffers, which become the transpose scratch)
+            gemm_store_tile_staged<C::FM, C::FN, C::TM, C::TN, true>(p, acc, m0, n0, wm, wn, lane,
+                                                                     reinterpret_cast<float*>(smem_raw) + wave * C::FM * 1024);
+        }
+    }
+    if (!staged) gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>

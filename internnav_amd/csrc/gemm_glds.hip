@@ -28,7 +28,7 @@ __device__ __forceinline__ void glds16(const bf16* src, bf16* lds_wave_base) {
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool STAGED>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p) {
     using C = GldsCfg<BM, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
@@ -50,14 +50,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
 #pragma unroll
     for (int s = 0; s < C::A_INST; ++s) {
         const int row = (wave * C::A_INST + s) * 8 + drow;
-        const int gm = min(m0 + row, p.M - 1);
-        asrc[s] = A + (size_t)gm * p.lda + ((dcp ^ (row & 7)) << 3);
+        asrc[s] = A + (size_t)min(m0 + row, p.M - 1) * p.lda + ((dcp ^ (row & 7)) << 3);
     }
 #pragma unroll
     for (int s = 0; s < C::B_INST; ++s) {
         const int row = (wave * C::B_INST + s) * 8 + drow;
-        const int gn = min(n0 + row, p.N - 1);
-        bsrc[s] = W + (size_t)gn * p.ldw + ((dcp ^ (row & 7)) << 3);
+        bsrc[s] = W + (size_t)min(n0 + row, p.N - 1) * p.ldw + ((dcp ^ (row & 7)) << 3);
     }
     auto stage = [&](int buf, int k0) {
         bf16* as = As + buf * BM * 64 + wave * C::A_INST * 512;
@@ -79,7 +77,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     stage(0, 0);
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of tile t has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of K tile t has landed
         __syncthreads();                                     // ... everyone's has, and everyone is done reading buf ^ 1
         if (t + 1 < nk) stage(buf ^ 1, (t + 1) * 64);
         const bf16* as = As + buf * BM * 64 + (wm * C::TM + frow) * 64;
@@ -98,17 +96,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
                 for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
-    gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
+    if constexpr (STAGED) {
+        __syncthreads();   // every wave is done with the stage buffers: the whole LDS becomes the per-wave transpose scratch
+        // all FM slabs of a wave at once when LDS is big enough (one copy of the epilogue math in the instruction stream)
+        constexpr bool ALL = C::LDS_BYTES >= size_t(C::NW) * C::FM * 4096;
+        float* scratch = reinterpret_cast<float*>(smem_raw) + wave * (ALL ? C::FM * 1024 : 1024);
+        gemm_store_tile_staged<C::FM, C::FN, C::TM, C::TN, ALL>(p, acc, m0, n0, wm, wn, lane, scratch);
+    } else {
+        gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
 int launch_glds(const GemmArgs& p, hipStream_t stream) {
     using C = GldsCfg<BM, BN, WM, WN>;
-    static bool attr_done = false;
-    auto kern = gemm_bf16_glds_kernel<BM, BN, WM, WN>;
-    if (!attr_done) {
+    // the LDS-transposed epilogue needs 16-byte aligned output (and residual) rows and 64-column wave tiles
+    const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
+    const bool staged = C::TN == 64 && ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
+                        (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) &&
+                        ((p.glu ? p.N / 2 : p.N) % 4 == 0);
+    static bool attr_done[2] = {false, false};
+    auto kern = staged ? gemm_bf16_glds_kernel<BM, BN, WM, WN, true> : gemm_bf16_glds_kernel<BM, BN, WM, WN, false>;
+    if (!attr_done[staged]) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
-        attr_done = true;
+        attr_done[staged] = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;

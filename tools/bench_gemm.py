@@ -22,6 +22,8 @@ def timeit(fn, iters=10, warmup=2):
 
 
 dev = torch.device("cuda:0")
+import os
+ACT = int(os.environ.get('GEMM_ACT', '0'))
 shapes = [
     (6440, 4608, 3584, "bf16"), (6440, 3584, 3584, "f32r"), (6440, 37888, 3584, "glu"), (6440, 3584, 18944, "f32r"),
     (21952, 3840, 1280, "bf16"), (21952, 1280, 1280, "f32r"), (21952, 6848, 1280, "glu"), (21952, 1280, 3424, "f32r"),
@@ -36,7 +38,7 @@ for (M, N, K, mode) in shapes:
     for cfg in cfgs:
         if mode == "bf16":
             out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-            fn = lambda: ops.linear(x, w, out=out, force_cfg=cfg)
+            fn = lambda: ops.linear(x, w, out=out, force_cfg=cfg, act=ACT)
         elif mode == "glu":
             out = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
             fn = lambda: ops.linear(x, w, out=out, act="silu", glu=True, force_cfg=cfg)

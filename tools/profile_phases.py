@@ -1,0 +1,21 @@
+"""Run N eager S2 micro-batch calls or N eager S1 calls of the n1_dual workload (for rocprofv3 --kernel-trace). Usage: profile_phases.py s2|s1 [n]"""
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import bench  # noqa: E402
+
+which, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3
+wl = bench.N1Dual(SimpleNamespace(envs=64), torch.device("cuda:0"), 0)
+m = max(wl.mb)
+wl.s2[m]["pv"].copy_(wl.pixel_values[:m].reshape(-1, 1176))
+for _ in range(n):
+    if which == "s2":
+        wl._s2_call(m)
+    else:
+        wl._s1_call()
+torch.cuda.synchronize()
+print("done", which, n)
