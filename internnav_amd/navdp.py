@@ -129,7 +129,10 @@ def decoder_layer_prenorm(L: _DecoderLayer, ws: _SeqWorkspace, nseq: int, T: int
     ops.norm(x, L.n[1][0], L.n[1][1], eps=eps, out=h)
     qc = qkv[:, :d]
     ops.linear(h, L.ca_qw, bias=L.ca_qb, out=qc)
-    ops.attention(qc.view(nseq, T, nh, hd), kv5[:, :, 0], kv5[:, :, 1], kv_start=kv_start, kv_bdiv=nseq // n_mem, out=a4)
+    # the nseq / n_mem sequences that share one memory are contiguous rows: present them as ONE query sequence per memory, so a
+    # workgroup stages the memory's K/V once per 64 query rows instead of once per (short) sequence
+    per = (nseq // n_mem) * T
+    ops.attention(qc.view(n_mem, per, nh, hd), kv5[:, :, 0], kv5[:, :, 1], kv_start=kv_start, out=att.view(n_mem, per, nh, hd))
     ops.linear(att, L.ca_ow, bias=L.ca_ob, residual=x, out=x)
     ops.norm(x, L.n[2][0], L.n[2][1], eps=eps, out=h)
     ops.linear(h, L.l1w, bias=L.l1b, act=act, out=ff)

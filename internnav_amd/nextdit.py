@@ -216,7 +216,9 @@ class NextDiTSystem1:
         a4 = att.view(nseq, T, nh, hd)
         ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], out=a4)
         kv5 = Lr["kv2"][: B * Lz].view(B, Lz, 2, nh, hd)
-        ops.attention(q5[:, :, 3], kv5[:, :, 0], kv5[:, :, 1], kv_bdiv=S, head_gate=Lr["gate"], out=a4, accumulate=True)
+        # the env's S samples share the condition K/V and are contiguous rows: one S*T-row query sequence per env
+        q2 = qkvq.view(B, S * T, 4, nh, hd)[:, :, 3]
+        ops.attention(q2, kv5[:, :, 0], kv5[:, :, 1], head_gate=Lr["gate"], out=att.view(B, S * T, nh, hd), accumulate=True)
         ops.linear(att, Lr["wo"], out=proj)
         ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x)
         ops.norm(x, Lr["fn1"], None, eps=1e-5, rms=True, mod_scale=scale_mlp, mod_div=S * T, out=h)
