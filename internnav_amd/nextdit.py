@@ -143,7 +143,7 @@ class NextDiTSystem1:
         self.h = torch.empty(rows, D, dtype=bf, device=dev)
         self.att = torch.empty(rows, D, dtype=bf, device=dev)
         self.qkvq = torch.empty(rows, 4 * D, dtype=bf, device=dev)
-        self.proj = torch.empty(rows, D, dtype=f32, device=dev)
+        self.proj = torch.empty(rows, D, dtype=bf, device=dev)   # wo / w2 outputs feed an RMSNorm, not the residual stream: bf16 halves their traffic
         self.ff = torch.empty(rows, cfg["dit_ffn"], dtype=bf, device=dev)
         self.sample = torch.empty(rows, 3, dtype=f32, device=dev)
 
