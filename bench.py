@@ -246,6 +246,18 @@ class N1Dual:
                           "combined at 1 S2 : 10 S1; fp32 torch CPU, batch-1 as the reference executes"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
+    bench): average FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per GEMM launch of the same workload, or None if not collected."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if not f.exists():
+        return None
+    t = json.loads(f.read_text()).get(workload)
+    if not t:
+        return None
+    return {"bytes_per_launch": round((t["read_MB_per_launch_x2_corrected"] + t["write_MB_per_launch"]) * 1e6), "kernel": t["kernel"], "source": t["source"]}
+
+
 # ------------------------------------------------------------------------------------------------------------ driver
 def main():
     a = parse()
@@ -308,7 +320,7 @@ def main():
         roofline = {
             "bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all tile configs)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic(a.workload),
             "instrumented_pass": {"what": "one System-1 call over all envs" + (f" + one System-2 call over {extra} envs" if extra else ""),
                                   "gemm_launches": gm["launches"], "gemm_avg_launch_us": round(gm["ms"] * 1e3 / max(gm["launches"], 1), 2),
                                   "gemm_tflop": round(gm["flops"] / 1e12, 3),
