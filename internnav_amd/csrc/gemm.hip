@@ -188,7 +188,11 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         else if (p.N <= 64) cfg = 5;
         else cfg = 2;
     }
-    if (p.force_cfg <= 0 && cfg == 1 && p.K % 64 == 0) cfg = 11;   // large problem, K multiple of 64: LDS-DMA staged kernel
+    if (p.force_cfg <= 0 && cfg == 1 && p.K % 64 == 0) {
+        // K multiple of 64: LDS-DMA staged kernels. Long K and enough 256x128 tiles to fill the chip: 8 waves, 3-stage ring.
+        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.batch;
+        cfg = (p.K >= 1024 && t256 >= 256) ? 14 : 11;
+    }
     switch (cfg) {
         case 1: return launch_cfg<128, 128, 64, 2, 2>(p, stream);
         case 2: return launch_cfg<64, 128, 64, 2, 2>(p, stream);   // wave tile 32x64
@@ -198,7 +202,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 11: case 12: case 13: case 14: case 15: case 16: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

@@ -15,12 +15,12 @@
 
 namespace {
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 struct GldsCfg {
     static constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     static constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;   // 1 KiB wave-instructions per wave per stage
-    static constexpr size_t LDS_BYTES = size_t(2) * (BM + BN) * BK * sizeof(bf16);
+    static constexpr size_t LDS_BYTES = size_t(NS) * (BM + BN) * BK * sizeof(bf16);
 };
 
 __device__ __forceinline__ void glds16(const bf16* src, bf16* lds_wave_base) {
@@ -28,12 +28,12 @@ __device__ __forceinline__ void glds16(const bf16* src, bf16* lds_wave_base) {
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool STAGED>
+template <int BM, int BN, int WM, int WN, int NS, bool STAGED>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p) {
-    using C = GldsCfg<BM, BN, WM, WN>;
+    using C = GldsCfg<BM, BN, WM, WN, NS>;
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
-    bf16* As = reinterpret_cast<bf16*>(smem_raw);          // [2][BM][64]
-    bf16* Bs = As + 2 * BM * 64;                           // [2][BN][64]
+    bf16* As = reinterpret_cast<bf16*>(smem_raw);          // [NS][BM][64]
+    bf16* Bs = As + NS * BM * 64;                          // [NS][BN][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -74,12 +74,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
 
     const int nk = p.K / 64;
     const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
-    stage(0, 0);
+    // NS-stage ring: K tiles t+1 .. t+NS-1 are in flight while tile t is multiplied. The wait is COUNTED (only the DMA of tile t
+    // has to have landed: the newer tiles' INST wave-instructions may stay outstanding) and the barrier is a raw s_barrier -
+    // __syncthreads() would emit vmcnt(0) for the pending LDS-DMA writes and drain the ring (guide 5, glds "span a barrier").
+    constexpr int INST = C::A_INST + C::B_INST;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s * 64);
+    int buf = 0;
     for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of K tile t has landed
-        __syncthreads();                                     // ... everyone's has, and everyone is done reading buf ^ 1
-        if (t + 1 < nk) stage(buf ^ 1, (t + 1) * 64);
+        // number of newer tiles already issued: min(NS - 2, nk - 1 - t)
+        const int newer = (nk - 1 - t) < (NS - 2) ? (nk - 1 - t) : (NS - 2);
+        if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // tile t visible to all waves; all waves done with the buffer refilled below
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        {
+            const int nt = t + NS - 1;                       // next tile to request goes into the buffer read in iteration t - 1
+            int nb = buf + NS - 1;
+            if (nb >= NS) nb -= NS;
+            if (nt < nk) stage(nb, nt * 64);
+        }
         const bf16* as = As + buf * BM * 64 + (wm * C::TM + frow) * 64;
         const bf16* bs = Bs + buf * BN * 64 + (wn * C::TN + frow) * 64;
 #pragma unroll
@@ -95,6 +110,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
 #pragma unroll
                 for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+        if (++buf == NS) buf = 0;
     }
     if constexpr (STAGED) {
         __syncthreads();   // every wave is done with the stage buffers: the whole LDS becomes the per-wave transpose scratch
@@ -107,16 +123,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 int launch_glds(const GemmArgs& p, hipStream_t stream) {
-    using C = GldsCfg<BM, BN, WM, WN>;
+    using C = GldsCfg<BM, BN, WM, WN, NS>;
     // the LDS-transposed epilogue needs 16-byte aligned output (and residual) rows and 64-column wave tiles
     const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
     const bool staged = C::TN == 64 && ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
                         (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) &&
                         ((p.glu ? p.N / 2 : p.N) % 4 == 0);
     static bool attr_done[2] = {false, false};
-    auto kern = staged ? gemm_bf16_glds_kernel<BM, BN, WM, WN, true> : gemm_bf16_glds_kernel<BM, BN, WM, WN, false>;
+    auto kern = staged ? gemm_bf16_glds_kernel<BM, BN, WM, WN, NS, true> : gemm_bf16_glds_kernel<BM, BN, WM, WN, NS, false>;
     if (!attr_done[staged]) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_done[staged] = true;
@@ -132,13 +148,17 @@ int launch_glds(const GemmArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-// cfg 11: 128x128 / 4 waves, cfg 12: 256x128 / 8 waves, cfg 13: 128x256 / 8 waves
+// cfg 11: 128x128 / 4 waves / 2 stages, cfg 12: 256x128 / 8 waves / 2 stages, cfg 13: 128x256 / 8 waves / 2 stages,
+// cfg 14: 256x128 / 8 waves / 3 stages, cfg 15: 128x128 / 4 waves / 3 stages, cfg 16: 128x256 / 8 waves / 3 stages
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
     INA_REQUIRE(p.K % 64 == 0, "gemm(glds): K=%d must be a multiple of 64", p.K);
     switch (cfg) {
-        case 11: return launch_glds<128, 128, 2, 2>(p, stream);
-        case 12: return launch_glds<256, 128, 4, 2>(p, stream);
-        case 13: return launch_glds<128, 256, 2, 4>(p, stream);
+        case 11: return launch_glds<128, 128, 2, 2, 2>(p, stream);
+        case 12: return launch_glds<256, 128, 4, 2, 2>(p, stream);
+        case 13: return launch_glds<128, 256, 2, 4, 2>(p, stream);
+        case 14: return launch_glds<256, 128, 4, 2, 3>(p, stream);
+        case 15: return launch_glds<128, 128, 2, 2, 3>(p, stream);
+        case 16: return launch_glds<128, 256, 2, 4, 3>(p, stream);
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }
 }
