@@ -159,6 +159,7 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 14: return launch_glds<256, 128, 4, 2, 3>(p, stream);
         case 15: return launch_glds<128, 128, 2, 2, 3>(p, stream);
         case 16: return launch_glds<128, 256, 2, 4, 3>(p, stream);
+        case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }
 }
