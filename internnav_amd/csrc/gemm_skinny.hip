@@ -39,14 +39,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, float* __r
     const bool wok = wn < p.N;
     const bf16* wrow = W + (size_t)(wok ? wn : 0) * p.ldw;
 
-    for (int k0 = k_begin; k0 < k_end; k0 += SK_BK) {
-        // lane group g owns k in [k0 + g*32, k0 + g*32 + 32): 4 MFMA k-steps of 8 elements each
-        bf16x8 wf[4];
+    // software pipeline: the loads of K step t+1 (4 x 16 B of W + 4*MF x 16 B of A per lane) are issued before the MFMAs of step t
+    auto load_w = [&](int k0, bf16x8 (&wf)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = k0 + g * 32 + s * 8;
+            const int k = k0 + g * 32 + s * 8;   // lane group g owns k in [k0 + g*32, k0 + g*32 + 32): 4 MFMA k-steps of 8 elements
             wf[s] = (wok && k < k_end) ? *reinterpret_cast<const bf16x8*>(wrow + k) : zero8;
         }
+    };
+    auto load_a = [&](int k0, bf16x8 (&af)[MF][4]) {
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const int m = i * 16 + r16;
@@ -54,12 +55,30 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, float* __r
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = k0 + g * 32 + s * 8;
-                bf16x8 af = (m < p.M && k < k_end) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8;
-                // D[row = n_local][col = m_local]: lane holds m = r16, n = g*4 + r
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc[i], 0, 0, 0);
+                af[i][s] = (m < p.M && k < k_end) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8;
             }
         }
+    };
+    bf16x8 wf[2][4], af[2][MF][4];
+    load_w(k_begin, wf[0]);
+    load_a(k_begin, af[0]);
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += 2 * SK_BK) {
+        // two K steps per trip so the ping-pong register sets are indexed statically
+        load_w(k0 + SK_BK, wf[1]);
+        load_a(k0 + SK_BK, af[1]);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][s], af[0][i][s], acc[i], 0, 0, 0);
+        load_w(k0 + 2 * SK_BK, wf[0]);
+        load_a(k0 + 2 * SK_BK, af[0]);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][s], af[1][i][s], acc[i], 0, 0, 0);
     }
+    (void)cur;
     const int n = n0 + g * 4;
     if (n < p.N) {
 #pragma unroll

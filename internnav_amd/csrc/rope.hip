@@ -65,16 +65,24 @@ __global__ __launch_bounds__(256) void mrope_table_kernel(MropeTableArgs p) {
     }
 }
 
-__global__ __launch_bounds__(256) void argmax_kernel(ArgmaxArgs p) {
-    __shared__ float bv[4];
-    __shared__ int bi[4];
+// 1024 threads per row, 16-byte loads: the row (152064 logits = 594 KiB) is a single latency-bound stream for one workgroup
+__global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxArgs p) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
     const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* x = p.X + (size_t)r * p.ldx;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int j = threadIdx.x; j < p.n; j += 256) {
+    const int n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? (p.n >> 2) : 0;
+    for (int j = threadIdx.x; j < n4; j += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (v[q] > best) { best = v[q]; idx = 4 * j + q; }   // ascending index per thread: the first maximum is kept
+    }
+    for (int j = n4 * 4 + threadIdx.x; j < p.n; j += 1024) {
         const float v = x[j];
-        if (v > best) { best = v; idx = j; }   // ascending j per thread: the first maximum is kept
+        if (v > best || (v == best && j < idx)) { best = v; idx = j; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(ArgmaxArgs p) {
     if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
         p.out[r] = idx;
     }
@@ -129,7 +137,7 @@ int ina_launch_mrope_table(const MropeTableArgs& p, hipStream_t stream) {
 int ina_launch_argmax(const ArgmaxArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.rows > 0 && p.n > 0 && p.X && p.out, "argmax_rows: bad arguments rows=%d n=%d", p.rows, p.n);
     InaProfScope prof(INA_PROF_ELEMENTWISE, 0.0, 4.0 * p.rows * p.n, stream);
-    hipLaunchKernelGGL(argmax_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(argmax_kernel, dim3(p.rows), dim3(1024), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -429,3 +429,17 @@ def test_attention_decode_gqa_split_kv(ops, B, Lq, Lk, H, Hkv, D, causal):
     for b in range(B):
         n = int(lens[b])
         _close(out2[b:b + 1], _ref_attn(q[b:b + 1], k[b:b + 1, :n], v[b:b + 1, :n], D ** -0.5, causal), atol=1.5e-2)
+
+
+def test_argmax_rows_first_maximum(ops):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(7, 152064, generator=g).to(_dev())
+    x[2, 777] = x[2, 90000] = 50.0   # tie: the first maximum wins (torch.argmax semantics used by greedy decoding)
+    x[5, 152063] = 60.0
+    out = torch.empty(7, dtype=torch.int32, device=_dev())
+    ops.argmax_rows(x, out)
+    assert out.tolist() == x.argmax(-1).tolist() and out[2].item() == 777 and out[5].item() == 152063
+    y = torch.randn(3, 1001, generator=g).to(_dev())[:, 1:]   # unaligned rows, odd length
+    o2 = torch.empty(3, dtype=torch.int32, device=_dev())
+    ops.argmax_rows(y, o2)
+    assert o2.tolist() == y.argmax(-1).tolist()
