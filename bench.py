@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
+    ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     return ap.parse_args()
 
 
@@ -168,6 +169,26 @@ class N1Dual:
         self.s1_graph = None
         self.action_shape = (B, 4)
         self.actions = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+        # Two-stream schedule (same results, different order): System-1 of the envs that do NOT run System-2 this step is independent
+        # of it and is launched on a side stream, concurrently with the System-2 micro-batch (whose decode passes are launch-latency /
+        # HBM bound and leave the MFMA pipes idle); System-1 of the 6-7 System-2 envs follows System-2 on the main stream, on a second
+        # small engine instance (own workspace).
+        self.overlap = not getattr(a, "no_overlap", False) and not a.no_graph
+        if self.overlap:
+            from internnav_amd.nextdit import NextDiTSystem1
+            from internnav_amd.policy import _Prefixed
+
+            self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax)
+            self.side = torch.cuda.Stream(device=dev)
+            nA = B - min(self.mb)
+            self.latA, self.imgA, self.xA = (torch.empty((nA,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                                             for t in (self.latent_table, self.images_dp, self.x_init))
+            self.latB, self.imgB, self.xB = (torch.empty((mmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                                             for t in (self.latent_table, self.images_dp, self.x_init))
+            self.idxA = [torch.tensor([e for e in range(B) if not (int(self.mb_start[j]) <= e < int(self.mb_start[j]) + self.mb[j])],
+                                      device=dev) for j in range(self.CADENCE)]
+            self.traj = torch.empty(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
+            self.gA, self.gB = {}, {}
 
     def _s2_call(self, m):
         s = self.s2[m]
@@ -183,8 +204,71 @@ class N1Dual:
             s["pv"].copy_(self.pixel_values[:m].reshape(-1, 1176))
             s["graph"] = runtime.GraphedCall(lambda m=m: self._s2_call(m), {})
         self.s1_graph = runtime.GraphedCall(lambda: self._s1_call(), {})
+        if self.overlap:
+            for m in sorted(set(self.mb)):
+                nA = self.B - m
+                self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA]), {}, workspace_slot=1)
+                self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m]), {}, workspace_slot=2)
+
+    def check_overlap(self):
+        """same step run with both schedules from the same state and noise: the trajectories must agree (different batch splits select
+        different GEMM tile kernels, so the comparison is to bf16 tolerance, not bit-exact)."""
+        self.freeze_noise = True
+        lat0 = self.latent_table.clone()
+        ov = self.overlap
+        self.overlap = False
+        self.step(0)
+        t1 = self.last_traj.clone()
+        self.latent_table.copy_(lat0)
+        self.overlap = ov
+        self.step(0)
+        t2 = self.last_traj.clone()
+        self.latent_table.copy_(lat0)
+        self.freeze_noise = False
+        return float((t1 - t2).abs().max().item()), float(t1.abs().max().item())
+
+    def _finish(self, traj):
+        self.last_traj = traj
+        t = traj.cpu()                                        # [B, 32, 32, 3] -> host post-processing of the reference (vln_utils)
+        acts = np.zeros((self.B, 4), dtype=np.int32)
+        for b in range(self.B):
+            al = [x for x in self.traj_to_actions(t[b]) if x != 0][:4]
+            acts[b, :len(al)] = al
+        self.actions.copy_(torch.from_numpy(acts))
+        return self.actions
+
+    def step_overlapped(self, i):
+        j = i % self.CADENCE
+        m, lo = self.mb[j], int(self.mb_start[j])
+        nA, idx = self.B - m, self.idxA[j]
+        s = self.s2[m]
+        main = torch.cuda.current_stream()
+        if not getattr(self, "freeze_noise", False):
+            self.x_init.normal_(generator=self.g)
+        # side stream: System-1 for the envs keeping their current plan (latents of earlier System-2 calls)
+        torch.index_select(self.latent_table, 0, idx, out=self.latA[:nA])
+        torch.index_select(self.images_dp, 0, idx, out=self.imgA[:nA])
+        torch.index_select(self.x_init, 0, idx, out=self.xA[:nA])
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            trajA = self.gA[nA]()
+        # main stream: System-2 micro-batch, then System-1 for exactly those envs
+        s["P"]["ids"].copy_(self.ids[lo:lo + m].reshape(-1).to(torch.int32))
+        s["pv"].copy_(self.pixel_values[lo:lo + m].reshape(-1, 1176))
+        s["graph"]()
+        self.latent_table[lo:lo + m].copy_(s["lat"])
+        self.latB[:m].copy_(s["lat"])
+        self.imgB[:m].copy_(self.images_dp[lo:lo + m])
+        self.xB[:m].copy_(self.x_init[lo:lo + m])
+        trajB = self.gB[m]()
+        main.wait_stream(self.side)
+        self.traj.index_copy_(0, idx, trajA)
+        self.traj[lo:lo + m].copy_(trajB)
+        return self._finish(self.traj)
 
     def step(self, i):
+        if self.overlap:
+            return self.step_overlapped(i)
         j = i % self.CADENCE
         m, lo = self.mb[j], int(self.mb_start[j])
         s = self.s2[m]
@@ -194,15 +278,10 @@ class N1Dual:
         s["graph"]() if s["graph"] else self._s2_call(m)
         self.latent_table[lo:lo + m].copy_(s["lat"])
         # System-1 for every env
-        self.x_init.normal_(generator=self.g)
+        if not getattr(self, "freeze_noise", False):
+            self.x_init.normal_(generator=self.g)
         traj = self.s1_graph() if self.s1_graph else self._s1_call()
-        t = traj.cpu()                                        # [B, 32, 32, 3] -> host post-processing of the reference (vln_utils)
-        acts = np.zeros((self.B, 4), dtype=np.int32)
-        for b in range(self.B):
-            al = [x for x in self.traj_to_actions(t[b]) if x != 0][:4]
-            acts[b, :len(al)] = al
-        self.actions.copy_(torch.from_numpy(acts))
-        return self.actions
+        return self._finish(traj)
 
     def instrumented(self):
         m = max(self.mb)
@@ -293,6 +372,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    overlap_check = None
+    if getattr(wl, "overlap", False):
+        overlap_check = wl.check_overlap()
     for i in range(a.warmup):
         step(i)
     sync()
@@ -334,9 +416,13 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}",
-                            "launch": "eager" if a.no_graph else "hipGraph replay", "device": arch}, **wl.desc),
+                            "launch": "eager" if a.no_graph else "hipGraph replay",
+                            "schedule": "S1(non-S2 envs) on a side stream || S2 micro-batch, then S1(S2 envs)" if getattr(wl, "overlap", False) else "single stream",
+                            "device": arch}, **wl.desc),
             "roofline": roofline,
         }
+        if overlap_check is not None:
+            line["config"]["schedule_check"] = {"max_abs_diff_vs_single_stream": round(overlap_check[0], 5), "traj_abs_max": round(overlap_check[1], 3)}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -43,6 +43,10 @@ int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
  * stream and its algorithmic FLOPs / bytes are tallied per kernel class (0 gemm, 1 attention, 2 norm, 3 elementwise).
  * ina_prof_enable(0|1) also clears the tally; ina_prof_read synchronises on the recorded events. Eager launches only. */
+/* Library-owned scratch (split-K partials of the skinny GEMM, flash-decoding partials) lives in numbered slots [0, 8). Launches
+ * use the slot current at issue time (default 0) and a captured graph keeps it: graphs that may replay concurrently on different
+ * streams must be captured under different slots. */
+int ina_set_workspace_slot(int slot);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 

@@ -159,6 +159,7 @@ SYMBOLS = {
     "ina_mrope_table": (C.c_int, [C.POINTER(MropeTableArgs), c_void_p]),
     "ina_argmax_rows": (C.c_int, [C.POINTER(ArgmaxArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
+    "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),
     "ina_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

@@ -40,7 +40,39 @@ InaProfScope::~InaProfScope() {
     (void)hipEventRecord(g_prof[idx].b, stream);
 }
 
+// ---- workspace slots -----------------------------------------------------------------------------------------------
+namespace {
+int g_ws_slot = 0;
+float* g_ws_ptr[INA_WS_KINDS][INA_WS_SLOTS] = {};
+size_t g_ws_cap[INA_WS_KINDS][INA_WS_SLOTS] = {};
+}  // namespace
+
+int ina_workspace(int kind, size_t bytes, hipStream_t stream, float** out) {
+    float*& ptr = g_ws_ptr[kind][g_ws_slot];
+    size_t& cap = g_ws_cap[kind][g_ws_slot];
+    if (bytes > cap) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &st);
+        INA_REQUIRE(st == hipStreamCaptureStatusNone,
+                    "workspace (kind %d, slot %d) of %zu bytes needed during graph capture: run the shape once eagerly under this slot first", kind,
+                    g_ws_slot, bytes);
+        INA_HIP_CHECK(hipDeviceSynchronize());
+        if (ptr) INA_HIP_CHECK(hipFree(ptr));
+        const size_t want = bytes < (size_t)(32u << 20) ? (size_t)(32u << 20) : bytes * 2;
+        INA_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ptr), want));
+        cap = want;
+    }
+    *out = ptr;
+    return 0;
+}
+
 extern "C" {
+
+int ina_set_workspace_slot(int slot) {
+    INA_REQUIRE(slot >= 0 && slot < INA_WS_SLOTS, "workspace slot %d out of range [0, %d)", slot, INA_WS_SLOTS);
+    g_ws_slot = slot;
+    return 0;
+}
 
 int ina_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -323,30 +323,19 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(AttnArgs p, con
     if (lane + 64 < p.D) O[lane + 64] = (bf16)(o1 * inv);
 }
 
-float* g_dec_ws = nullptr;
-size_t g_dec_ws_bytes = 0;
-
 template <int DP, int DV>
 int launch_decode(const AttnArgs& p, hipStream_t stream) {
     const int G = p.H / p.Hkv;
     const int rtiles = (G * p.Lq + 15) / 16;
     const int nsplit = (p.Lk + DEC_CHUNK - 1) / DEC_CHUNK;
     const size_t bytes = (size_t)p.B * p.Hkv * rtiles * nsplit * 16 * (DV + 2) * sizeof(float);
-    if (bytes > g_dec_ws_bytes) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &st);
-        INA_REQUIRE(st == hipStreamCaptureStatusNone, "attention(decode): workspace of %zu bytes needed during graph capture: run the shape once eagerly first", bytes);
-        INA_HIP_CHECK(hipDeviceSynchronize());
-        if (g_dec_ws) INA_HIP_CHECK(hipFree(g_dec_ws));
-        const size_t want = bytes < (size_t)(32u << 20) ? (size_t)(32u << 20) : bytes * 2;
-        INA_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_dec_ws), want));
-        g_dec_ws_bytes = want;
-    }
+    float* ws = nullptr;
+    if (int rc = ina_workspace(1, bytes, stream, &ws)) return rc;
     const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)p.Lk;
     InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
                       2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)p.B * p.Hkv * p.Lk), stream);
-    hipLaunchKernelGGL((attn_decode_split_kernel<DP, DV>), dim3(nsplit, p.Hkv * rtiles, p.B), dim3(64), 0, stream, p, g_dec_ws, nsplit, rtiles);
-    hipLaunchKernelGGL((attn_decode_combine_kernel<DV>), dim3(G * p.Lq, p.Hkv, p.B), dim3(64), 0, stream, p, g_dec_ws, nsplit, rtiles);
+    hipLaunchKernelGGL((attn_decode_split_kernel<DP, DV>), dim3(nsplit, p.Hkv * rtiles, p.B), dim3(64), 0, stream, p, ws, nsplit, rtiles);
+    hipLaunchKernelGGL((attn_decode_combine_kernel<DV>), dim3(G * p.Lq, p.Hkv, p.B), dim3(64), 0, stream, p, ws, nsplit, rtiles);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

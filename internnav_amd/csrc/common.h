@@ -84,6 +84,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 void ina_set_error(const char* fmt, ...);
 
+// Library-owned scratch (split-K partials, flash-decoding partials) lives in numbered workspace slots. Launches use the slot that
+// is current when they are issued (ina_set_workspace_slot, default 0); the pointer is baked into a captured graph, so graphs that
+// may be replayed CONCURRENTLY on different streams must be captured under different slots. Buffers grow on demand outside capture.
+constexpr int INA_WS_SLOTS = 8;
+constexpr int INA_WS_KINDS = 2;   // 0 skinny-GEMM split-K partials, 1 decode-attention partials
+int ina_workspace(int kind, size_t bytes, hipStream_t stream, float** out);
+
 // Optional per-launch timing (ina_prof_enable): every launch function opens a scope that records a hipEvent pair on the
 // launch stream around its kernel and tallies the algorithmic FLOPs / bytes of that launch. bench.py reads the totals per
 // kernel class for the live roofline line; disabled (the default) it costs one branch. Not usable under graph capture.

@@ -146,27 +146,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue(GemmArgs p, const fl
     }
 }
 
-float* g_ws = nullptr;
-size_t g_ws_bytes = 0;
-
 }  // namespace
-
-// Workspace for the split-K partials: owned by the library, grown on demand OUTSIDE of stream capture (the first eager call of a
-// shape - every engine warms up before capturing).
-static int skinny_workspace(size_t bytes, hipStream_t stream, float** out) {
-    if (bytes > g_ws_bytes) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &st);
-        INA_REQUIRE(st == hipStreamCaptureStatusNone, "gemm(skinny): workspace of %zu bytes needed during graph capture: run the shape once eagerly first", bytes);
-        INA_HIP_CHECK(hipDeviceSynchronize());
-        if (g_ws) INA_HIP_CHECK(hipFree(g_ws));
-        const size_t want = bytes < (size_t)(64u << 20) ? (size_t)(64u << 20) : bytes * 2;
-        INA_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g_ws), want));
-        g_ws_bytes = want;
-    }
-    *out = g_ws;
-    return 0;
-}
 
 int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     const int tiles = (p.N + SK_BN - 1) / SK_BN;
@@ -176,7 +156,7 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     const int kslice = ((ksteps + splits - 1) / splits) * SK_BK;
     splits = (p.K + kslice - 1) / kslice;
     float* part = nullptr;
-    const int rc = skinny_workspace((size_t)splits * p.M * p.N * sizeof(float), stream, &part);
+    const int rc = ina_workspace(0, (size_t)splits * p.M * p.N * sizeof(float), stream, &part);
     if (rc) return rc;
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);

@@ -129,8 +129,8 @@ class NextDiTSystem1:
         self.mod_w = torch.cat(mods_w, 0).to(device=dev, dtype=bf).contiguous()    # [12*1536 + 384, 384]
         self.mod_b = torch.cat(mods_b, 0).to(device=dev, dtype=f32).contiguous()
         self.mod = torch.empty(max_envs, self.mod_w.shape[0], dtype=f32, device=dev)
-        w2, b2 = sd[p + "norm_out.linear_2.weight"].float(), sd[p + "norm_out.linear_2.bias"].float()
-        wd, bd = sd["action_decoder.weight"].float(), sd["action_decoder.bias"].float()
+        w2, b2 = sd[p + "norm_out.linear_2.weight"].float().cpu(), sd[p + "norm_out.linear_2.bias"].float().cpu()
+        wd, bd = sd["action_decoder.weight"].float().cpu(), sd["action_decoder.bias"].float().cpu()   # load-time constant folding on the host
         self.head_w = (wd @ w2).to(dev).contiguous()            # [3, 384]
         self.head_b = (wd @ b2 + bd).to(dev).contiguous()       # [3]
         self.ae_w, self.ae_b = f("action_encoder.weight"), f("action_encoder.bias")

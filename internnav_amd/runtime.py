@@ -31,8 +31,10 @@ class GraphedCall:
     """Capture `fn(**static_inputs)` once and replay it. `fn` must only launch library kernels / torch copies on the current
     stream and write its results into persistent buffers (all engines in this package do)."""
 
-    def __init__(self, fn: Callable, static_inputs: Dict[str, torch.Tensor], warmup: int = 2):
+    def __init__(self, fn: Callable, static_inputs: Dict[str, torch.Tensor], warmup: int = 2, workspace_slot: int = 0):
+        """workspace_slot: library scratch slot baked into this graph; graphs that may replay concurrently need different slots."""
         self.inputs = static_inputs
+        _lib.check(_lib.lib().ina_set_workspace_slot(workspace_slot), "set_workspace_slot")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -43,6 +45,7 @@ class GraphedCall:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.outputs = fn(**static_inputs)
+        _lib.check(_lib.lib().ina_set_workspace_slot(0), "set_workspace_slot")
 
     def __call__(self, **new_inputs):
         for k, v in new_inputs.items():
