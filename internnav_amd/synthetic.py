@@ -368,6 +368,19 @@ def qwen_inputs(B: int, n_img: int, seed: int = 0, cfg=QWEN_TEST_CFG, grid=(1, 2
     return dict(input_ids=input_ids, pixel_values=pixel_values, grid_thw=grid_thw)
 
 
+def qwen_lookdown_inputs(cfg=QWEN_TEST_CFG):
+    """S2 prompt with the un-resized look-down frame of the reference's callers (internvla_n1_policy.py:113-116,140):
+    text | <vs> 196 img <ve> | text | <vs> 391 img <ve> | tail, grids (1,28,28) and (1,34,46) (476x644 pixels -> ragged windows)."""
+    g = torch.Generator().manual_seed(4242)
+    lim = cfg["image_token_id"] - 8
+    ids = torch.randint(0, lim, (12,), generator=g).tolist()
+    for n in (196, 391):
+        ids += [cfg["vision_start_id"]] + [cfg["image_token_id"]] * n + [cfg["vision_end_id"]] + torch.randint(0, lim, (5,), generator=g).tolist()
+    grid = torch.tensor([[1, 28, 28], [1, 34, 46]])
+    pv = torch.randn(28 * 28 + 34 * 46, 1176, generator=g).to(torch.bfloat16).float()
+    return dict(input_ids=torch.tensor([ids]), pixel_values=pv, grid_thw=grid)
+
+
 def navdpnet_state_dict(seed: int = 0, cfg=NAVDPNET_CFG):
     return materialize(navdpnet_spec(cfg), seed)
 

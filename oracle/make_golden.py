@@ -262,7 +262,7 @@ def gold_qwen(B=2, n_img=2):
         gen = torch.cat([gen, lg[:, -1].argmax(-1)[:, None]], dim=1)
     ids_q = torch.cat([gen, torch.full((B, cfg["n_query"]), cfg["traj_token_id"], dtype=torch.long)], dim=1)
     _, hq, _, _ = ref_forward(ids_q)
-    latents = hq[:, -cfg["n_query"]:]
+    latents = hq[:, -cfg["n_query"]:].clone()
     with torch.no_grad():
         o_emb = o_q.vision_tower(pv, grid, sd, cfg)
         o_pos, _ = o_q.rope_index(ids, grid, cfg["image_token_id"], cfg["vision_start_id"])
@@ -272,8 +272,9 @@ def gold_qwen(B=2, n_img=2):
     assert torch.equal(o_pos, pos), "rope_index differs from the reference's get_rope_index_25"
     assert torch.equal(o_gen, gen), "greedy tokens differ"
     d = max((o_emb - emb).abs().max().item(), (o_logits - logits).abs().max().item(), (o_lat - latents).abs().max().item())
-    return dict(B=B, n_img=n_img, seed=6, image_embeds=emb, position_ids=pos, last_logits=logits[:, -1].clone(),
-                logits_sample=logits[:, ::37].clone(), generated=gen, latents=latents, oracle_max_abs_diff=d)
+    # fixtures stay small: every 8th row of the image embeds, last-position logits only
+    return dict(B=B, n_img=n_img, seed=6, image_embeds=emb[::8].clone(), embed_row_stride=8, position_ids=pos.to(torch.int32),
+                last_logits=logits[:, -1].clone(), generated=gen, latents=latents, oracle_max_abs_diff=d)
 
 
 def gold_vln_utils():
@@ -297,7 +298,56 @@ def gold_vln_utils():
     return dict(cases=cases, texts=texts, split=[vu.split_and_clean(t) for t in texts], oracle_max_abs_diff=0.0)
 
 
-UNITS = {"vln_utils": gold_vln_utils, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_qwen_lookdown():
+    """S2 with the un-resized look-down frame the reference feeds (476x644 -> 34x46 patches, ragged 112-pixel windows: 17x23 merged
+    cells = 9 full + 6 half + ... windows) next to a 28x28 frame, B = 1: transformers vision tower + text model, same glue as gold_qwen."""
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLTextConfig, Qwen2_5_VLVisionConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel, Qwen2_5_VLTextModel
+
+    from . import qwen_vl as o_q
+
+    cfg = W.QWEN_TEST_CFG
+    sd = W.qwen_state_dict(seed=6, cfg=cfg)
+    vc = Qwen2_5_VLVisionConfig(depth=cfg["v_depth"], hidden_size=cfg["v_hidden"], intermediate_size=cfg["v_inter"], num_heads=cfg["v_heads"],
+                                out_hidden_size=cfg["v_out"], fullatt_block_indexes=list(cfg["v_fullatt"]), window_size=cfg["v_window"])
+    vc._attn_implementation = "eager"
+    vit = Qwen2_5_VisionTransformerPretrainedModel(vc).float().eval()
+    vit.load_state_dict({k[len("visual."):]: v for k, v in sd.items() if k.startswith("visual.")}, strict=True)
+    tc = Qwen2_5_VLTextConfig(vocab_size=cfg["vocab"], hidden_size=cfg["t_hidden"], intermediate_size=cfg["t_inter"],
+                              num_hidden_layers=cfg["t_layers"], num_attention_heads=cfg["t_heads"], num_key_value_heads=cfg["t_kv_heads"],
+                              rms_norm_eps=1e-6, rope_parameters={"rope_type": "default", "rope_theta": cfg["rope_theta"], "mrope_section": [16, 24, 24]},
+                              max_position_embeddings=32768, pad_token_id=0)
+    tc._attn_implementation = "eager"
+    llm = Qwen2_5_VLTextModel(tc).float().eval()
+    llm.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.") and k != "model.latent_queries"}, strict=True)
+    inp = lookdown_inputs(cfg)
+    ids, pv, grid = inp["input_ids"], inp["pixel_values"], inp["grid_thw"]
+    src = (R.REF / "internnav" / "dataset" / "rope2d.py").read_text()
+    src = src.replace("image_token_id = 151655", f"image_token_id = {cfg['image_token_id']}").replace(
+        "vision_start_token_id = 151652", f"vision_start_token_id = {cfg['vision_start_id']}")
+    ns = {}
+    exec(compile(src, "rope2d_patched", "exec"), ns)
+    with torch.no_grad():
+        emb = vit(pv, grid_thw=grid).pooler_output
+        x = llm.embed_tokens(ids)
+        x = x.masked_scatter((ids == cfg["image_token_id"]).unsqueeze(-1).expand_as(x), emb)
+        pos, _ = ns["get_rope_index_25"](2, ids, grid)
+        h = llm(inputs_embeds=x, position_ids=pos, use_cache=False).last_hidden_state
+        logits = torch.nn.functional.linear(h[:, -1], sd["lm_head.weight"])
+        o_emb = o_q.vision_tower(pv, grid, sd, cfg)
+        o_pos, _ = o_q.rope_index(ids, grid, cfg["image_token_id"], cfg["vision_start_id"])
+        o_logits, _ = o_q.forward_logits(sd, cfg, ids, pv, grid)
+    assert torch.equal(o_pos, pos)
+    d = max((o_emb - emb).abs().max().item(), (o_logits[:, -1] - logits).abs().max().item())
+    return dict(seed=6, image_embeds=emb[::8].clone(), embed_row_stride=8, position_ids=pos.to(torch.int32), last_logits=logits,
+                oracle_max_abs_diff=d)
+
+
+def lookdown_inputs(cfg):
+    return W.qwen_lookdown_inputs(cfg)
+
+
+UNITS = {"vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

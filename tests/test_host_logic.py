@@ -32,7 +32,7 @@ def test_rope_index_and_window_permutation_match_fixture_and_oracle():
     inp = synthetic.qwen_inputs(gold["B"], gold["n_img"], seed=gold["seed"], cfg=cfg)
     grids = [tuple(g) for g in inp["grid_thw"].tolist()]
     pos, deltas = rope_index(inp["input_ids"].numpy(), grids, cfg["image_token_id"], cfg["vision_start_id"])
-    assert np.array_equal(pos, gold["position_ids"].numpy())
+    assert np.array_equal(pos, gold["position_ids"].numpy().astype(np.int64))
     # ragged / odd grids incl. the 476x644 look-down frame (34x46 patches) and a tiny 2x2-cell image
     for gs in ([(1, 28, 28)], [(1, 34, 46), (1, 28, 28)], [(1, 4, 4)], [(1, 16, 16), (1, 18, 30), (1, 28, 28)]):
         wi, cu = vision_window_permutation(gs)
@@ -159,3 +159,81 @@ def test_data_parallel_helpers_gloo_world2():
     for r in res:
         assert r[2] == [[[0.0] * 4] * 3, [[1.0] * 4] * 3]
         assert r[3] == [float(i) for i in range(11)]
+
+
+class _FakeTok:
+    def decode(self, ids, skip_special_tokens=True):
+        return "".join(chr(int(i)) for i in ids)
+
+
+class _FakeProcessor:
+    """stand-in for the HF processor: one token per character of the chat text, one 4-patch image per <image>."""
+    tokenizer = _FakeTok()
+
+    def apply_chat_template(self, conv, tokenize=False, add_generation_prompt=True):
+        out = ""
+        for turn in conv:
+            for c in turn["content"]:
+                out += "<image>" if c["type"] == "image" else c["text"]
+        return out
+
+    def __call__(self, text, images, return_tensors="pt"):
+        t = text[0]
+        ids = [ord(ch) % 500 for ch in t.replace("<image>", "")] + [1001] * (4 * len(images))
+        return {"input_ids": torch.tensor([ids]), "pixel_values": torch.zeros(16 * len(images), 1176),
+                "image_grid_thw": torch.tensor([[1, 4, 4]] * len(images))}
+
+
+class _FakeModel:
+    device = torch.device("cpu")
+
+    def __init__(self, answers):
+        self.answers, self.batches, self.fail_b = answers, [], None
+
+    def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, **kw):
+        from types import SimpleNamespace
+
+        B, S = input_ids.shape
+        self.batches.append((B, S))
+        if self.fail_b == B:
+            raise RuntimeError("injected S2 failure")
+        ans = [self.answers.pop(0) for _ in range(B)]
+        n = max(len(a) for a in ans)
+        toks = torch.tensor([[ord(c) for c in a] + [0] * (n - len(a)) for a in ans])
+        return SimpleNamespace(sequences=torch.cat([input_ids, toks], 1))
+
+    def generate_latents(self, seqs, pv, grid):
+        return torch.zeros(seqs.shape[0], 4, 8)
+
+    def generate_traj(self, traj_latents=None, images_dp=None, depths_dp=None):
+        B = traj_latents.shape[0]
+        t = torch.zeros(B * 32, 32, 3)
+        t[:, :, 0] = 1.0   # straight ahead: 0.25 m per waypoint after the /4 un-normalisation -> forward actions
+        return t
+
+
+def test_agent_batches_s2_by_prompt_length_and_falls_back_to_stop_on_failure():
+    """real InternVLAN1Net prompt building (history sampling, chat template, processor call) inside the batched agent: envs with equal
+    prompt lengths share one generate() call; a failing group emits STOP ([0]) for its envs only and the agent never raises (:156-189)."""
+    from internnav_amd.agent import InternVLAN1Agent
+
+    model = _FakeModel(["↑↑", "←", "12 34"])
+    ag = InternVLAN1Agent({"model_settings": {"infer_mode": "partial_async"}}, model=model, processor=_FakeProcessor())
+    rgb = np.zeros((8, 8, 3), np.uint8)
+    dep = np.zeros((8, 8, 1), np.float32)
+    obs = [{"rgb": rgb, "depth": dep, "instruction": "go to the door"}, {"rgb": rgb, "depth": dep, "instruction": "go to the wall"},
+           {"rgb": rgb, "depth": dep, "instruction": "a much longer instruction than the other two"}]
+    ag.reset()
+    out = ag.step(obs)
+    assert sorted(model.batches) == sorted([(2, model.batches[0][1] if model.batches[0][0] == 2 else model.batches[1][1]), (1, max(b[1] for b in model.batches))])
+    assert [o["action"] for o in out][:2] == [[1], [2]]
+    assert out[2]["action"] == [1]          # pixel goal "12 34" -> latent -> System-1 -> forward
+    # failure of one length group: only its envs stop
+    model.answers = ["→", "→", "→"]
+    for e in ag.envs:
+        e.s2_output.output_action = None
+        e.s2_output.output_latent = None
+        e.s2_output.output_pixel = None
+    model.fail_b = 1                          # the singleton length group (env 2) fails inside generate()
+    out = ag.step(obs)
+    assert [o["action"] for o in out] == [[3], [3], [0]]

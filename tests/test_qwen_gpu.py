@@ -32,14 +32,14 @@ def test_rope_index_matches_reference(setup):
     gold, cfg, inp, _ = setup
     grids = [tuple(g) for g in inp["grid_thw"].tolist()]
     pos, _ = rope_index(inp["input_ids"].numpy(), grids, cfg["image_token_id"], cfg["vision_start_id"])
-    assert np.array_equal(pos, gold["position_ids"].numpy())  # bit-exact integer logic vs the reference's get_rope_index_25
+    assert np.array_equal(pos, gold["position_ids"].numpy().astype(np.int64))  # bit-exact integer logic vs the reference's get_rope_index_25
 
 
 def test_vision_tower(setup):
     gold, cfg, inp, eng = setup
     grids = [tuple(g) for g in inp["grid_thw"].tolist()]
     emb, inv = eng.vision(inp["pixel_values"].to(DEV, torch.bfloat16), grids)
-    out = emb.float().cpu()[torch.from_numpy(inv).long()]
+    out = emb.float().cpu()[torch.from_numpy(inv).long()][:: gold["embed_row_stride"]]
     ref = gold["image_embeds"]
     d = (out - ref).abs()
     print(f"image embeds: mean|err| {d.mean():.3e} max|err| {d.max():.3e} ref rms {ref.pow(2).mean().sqrt():.3f}")
@@ -139,3 +139,59 @@ def test_facade_generate_then_latents_reuses_cache(setup):
     img = torch.rand(gold["B"], 2, 224, 224, 3, generator=torch.Generator().manual_seed(1))
     traj = m.generate_traj(lat, img.to(DEV))
     assert traj.shape == (32 * gold["B"], 32, 3) and torch.isfinite(traj).all()
+
+
+def test_lookdown_frame_ragged_windows(built_lib):
+    """the un-resized look-down frame (476x644 -> 34x46 patches): ragged 112-px windows (full / half / quarter) and a 391-token image next
+    to a 196-token one - vision tower, 3-D rope index and last-position logits vs the transformers / reference fixture."""
+    from internnav_amd import synthetic
+    from internnav_amd.qwen_vl import QwenVLEngine, rope_index
+
+    gold = torch.load(Path(__file__).resolve().parent / "golden" / "qwen_lookdown.pt", weights_only=True)
+    cfg = W.QWEN_TEST_CFG
+    sd = W.qwen_state_dict(seed=gold["seed"], cfg=cfg)
+    inp = synthetic.qwen_lookdown_inputs(cfg)
+    grids = [tuple(g) for g in inp["grid_thw"].tolist()]
+    pos, _ = rope_index(inp["input_ids"].numpy(), grids, cfg["image_token_id"], cfg["vision_start_id"])
+    assert np.array_equal(pos, gold["position_ids"].numpy().astype(np.int64))
+    eng = QwenVLEngine(sd, cfg, DEV, max_seqs=1, max_seq_len=1024, max_patches=inp["pixel_values"].shape[0])
+    pv = inp["pixel_values"].to(DEV, torch.bfloat16)
+    emb, inv = eng.vision(pv, grids)
+    out = emb.float().cpu()[torch.from_numpy(inv).long()][:: gold["embed_row_stride"]]
+    d = (out - gold["image_embeds"]).abs()
+    rms = gold["image_embeds"].pow(2).mean().sqrt()
+    print(f"look-down image embeds: mean|err| {d.mean():.3e} max|err| {d.max():.3e} ref rms {rms:.3f}")
+    assert d.mean() < 1e-2 * rms
+    st = eng.prefill(inp["input_ids"], pv, inp["grid_thw"])
+    eng._last_logits(1, st["S"], st["S"] - 1)
+    dl = (eng.logits[:1].float().cpu() - gold["last_logits"]).abs()
+    print(f"look-down last logits: mean|err| {dl.mean():.3e} max|err| {dl.max():.3e}")
+    assert dl.mean() < 5e-3 * gold["last_logits"].std() and dl.max() < 5e-2 * gold["last_logits"].std()
+
+
+def test_ragged_answers_latents_after_early_eos(setup):
+    """batched generate where one sequence hits EOS after its first token: generate_latents must place the latent queries right behind
+    each sequence's own last kept token (per-sequence key lengths) == the reference's batch-1 semantics, checked against the oracle."""
+    from internnav_amd.policy import InternVLAN1ForCausalLM
+    from internnav_amd import synthetic
+    from oracle import qwen_vl as o_q
+
+    gold, cfg, inp, eng = setup
+    S = inp["input_ids"].shape[1]
+    eos = int(gold["generated"][0, S])          # first generated token of sequence 0 plays EOS: sequence 0 stops after one token
+    assert int(gold["generated"][1, S]) != eos and eos not in gold["generated"][1, S:].tolist()
+    sd = synthetic.materialize(synthetic.n1_full_spec(cfg), seed=gold["seed"])
+    m = InternVLAN1ForCausalLM(sd, cfg, "nextdit_async", device=DEV, max_envs=2, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+    seqs = m.generate(input_ids=inp["input_ids"], pixel_values=inp["pixel_values"], image_grid_thw=inp["grid_thw"], max_new_tokens=3,
+                      do_sample=False, return_dict_in_generate=True, eos_token_id=eos).sequences.cpu()
+    assert seqs[0, S:].tolist() == [eos, eos, eos] and torch.equal(seqs[1], gold["generated"][1])
+    lat = m.generate_latents(seqs, inp["pixel_values"], inp["grid_thw"]).float().cpu()
+    qsd = {k: v for k, v in sd.items() if not k.startswith("model.traj_dit") and not k.startswith("model.rgb_")}
+    per_img = inp["pixel_values"].shape[0] // 2
+    with torch.no_grad():
+        ref0 = o_q.generate_latents(qsd, cfg, seqs[0:1, : S + 1], inp["pixel_values"][:per_img], inp["grid_thw"][: gold["n_img"]])
+        ref1 = o_q.generate_latents(qsd, cfg, seqs[1:2], inp["pixel_values"][per_img:], inp["grid_thw"][gold["n_img"]:])
+    for b, ref in ((0, ref0), (1, ref1)):
+        d = (lat[b] - ref[0]).abs()
+        print(f"seq {b}: latents mean|err| {d.mean():.3e} max|err| {d.max():.3e}")
+        assert d.mean() < 1e-2 * ref.pow(2).mean().sqrt()
