@@ -400,14 +400,15 @@ def main():
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         step_tflops = (value / world) * wl.f_alg / 1e12
         roofline = {
-            "bound": "mfma", "kernel": "gemm_bf16_nt_kernel (all tile configs)",
+            "bound": "mfma", "kernel": "gemm_bf16_glds_kernel (LDS-DMA tiled MFMA GEMM, all tile configs; + gemm_bf16_nt_kernel for K % 64 != 0)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": pmc_traffic(a.workload),
             "instrumented_pass": {"what": "one System-1 call over all envs" + (f" + one System-2 call over {extra} envs" if extra else ""),
                                   "gemm_launches": gm["launches"], "gemm_avg_launch_us": round(gm["ms"] * 1e3 / max(gm["launches"], 1), 2),
                                   "gemm_tflop": round(gm["flops"] / 1e12, 3),
                                   "kernel_class_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
-                                  "kernel_class_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) for k, v in prof.items()}},
+                                  "kernel_class_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1) for k, v in prof.items()},
+                                  "kernel_class_algorithmic_GBps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in prof.items()}},
             "whole_step": {"algorithmic_tflop_per_env_step": round(wl.f_alg / 1e12, 4),
                            "achieved_tflops_per_gpu": round(step_tflops, 1), "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
         }

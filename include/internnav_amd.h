@@ -41,7 +41,8 @@ int ina_device_check(char* name, int n);
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
- * stream and its algorithmic FLOPs / bytes are tallied per kernel class (0 gemm, 1 attention, 2 norm, 3 elementwise).
+ * stream and its algorithmic FLOPs / bytes are tallied per kernel class (0 tiled MFMA gemm, 1 attention, 2 norm, 3 elementwise,
+ * 4 weight-streaming skinny gemm (M <= 64, HBM-bound)).
  * ina_prof_enable(0|1) also clears the tally; ina_prof_read synchronises on the recorded events. Eager launches only. */
 /* Library-owned scratch (split-K partials of the skinny GEMM, flash-decoding partials) lives in numbered slots [0, 8). Launches
  * use the slot current at issue time (default 0) and a captured graph keeps it: graphs that may replay concurrently on different
@@ -71,7 +72,7 @@ typedef struct ina_gemm_args {
     int32_t batch;          /* 0 means 1; grid.y batches with the element strides below */
     int64_t strideA, strideW, strideC, strideR;
     int32_t force_cfg;      /* 0 = auto tile selection */
-    int32_t _pad;
+    int32_t group_m;        /* tile order of the LDS-DMA kernels: 0 = auto, 1 = row-major, n > 1 = groups of n row-tiles (L2 locality) */
 } ina_gemm_args;
 int ina_gemm_bf16(const ina_gemm_args* args, void* stream);
 

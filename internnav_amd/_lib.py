@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
         ("act", c_int32), ("out_dtype", c_int32), ("res_dtype", c_int32), ("glu", c_int32),
         ("rowscale_div", c_int32), ("batch", c_int32),
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
-        ("force_cfg", c_int32), ("_pad", c_int32),
+        ("force_cfg", c_int32), ("group_m", c_int32),
     ]
 
 

@@ -94,7 +94,7 @@ int ina_workspace(int kind, size_t bytes, hipStream_t stream, float** out);
 // Optional per-launch timing (ina_prof_enable): every launch function opens a scope that records a hipEvent pair on the
 // launch stream around its kernel and tallies the algorithmic FLOPs / bytes of that launch. bench.py reads the totals per
 // kernel class for the live roofline line; disabled (the default) it costs one branch. Not usable under graph capture.
-enum : int { INA_PROF_GEMM = 0, INA_PROF_ATTN = 1, INA_PROF_NORM = 2, INA_PROF_ELEMENTWISE = 3, INA_PROF_KINDS = 4 };
+enum : int { INA_PROF_GEMM = 0, INA_PROF_ATTN = 1, INA_PROF_NORM = 2, INA_PROF_ELEMENTWISE = 3, INA_PROF_GEMM_SKINNY = 4, INA_PROF_KINDS = 5 };
 struct InaProfScope {
     InaProfScope(int kind, double flops, double bytes, hipStream_t stream);
     ~InaProfScope();

@@ -39,7 +39,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (id / tiles_n) * BM, n0 = (id % tiles_n) * BN;
+    int tm, tn;
+    if (p.group_m > 1) {
+        // grouped order: GM row-tiles x all column-tiles per group, row index fastest -> the ~32 workgroups an XCD runs at a time
+        // cover a GM x (32/GM) block of tiles (GM + 32/GM operand panels instead of 1 + 32)
+        const int gsz = p.group_m * tiles_n, grp = id / gsz, first = grp * p.group_m;
+        const int gm = min(tiles_m - first, p.group_m), in = id - grp * gsz;
+        tm = first + in % gm;
+        tn = in / gm;
+    } else {
+        tm = id / tiles_n;
+        tn = id % tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (size_t)blockIdx.y * p.strideA;
     const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (size_t)blockIdx.y * p.strideW;
 
@@ -138,10 +150,15 @@ int launch_glds(const GemmArgs& p, hipStream_t stream) {
         attr_done[staged] = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    GemmArgs q = p;
+    // auto tile order: with many column tiles the ~32 workgroups an XCD runs concurrently would share one A panel and stream 32
+    // different W panels; groups of 8 row-tiles cut the panels per 32 tiles from 33 to 12 (PMC: FETCH_SIZE of the gate/up GEMM,
+    // measured +9 % on 6440x37888x3584 and +10 % on 8192^3). Small grids keep the plain row-major order.
+    if (q.group_m == 0) q.group_m = ((p.N + BN - 1) / BN >= 24 && (p.M + BM - 1) / BM >= 8) ? 8 : 1;
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
                       (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, q);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

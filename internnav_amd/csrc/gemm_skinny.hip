@@ -159,7 +159,7 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     const int rc = ina_workspace(0, (size_t)splits * p.M * p.N * sizeof(float), stream, &part);
     if (rc) return rc;
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
-    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
+    InaProfScope prof(INA_PROF_GEMM_SKINNY, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
     dim3 grid(tiles, splits);
     const int mf = (p.M + 15) / 16;
     switch (mf) {

@@ -41,7 +41,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
            rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
-           batched: bool = False) -> torch.Tensor:
+           batched: bool = False, group_m: int = 0) -> torch.Tensor:
     """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
 
     batched=True: x is [Bt, M, K] and out [Bt, M, N] views with arbitrary batch strides (rows contiguous-strided inside a
@@ -88,6 +88,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.glu = 1 if glu else 0
     a.rowscale_div = rowscale_div
     a.force_cfg = force_cfg
+    a.group_m = group_m
     _lib.check(_lib.lib().ina_gemm_bf16(C.byref(a), _stream()), "gemm_bf16")
     return out
 

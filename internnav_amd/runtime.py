@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-PROF_KINDS = ("gemm", "attention", "norm", "elementwise")
+PROF_KINDS = ("gemm", "attention", "norm", "elementwise", "gemm_skinny")
 
 
 def require_gfx950() -> str:

@@ -380,6 +380,19 @@ def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     _close(out, ref, rtol=2e-3, atol=5e-3)
 
 
+@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (17, 5), (17, 0)])
+def test_gemm_glds_grouped_tile_order(ops, cfg, group_m):
+    """Grouped tile order (group_m row-tiles per group, ragged last group, auto rule at 0) is a pure re-ordering: same result as
+    row-major, bit for bit, and equal to the fp32 reference."""
+    M, N, K = 2900, 6400 + 72, 256
+    g = torch.Generator().manual_seed(cfg * 31 + group_m)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    out = ops.linear(x, w, out_dtype=torch.float32, force_cfg=cfg, group_m=group_m)
+    row_major = ops.linear(x, w, out_dtype=torch.float32, force_cfg=cfg, group_m=1)
+    assert torch.equal(out, row_major)
+    _close(out, x.float() @ w.float().t(), rtol=2e-3, atol=5e-3)
+
+
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]
 
 
