@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
+    ap.add_argument("--overlap-at", choices=["start", "decode"], default="start",
+                    help="n1_dual: side-stream System-1 starts with the System-2 micro-batch, or only once its prefill is done (decode phase)")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     return ap.parse_args()
 
@@ -188,7 +190,9 @@ class N1Dual:
             self.idxA = [torch.tensor([e for e in range(B) if not (int(self.mb_start[j]) <= e < int(self.mb_start[j]) + self.mb[j])],
                                       device=dev) for j in range(self.CADENCE)]
             self.traj = torch.empty(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
-            self.gA, self.gB = {}, {}
+            self.gA, self.gB, self.gP, self.gD = {}, {}, {}, {}
+            self.overlap_at = a.overlap_at
+            self.ev = torch.cuda.Event()
 
     def _s2_call(self, m):
         s = self.s2[m]
@@ -209,6 +213,14 @@ class N1Dual:
                 nA = self.B - m
                 self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA]), {}, workspace_slot=1)
                 self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m]), {}, workspace_slot=2)
+                if self.overlap_at == "decode":
+                    s, q = self.s2[m], self.model.qwen
+                    self.gP[m] = runtime.GraphedCall(lambda s=s: q.run_prefill(s["P"], s["pv"]), {})
+
+                    def dec(s=s):
+                        q.run_decode(s["P"], s["toks"])
+                        q.run_latents(s["P"], s["lat"])
+                    self.gD[m] = runtime.GraphedCall(dec, {})
 
     def check_overlap(self):
         """same step run with both schedules from the same state and noise: the trajectories must agree (different batch splits select
@@ -249,13 +261,23 @@ class N1Dual:
         torch.index_select(self.latent_table, 0, idx, out=self.latA[:nA])
         torch.index_select(self.images_dp, 0, idx, out=self.imgA[:nA])
         torch.index_select(self.x_init, 0, idx, out=self.xA[:nA])
-        self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            trajA = self.gA[nA]()
+        late = self.overlap_at == "decode"
+        if not late:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                trajA = self.gA[nA]()
         # main stream: System-2 micro-batch, then System-1 for exactly those envs
         s["P"]["ids"].copy_(self.ids[lo:lo + m].reshape(-1).to(torch.int32))
         s["pv"].copy_(self.pixel_values[lo:lo + m].reshape(-1, 1176))
-        s["graph"]()
+        if late:
+            self.gP[m]()
+            self.ev.record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev)
+                trajA = self.gA[nA]()
+            self.gD[m]()
+        else:
+            s["graph"]()
         self.latent_table[lo:lo + m].copy_(s["lat"])
         self.latB[:m].copy_(s["lat"])
         self.imgB[:m].copy_(self.images_dp[lo:lo + m])
