@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
-    ap.add_argument("--overlap-at", choices=["start", "decode"], default="start",
+    ap.add_argument("--overlap-at", choices=["start", "decode"], default="decode",
                     help="n1_dual: side-stream System-1 starts with the System-2 micro-batch, or only once its prefill is done (decode phase)")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     return ap.parse_args()
@@ -440,7 +440,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}",
                             "launch": "eager" if a.no_graph else "hipGraph replay",
-                            "schedule": "S1(non-S2 envs) on a side stream || S2 micro-batch, then S1(S2 envs)" if getattr(wl, "overlap", False) else "single stream",
+                            "schedule": (("S2 ViT+prefill, then S2 decode+latent queries || S1(non-S2 envs) on a side stream, then S1(S2 envs)"
+                                          if getattr(wl, "overlap_at", "") == "decode" else
+                                          "S1(non-S2 envs) on a side stream || S2 micro-batch, then S1(S2 envs)")
+                                         if getattr(wl, "overlap", False) else "single stream"),
                             "device": arch}, **wl.desc),
             "roofline": roofline,
         }

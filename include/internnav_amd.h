@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -271,6 +271,31 @@ typedef struct ina_select_args {
     int32_t B, S, T, k, _pad;
 } ina_select_args;
 int ina_select_traj(const ina_select_args* args, void* stream);
+
+/* ---- dit_attention: the attention stage of one NextDiT block in one launch:
+ *          O = SDPA(LN(q1), LN(k1), v1) + tanh(head_gate[h]) * SDPA(LN(q2), K2, V2)
+ *      X rows hold the fused projection [q1 | k1 | v1 | q2], each heads*64 wide; LN = LayerNorm over the whole segment
+ *      ("layer_norm_across_heads"); self-attention inside each T-token sequence, cross-attention against the Lz condition rows of
+ *      env = seq / seq_per_env.  reference: diffusers LuminaAttnProcessor2_0 + LuminaNextDiTBlock gate (diffusers==0.33.1,
+ *      requirements/internvla_n1.txt:3) as wired by nextdit_traj.py:121-188.
+ *      V2T is the transposed, key-permuted image of the condition V the kernel consumes; a call with V2T_src != NULL (re)builds it
+ *      from V2T_src [env][Lz][heads*64] (strides v2_bs / v2_rs) first, and with X == NULL does only that. */
+typedef struct ina_dit_attn_args {
+    const void* X;          /* bf16 [nseq*T, 4*heads*64], row stride ldx */
+    void* O;                /* bf16 [nseq*T, heads*64], row stride ldo */
+    const float* g_q1; const float* b_q1;   /* f32 [heads*64] LayerNorm weight / bias of q1, k1, q2 */
+    const float* g_k1; const float* b_k1;
+    const float* g_q2; const float* b_q2;
+    const void* K2;         /* bf16 condition keys: element (env, row, h, d) at env*k2_bs + row*k2_rs + h*64 + d */
+    void* V2T;              /* bf16 [envs, heads, 64, 64] */
+    const void* V2T_src;    /* bf16 condition values or NULL */
+    const float* head_gate; /* f32 [heads] (tanh applied) or NULL */
+    int64_t k2_bs, k2_rs, v2_bs, v2_rs;
+    int32_t nseq, T, heads, seq_per_env, Lz, ldx, ldo;
+    float scale, eps;
+    int32_t _pad;
+} ina_dit_attn_args;
+int ina_dit_attention(const ina_dit_attn_args* args, void* stream);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,16 @@ class ArgmaxArgs(C.Structure):
     _fields_ = [("X", c_void_p), ("out", c_void_p), ("rows", c_int32), ("n", c_int32), ("ldx", c_int32), ("_pad", c_int32)]
 
 
+class DitAttnArgs(C.Structure):
+    _fields_ = [
+        ("X", c_void_p), ("O", c_void_p), ("g_q1", c_void_p), ("b_q1", c_void_p), ("g_k1", c_void_p), ("b_k1", c_void_p),
+        ("g_q2", c_void_p), ("b_q2", c_void_p), ("K2", c_void_p), ("V2T", c_void_p), ("V2T_src", c_void_p), ("head_gate", c_void_p),
+        ("k2_bs", c_int64), ("k2_rs", c_int64), ("v2_bs", c_int64), ("v2_rs", c_int64),
+        ("nseq", c_int32), ("T", c_int32), ("heads", c_int32), ("seq_per_env", c_int32), ("Lz", c_int32), ("ldx", c_int32), ("ldo", c_int32),
+        ("scale", c_float), ("eps", c_float), ("_pad", c_int32),
+    ]
+
+
 class SelectArgs(C.Structure):
     _fields_ = [
         ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
@@ -158,6 +168,7 @@ SYMBOLS = {
     "ina_rope_bf16": (C.c_int, [C.POINTER(RopeArgs), c_void_p]),
     "ina_mrope_table": (C.c_int, [C.POINTER(MropeTableArgs), c_void_p]),
     "ina_argmax_rows": (C.c_int, [C.POINTER(ArgmaxArgs), c_void_p]),
+    "ina_dit_attention": (C.c_int, [C.POINTER(DitAttnArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),

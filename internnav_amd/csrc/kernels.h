@@ -21,6 +21,7 @@ using GatherArgs = ina_gather_args;
 using RopeArgs = ina_rope_args;
 using MropeTableArgs = ina_mrope_table_args;
 using ArgmaxArgs = ina_argmax_args;
+using DitAttnArgs = ina_dit_attn_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
@@ -37,3 +38,4 @@ int ina_launch_gather(const GatherArgs& p, hipStream_t stream);
 int ina_launch_rope(const RopeArgs& p, hipStream_t stream);
 int ina_launch_mrope_table(const MropeTableArgs& p, hipStream_t stream);
 int ina_launch_argmax(const ArgmaxArgs& p, hipStream_t stream);
+int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream);  // q/k-LayerNorm + self-attention + gated cross-attention of a NextDiT block

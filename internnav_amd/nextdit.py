@@ -123,7 +123,8 @@ class NextDiTSystem1:
                 wo=w(b + ".attn2.to_out.0.weight"), n2=f(b + ".norm2.weight"), fn1=f(b + ".ffn_norm1.weight"), fn2=f(b + ".ffn_norm2.weight"),
                 w13=_interleave16(sd[b + ".feed_forward.linear_1.weight"].float(), sd[b + ".feed_forward.linear_3.weight"].float()).to(device=dev, dtype=bf),
                 w2=w(b + ".feed_forward.linear_2.weight"),
-                kv2=torch.empty(max_envs * self.Lz, 2 * D, dtype=bf, device=dev)))
+                kv2=torch.empty(max_envs * self.Lz, 2 * D, dtype=bf, device=dev),
+                v2t=torch.empty(max_envs, self.nh, 64, 64, dtype=bf, device=dev)))
         mods_w.append(sd[p + "norm_out.linear_1.weight"])
         mods_b.append(sd[p + "norm_out.linear_1.bias"])
         self.mod_w = torch.cat(mods_w, 0).to(device=dev, dtype=bf).contiguous()    # [12*1536 + 384, 384]
@@ -199,6 +200,7 @@ class NextDiTSystem1:
             ops.linear(self.enc_n[:zr], Lr["wkv2"], out=kv)
             kk = kv.view(zr * 2, D)
             ops.norm(kk, Lr["k2n"][0], Lr["k2n"][1], eps=1e-5, out=kk, rows=zr, in_map=(1, 2, 0), out_map=(1, 2, 0))
+            ops.dit_v2t(kv.view(B, Lz, 2, self.nh, D // self.nh), self.nh, Lr["v2t"])   # V image the fused attention stage consumes
 
     # ------------------------------------------------------------------------------------------------ DiT
     def _dit_layer(self, l: int, B: int):
@@ -209,16 +211,10 @@ class NextDiTSystem1:
         scale_msa, gate_msa, scale_mlp, gate_mlp = m[:, :D], m[:, D:2 * D], m[:, 2 * D:3 * D], m[:, 3 * D:]
         ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
         ops.linear(h, Lr["wq"], out=qkvq)
-        seg = qkvq.view(rows * 4, D)   # row 4r + j = segment j (q1, k1, v1, q2) of token r
-        for j, nrm in ((0, Lr["q1n"]), (1, Lr["k1n"]), (3, Lr["q2n"])):   # LayerNorm across heads on q1, k1, q2 (in place)
-            ops.norm(seg, nrm[0], nrm[1], eps=1e-5, out=seg, rows=rows, in_map=(1, 4, j), out_map=(1, 4, j))
-        q5 = qkvq.view(nseq, T, 4, nh, hd)
-        a4 = att.view(nseq, T, nh, hd)
-        ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], out=a4)
+        # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
+        # env's condition rows (shared by its S samples): one launch, the projection row is read once
         kv5 = Lr["kv2"][: B * Lz].view(B, Lz, 2, nh, hd)
-        # the env's S samples share the condition K/V and are contiguous rows: one S*T-row query sequence per env
-        q2 = qkvq.view(B, S * T, 4, nh, hd)[:, :, 3]
-        ops.attention(q2, kv5[:, :, 0], kv5[:, :, 1], head_gate=Lr["gate"], out=att.view(B, S * T, nh, hd), accumulate=True)
+        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, Lr["v2t"], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5)
         ops.linear(att, Lr["wo"], out=proj)
         ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x)
         ops.norm(x, Lr["fn1"], None, eps=1e-5, rms=True, mod_scale=scale_mlp, mod_div=S * T, out=h)

@@ -354,3 +354,42 @@ def argmax_rows(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     a.X, a.out, a.rows, a.n, a.ldx = x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0)
     _lib.check(_lib.lib().ina_argmax_rows(C.byref(a), _stream()), "argmax_rows")
     return out
+
+
+def dit_v2t(kv2: torch.Tensor, heads: int, v2t: torch.Tensor) -> torch.Tensor:
+    """condition V of a NextDiT block -> the transposed key-permuted image dit_attention consumes.
+    kv2 bf16 [envs, Lz, 2, heads, 64] (K | V as produced by the fused kv projection); v2t bf16 [envs, heads, 64, 64]."""
+    envs, Lz = kv2.shape[0], kv2.shape[1]
+    assert kv2.dtype == torch.bfloat16 and kv2.stride(-1) == 1 and v2t.dtype == torch.bfloat16 and v2t.is_contiguous()
+    assert v2t.numel() >= envs * heads * 64 * 64
+    v = kv2[:, :, 1]
+    a = _lib.DitAttnArgs()
+    a.X, a.V2T, a.V2T_src = None, v2t.data_ptr(), v.data_ptr()
+    a.v2_bs, a.v2_rs = v.stride(0), v.stride(1)
+    a.nseq, a.seq_per_env, a.T, a.heads, a.Lz = envs, 1, 1, heads, Lz
+    a.ldx, a.ldo, a.k2_bs, a.k2_rs = 8, 8, 8, 8
+    _lib.check(_lib.lib().ina_dit_attention(C.byref(a), _stream()), "dit_attention(v2t)")
+    return v2t
+
+
+def dit_attention(x: torch.Tensor, out: torch.Tensor, norms, kv2: torch.Tensor, v2t: torch.Tensor, head_gate: Optional[torch.Tensor],
+                  T: int, seq_per_env: int, heads: int, eps: float = 1e-5, scale: Optional[float] = None) -> torch.Tensor:
+    """NextDiT attention stage in one launch: out = SDPA(LN(q1), LN(k1), v1) + tanh(gate) * SDPA(LN(q2), K2, V2).
+
+    x bf16 [rows, 4*heads*64] = [q1 | k1 | v1 | q2] per token, rows = nseq * T; norms = ((g_q1, b_q1), (g_k1, b_k1), (g_q2, b_q2)) f32;
+    kv2 bf16 [envs, Lz, 2, heads, 64]; v2t from dit_v2t(kv2); out bf16 [rows, heads*64]."""
+    D = heads * 64
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 4 * D and x.stride(1) == 1 and x.shape[0] % T == 0
+    assert out.dtype == torch.bfloat16 and out.shape == (x.shape[0], D) and out.stride(1) == 1
+    nseq = x.shape[0] // T
+    assert kv2.shape[0] * seq_per_env >= nseq and kv2.stride(-1) == 1 and kv2.stride(-2) == 64
+    a = _lib.DitAttnArgs()
+    a.X, a.O = x.data_ptr(), out.data_ptr()
+    (a.g_q1, a.b_q1), (a.g_k1, a.b_k1), (a.g_q2, a.b_q2) = [(_f32(g).data_ptr(), _f32(b).data_ptr()) for g, b in norms]
+    k = kv2[:, :, 0]
+    a.K2, a.V2T, a.V2T_src, a.head_gate = k.data_ptr(), v2t.data_ptr(), None, _ptr(head_gate)
+    a.k2_bs, a.k2_rs = k.stride(0), k.stride(1)
+    a.nseq, a.T, a.heads, a.seq_per_env, a.Lz, a.ldx, a.ldo = nseq, T, heads, seq_per_env, kv2.shape[1], x.stride(0), out.stride(0)
+    a.scale, a.eps = (scale if scale is not None else 64 ** -0.5), eps
+    _lib.check(_lib.lib().ina_dit_attention(C.byref(a), _stream()), "dit_attention")
+    return out

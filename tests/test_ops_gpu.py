@@ -456,3 +456,45 @@ def test_argmax_rows_first_maximum(ops):
     o2 = torch.empty(3, dtype=torch.int32, device=_dev())
     ops.argmax_rows(y, o2)
     assert o2.tolist() == y.argmax(-1).tolist()
+
+
+@pytest.mark.parametrize("envs,S,T,Lz", [(2, 5, 32, 36), (1, 3, 20, 64), (3, 1, 32, 5), (2, 32, 32, 36)])
+def test_dit_attention_fused_qknorm_self_cross(ops, envs, S, T, Lz):
+    """NextDiT attention stage in one launch vs the unfused fp32 formula: LayerNorm across heads on q1 / k1 / q2, self-attention
+    inside each T-token sequence, tanh-gated cross-attention against the env's Lz condition rows; and vs the unfused op sequence
+    (3 norm launches + 2 attention launches) it replaces in the engine."""
+    heads, D = 6, 384
+    g = torch.Generator().manual_seed(envs * 100 + S * 10 + T + Lz)
+    nseq = envs * S
+    x = _rand((nseq * T, 4 * D), g)
+    kv2 = _rand((envs, Lz, 2, heads, 64), g)
+    norms = [(1.0 + 0.2 * torch.randn(D, generator=g)).to(_dev()) for _ in range(3)]
+    biases = [(0.2 * torch.randn(D, generator=g)).to(_dev()) for _ in range(3)]
+    gate = torch.randn(heads, generator=g).to(_dev())
+    v2t = torch.empty(envs, heads, 64, 64, dtype=torch.bfloat16, device=_dev())
+    ops.dit_v2t(kv2, heads, v2t)
+    out = torch.empty(nseq * T, D, dtype=torch.bfloat16, device=_dev())
+    ops.dit_attention(x, out, list(zip(norms, biases)), kv2, v2t, gate, T=T, seq_per_env=S, heads=heads)
+
+    xf = x.float().view(nseq, T, 4, D)
+    ln = lambda t, i: torch.nn.functional.layer_norm(t, (D,), norms[i], biases[i], 1e-5).to(torch.bfloat16).float()
+    q1, k1, v1, q2 = ln(xf[:, :, 0], 0), ln(xf[:, :, 1], 1), xf[:, :, 2], ln(xf[:, :, 3], 2)
+    hv = lambda t: t.view(t.shape[0], t.shape[1], heads, 64).transpose(1, 2)
+    sdpa = torch.nn.functional.scaled_dot_product_attention
+    o1 = sdpa(hv(q1), hv(k1), hv(v1)).transpose(1, 2).reshape(nseq, T, D)
+    kc = kv2[:, :, 0].float().repeat_interleave(S, 0).transpose(1, 2)
+    vc = kv2[:, :, 1].float().repeat_interleave(S, 0).transpose(1, 2)
+    o2 = sdpa(hv(q2), kc, vc).transpose(1, 2).reshape(nseq, T, heads, 64) * torch.tanh(gate).view(1, 1, heads, 1)
+    ref = (o1 + o2.reshape(nseq, T, D)).view(nseq * T, D)
+    _close(out, ref, atol=2e-2)
+
+    # the unfused launch sequence
+    seg = x.clone().view(nseq * T * 4, D)
+    for j, i in ((0, 0), (1, 1), (3, 2)):
+        ops.norm(seg, norms[i], biases[i], eps=1e-5, out=seg, rows=nseq * T, in_map=(1, 4, j), out_map=(1, 4, j))
+    q5 = seg.view(nseq, T, 4, heads, 64)
+    un = torch.empty_like(out)
+    ops.attention(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], out=un.view(nseq, T, heads, 64))
+    ops.attention(seg.view(envs, S * T, 4, heads, 64)[:, :, 3], kv2[:, :, 0], kv2[:, :, 1], head_gate=gate,
+                  out=un.view(envs, S * T, heads, 64), accumulate=True)
+    _close(out, un, atol=8e-3, rtol=1.0 / 128)
