@@ -114,7 +114,10 @@ typedef struct ina_rowmap {
 /* ---- LayerNorm / RMSNorm (+ NextDiT modulation / tanh gate / base add / positional table); reference: nn.LayerNorm call
  *      sites (dinov2_layers/block.py:83-87, navdp.py:78,193), diffusers RMSNorm / LuminaRMSNormZero (nextdit_traj.py:109-119,146,172-176).
  *      t = norm(X[in_map(r)]) * gamma + beta ; t *= 1 + mod_scale[r/mod_div] ; t *= tanh(gate[r/mod_div]) ; t += G[r] ; t += P[r % p_mod]
- *      -> Y[out_map(r)] (bf16) and/or Y32[out_map(r)] (f32). */
+ *      -> Y[out_map(r)] (bf16) and/or Y32[out_map(r)] (f32).
+ *      Chained pre-norm (Y2 != NULL): Y2[out_map(r)] = norm(t) * gamma2 * (1 + mod_scale2[r/mod_div]) (bf16; same rms / eps) - the
+ *      next sub-block's modulated norm of the residual row this call just produced (LuminaNextDiTBlock: norm2 -> ffn_norm1,
+ *      ffn_norm2 -> next block's norm1). */
 typedef struct ina_norm_args {
     const void* X;          /* bf16|f32 (x_dtype) rows of C, row stride ldx */
     void* Y;                /* bf16 out or NULL */
@@ -132,7 +135,10 @@ typedef struct ina_norm_args {
     int32_t mod_div, mod_ld;
     int32_t p_mod, rms;
     float eps;
-    int32_t _pad;
+    int32_t ldy2;
+    void* Y2;               /* bf16 chained output or NULL */
+    const float* gamma2;    /* f32 [C] or NULL */
+    const float* mod_scale2;/* f32 [rows/mod_div, mod_ld] or NULL */
 } ina_norm_args;
 int ina_norm_bf16(const ina_norm_args* args, void* stream);
 

@@ -57,7 +57,8 @@ class NormArgs(C.Structure):
         ("x_dtype", c_int32), ("g_dtype", c_int32),
         ("mod_div", c_int32), ("mod_ld", c_int32),
         ("p_mod", c_int32), ("rms", c_int32),
-        ("eps", c_float), ("_pad", c_int32),
+        ("eps", c_float), ("ldy2", c_int32),
+        ("Y2", c_void_p), ("gamma2", c_void_p), ("mod_scale2", c_void_p),
     ]
 
 

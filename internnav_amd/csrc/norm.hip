@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
         }
     }
     const float rstd = rsqrtf(group_sum(sq) * invC + p.eps);
-    if (!live) return;
+    if (!live) return;   // the lanes of a row group leave together: later group reductions stay well defined
 
     const int mrow = row / p.mod_div;
     const float* ms = p.mod_scale ? p.mod_scale + (size_t)mrow * p.mod_ld : nullptr;
@@ -126,6 +126,53 @@ __global__ __launch_bounds__(256) void norm_kernel(NormArgs p) {
             *reinterpret_cast<f32x4*>(y) = f32x4{t[0], t[1], t[2], t[3]};
             *reinterpret_cast<f32x4*>(y + 4) = f32x4{t[4], t[5], t[6], t[7]};
         }
+        if (p.Y2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = t[j];
+        }
+    }
+    if (!p.Y2) return;
+    // ---- chained second norm on the row just produced (the next sub-block's pre-norm of the new residual): saves re-reading it
+    float mean2 = 0.f;
+    if (!p.rms) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (gl + i * GL < nchunks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s2 += v[i][j];
+        mean2 = group_sum(s2) * invC;
+    }
+    float sq2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (gl + i * GL < nchunks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean2; sq2 += d * d; }
+    const float rstd2 = rsqrtf(group_sum(sq2) * invC + p.eps);
+    const float* ms2 = p.mod_scale2 ? p.mod_scale2 + (size_t)mrow * p.mod_ld : nullptr;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = gl + i * GL;
+        if (c >= nchunks) continue;
+        const int col = c * 8;
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (v[i][j] - mean2) * rstd2;
+        if (p.gamma2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.gamma2 + col), b = *reinterpret_cast<const f32x4*>(p.gamma2 + col + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t[j] *= a[j]; t[4 + j] *= b[j]; }
+        }
+        if (ms2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ms2 + col), b = *reinterpret_cast<const f32x4*>(ms2 + col + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { t[j] *= 1.0f + a[j]; t[4 + j] *= 1.0f + b[j]; }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)t[j];
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.Y2) + (size_t)out_row * p.ldy2 + col) = o;
     }
 }
 
@@ -148,10 +195,11 @@ int ina_launch_norm(const NormArgs& p_in, hipStream_t stream) {
     INA_REQUIRE(!p.Y || p.ldy % 8 == 0, "norm: ldy must be a multiple of 8");
     INA_REQUIRE(!p.Y32 || p.ldy32 % 4 == 0, "norm: ldy32 must be a multiple of 4");
     INA_REQUIRE(!p.G || p.ldg % 8 == 0, "norm: ldg must be a multiple of 8");
-    INA_REQUIRE((!p.mod_scale && !p.gate) || (p.mod_ld > 0 && p.mod_ld % 4 == 0), "norm: modulation needs mod_ld (multiple of 4)");
+    INA_REQUIRE(!p.Y2 || p.ldy2 % 8 == 0, "norm: ldy2 must be a multiple of 8");
+    INA_REQUIRE((!p.mod_scale && !p.gate && !p.mod_scale2) || (p.mod_ld > 0 && p.mod_ld % 4 == 0), "norm: modulation needs mod_ld (multiple of 4)");
     const int nchunks = p.C / 8;
     InaProfScope prof(INA_PROF_NORM, 8.0 * p.rows * p.C,
-                      (double)p.rows * p.C * ((p.x_dtype == INA_DT_F32 ? 4.0 : 2.0) + (p.Y ? 2.0 : 0.0) + (p.Y32 ? 4.0 : 0.0) +
+                      (double)p.rows * p.C * ((p.x_dtype == INA_DT_F32 ? 4.0 : 2.0) + (p.Y ? 2.0 : 0.0) + (p.Y32 ? 4.0 : 0.0) + (p.Y2 ? 2.0 : 0.0) +
                                               (p.G ? (p.g_dtype == INA_DT_F32 ? 4.0 : 2.0) : 0.0)), stream);
     if (nchunks <= 16) launch_norm<1, 4>(p, stream);        // C <= 128: 4 rows per wave
     else if (nchunks <= 32) launch_norm<1, 2>(p, stream);   // C <= 256

@@ -209,18 +209,26 @@ class NextDiTSystem1:
         x, h, att, qkvq, proj, ff = self.x[:rows], self.h[:rows], self.att[:rows], self.qkvq[:rows], self.proj[:rows], self.ff[:rows]
         m = self.mod[:B, l * 4 * D:(l + 1) * 4 * D]
         scale_msa, gate_msa, scale_mlp, gate_mlp = m[:, :D], m[:, D:2 * D], m[:, 2 * D:3 * D], m[:, 3 * D:]
-        ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
+        if l == 0:   # later blocks get their pre-norm from the previous block's ffn_norm2 launch (chained)
+            ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
         ops.linear(h, Lr["wq"], out=qkvq)
         # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
         # env's condition rows (shared by its S samples): one launch, the projection row is read once
         kv5 = Lr["kv2"][: B * Lz].view(B, Lz, 2, nh, hd)
         ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, Lr["v2t"], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5)
         ops.linear(att, Lr["wo"], out=proj)
-        ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x)
-        ops.norm(x, Lr["fn1"], None, eps=1e-5, rms=True, mod_scale=scale_mlp, mod_div=S * T, out=h)
+        # x += tanh(gate) * norm2(attn) and, chained in the same launch on the fresh row, h = ffn_norm1(x) * (1 + scale_mlp)
+        ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x,
+                 out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
         ops.linear(h, Lr["w13"], act="silu", glu=True, out=ff)
         ops.linear(ff, Lr["w2"], out=proj)
-        ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x)
+        # x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
+        if l + 1 < self.nl:
+            nxt = self.mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
+            ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x,
+                     out2=h, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt)
+        else:
+            ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x)
 
     def generate_traj(self, traj_latents: torch.Tensor, images_dp: torch.Tensor, x_init: torch.Tensor) -> torch.Tensor:
         """traj_latents bf16 [B,n_query,3584]; images_dp bf16|f32 [B,2,224,224,3] in 0..1; x_init f32 [B,S,T,3] (the initial

@@ -156,11 +156,13 @@ def norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[t
          eps: float = 1e-5, rms: bool = False, mod_scale: Optional[torch.Tensor] = None,
          gate: Optional[torch.Tensor] = None, base: Optional[torch.Tensor] = None, mod_div: int = 1,
          pos: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-         out32: Optional[torch.Tensor] = None, rows: Optional[int] = None, in_map=None, out_map=None) -> torch.Tensor:
+         out32: Optional[torch.Tensor] = None, rows: Optional[int] = None, in_map=None, out_map=None,
+         out2: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """LayerNorm / RMSNorm over the last dim of x (bf16 or f32) -> out (bf16) and/or out32 (f32).
 
     t = norm(x) * gamma + beta; t *= 1 + mod_scale[r // mod_div]; t *= tanh(gate[r // mod_div]); t += base[r]; t += pos[r % len(pos)].
     in_map / out_map = (seg_len, seg_stride, off) gather / scatter logical rows; `rows` = number of logical rows (default: all of x).
+    out2 (bf16): chained pre-norm of the produced row, out2 = norm(t) * gamma2 * (1 + mod_scale2[r // mod_div]) (same rms / eps).
     """
     assert x.dtype in _DT
     x2 = _as2d(x)
@@ -195,6 +197,13 @@ def norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[t
     if pos is not None:
         assert pos.dtype == torch.float32 and pos.is_contiguous() and pos.shape[-1] == Cdim
         a.P, a.p_mod = pos.data_ptr(), pos.numel() // Cdim
+    if out2 is not None:
+        w2 = _as2d(out2)
+        assert w2.dtype == torch.bfloat16 and w2.shape[1] == Cdim
+        a.Y2, a.ldy2, a.gamma2 = w2.data_ptr(), w2.stride(0), _ptr(_f32(gamma2))
+        if mod_scale2 is not None:
+            assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and (a.mod_ld in (0, mod_scale2.stride(0)))
+            a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
     a.in_map, a.out_map = _rowmap(in_map), _rowmap(out_map)
     a.mod_div = mod_div
     a.rms = 1 if rms else 0

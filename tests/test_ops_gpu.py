@@ -498,3 +498,26 @@ def test_dit_attention_fused_qknorm_self_cross(ops, envs, S, T, Lz):
     ops.attention(seg.view(envs, S * T, 4, heads, 64)[:, :, 3], kv2[:, :, 0], kv2[:, :, 1], head_gate=gate,
                   out=un.view(envs, S * T, heads, 64), accumulate=True)
     _close(out, un, atol=8e-3, rtol=1.0 / 128)
+
+
+@pytest.mark.parametrize("rms,C", [(True, 384), (False, 384), (True, 1024), (True, 96)])
+def test_norm_chained_prenorm(ops, rms, C):
+    """norm launch with a chained second norm on the produced residual row == the two separate launches it replaces."""
+    g = torch.Generator().manual_seed(C + int(rms))
+    rows, div = 300, 60
+    xin = _rand((rows, C), g)
+    base = torch.randn(rows, C, generator=g).to(_dev())
+    g1, g2 = [(1.0 + 0.1 * torch.randn(C, generator=g)).to(_dev()) for _ in range(2)]
+    mod = (0.3 * torch.randn(rows // div, 3 * C, generator=g)).to(_dev())
+    gate, ms2 = mod[:, :C], mod[:, 2 * C:]
+    x_a, h_a = torch.empty(rows, C, device=_dev()), torch.empty(rows, C, dtype=torch.bfloat16, device=_dev())
+    ops.norm(xin, g1, None, eps=1e-5, rms=rms, gate=gate, base=base, mod_div=div, out32=x_a, out2=h_a, gamma2=g2, mod_scale2=ms2)
+    x_b = torch.empty_like(x_a)
+    ops.norm(xin, g1, None, eps=1e-5, rms=rms, gate=gate, base=base, mod_div=div, out32=x_b)
+    h_b = ops.norm(x_b, g2, None, eps=1e-5, rms=rms, mod_scale=ms2, mod_div=div)
+    assert torch.equal(x_a, x_b)
+    _close(h_a, h_b, atol=1e-2, rtol=1.0 / 128)
+    # in place on the base buffer (how the DiT block uses it)
+    x_c = base.clone()
+    ops.norm(xin, g1, None, eps=1e-5, rms=rms, gate=gate, base=x_c, mod_div=div, out32=x_c, out2=h_a, gamma2=g2, mod_scale2=ms2)
+    assert torch.equal(x_c, x_b)
