@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--overlap-at", choices=["start", "decode"], default="decode",
                     help="n1_dual: side-stream System-1 starts with the System-2 micro-batch, or only once its prefill is done (decode phase)")
+    ap.add_argument("--priority", choices=["none", "decode", "s1"], default="none",
+                    help="n1_dual experiment: high-priority stream for the System-2 decode graph or for the side-stream System-1")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     return ap.parse_args()
 
@@ -192,7 +194,12 @@ class N1Dual:
             self.traj = torch.empty(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
             self.gA, self.gB, self.gP, self.gD = {}, {}, {}, {}
             self.overlap_at = a.overlap_at
-            self.ev = torch.cuda.Event()
+            self.ev, self.ev2 = torch.cuda.Event(), torch.cuda.Event()
+            # the decode / latent-query passes are chains of short kernels: on a high-priority stream their workgroups are dispatched
+            # ahead of the queued workgroups of the concurrent System-1 kernels instead of waiting behind them
+            self.hi = torch.cuda.Stream(device=dev, priority=-1) if getattr(a, "priority", "none") == "decode" else None
+            if getattr(a, "priority", "none") == "s1":
+                self.side = torch.cuda.Stream(device=dev, priority=-1)
 
     def _s2_call(self, m):
         s = self.s2[m]
@@ -275,7 +282,14 @@ class N1Dual:
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev)
                 trajA = self.gA[nA]()
-            self.gD[m]()
+            if self.hi is not None:
+                with torch.cuda.stream(self.hi):
+                    self.hi.wait_event(self.ev)
+                    self.gD[m]()
+                    self.ev2.record(self.hi)
+                main.wait_event(self.ev2)
+            else:
+                self.gD[m]()
         else:
             s["graph"]()
         self.latent_table[lo:lo + m].copy_(s["lat"])

@@ -135,6 +135,128 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     }
 }
 
+// Ping-pong variant (2 wave rows x WN wave columns, 2 stages): the two waves that share a SIMD (wave row 0 / 1 of the same wave
+// column) run the same [ds_read fragments | MFMA] sequence HALF A STEP APART - while one issues its 32 MFMAs the other fetches its
+// next fragments from LDS (different issue ports, so they overlap), and the roles swap at the next barrier. Time is cut into slots
+// separated by one s_barrier each; with s = 2*tile + kk:
+//     wave row 0:  slot 2s: R(s)  slot 2s+1: M(s)          wave row 1 (one extra barrier up front): slot 2s+1: R(s)  slot 2s+2: M(s)
+// LDS buffer of tile t is read in slots 4t .. 4t+3 and may be refilled from slot 4t+4 on: every wave issues its share of tile
+// t+1's DMA at the start of its R(2t) slot (4t / 4t+1; the buffer's last reader finished in slot 4t-1 and retired its reads with
+// lgkmcnt(0) before that slot's barrier) and retires it (vmcnt(0)) before the barrier that ends slot 4t+3, one slot before the
+// first read of tile t+1.
+template <int BM, int BN, int WN, bool STAGED, bool PRIO>
+__global__ __launch_bounds__(2 * WN * 64) void gemm_bf16_pp_kernel(GemmArgs p) {
+    constexpr int WM = 2, NS = 2;
+    using C = GldsCfg<BM, BN, WM, WN, NS>;
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    bf16* As = reinterpret_cast<bf16*>(smem_raw);          // [2][BM][64]
+    bf16* Bs = As + NS * BM * 64;                          // [2][BN][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // waves w and w + 4 land on the same SIMD (4 SIMDs, round robin): make them the two wave rows of one wave column
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    if (p.group_m > 1) {
+        const int gsz = p.group_m * tiles_n, grp = id / gsz, first = grp * p.group_m;
+        const int gm = min(tiles_m - first, p.group_m), in = id - grp * gsz;
+        tm = first + in % gm;
+        tn = in / gm;
+    } else {
+        tm = id / tiles_n;
+        tn = id % tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (size_t)blockIdx.y * p.strideA;
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (size_t)blockIdx.y * p.strideW;
+
+    const bf16* asrc[C::A_INST];
+    const bf16* bsrc[C::B_INST];
+    const int drow = lane >> 3, dcp = lane & 7;
+#pragma unroll
+    for (int s = 0; s < C::A_INST; ++s) {
+        const int row = (wave * C::A_INST + s) * 8 + drow;
+        asrc[s] = A + (size_t)min(m0 + row, p.M - 1) * p.lda + ((dcp ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int s = 0; s < C::B_INST; ++s) {
+        const int row = (wave * C::B_INST + s) * 8 + drow;
+        bsrc[s] = W + (size_t)min(n0 + row, p.N - 1) * p.ldw + ((dcp ^ (row & 7)) << 3);
+    }
+    auto stage = [&](int buf, int k0) {
+        bf16* as = As + buf * BM * 64 + wave * C::A_INST * 512;
+        bf16* bs = Bs + buf * BN * 64 + wave * C::B_INST * 512;
+#pragma unroll
+        for (int s = 0; s < C::A_INST; ++s) glds16(asrc[s] + k0, as + s * 512);
+#pragma unroll
+        for (int s = 0; s < C::B_INST; ++s) glds16(bsrc[s] + k0, bs + s * 512);
+    };
+
+    f32x4 acc[C::FM][C::FN];
+#pragma unroll
+    for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+    bf16x8 fa[C::FM], fb[C::FN];
+    auto read_frags = [&](int buf, int kk) {
+        const bf16* as = As + buf * BM * 64 + (wm * C::TM + frow) * 64;
+        const bf16* bs = Bs + buf * BN * 64 + (wn * C::TN + frow) * 64;
+        const int chunk = ((kk * 4 + g) ^ sw) << 3;
+#pragma unroll
+        for (int j = 0; j < C::FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 16 * 64 + chunk);
+#pragma unroll
+        for (int i = 0; i < C::FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(as + i * 16 * 64 + chunk);
+    };
+    auto mfmas = [&]() {
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    auto slot_end = [&]() {   // close a slot: nothing moves across, LDS reads of this slot have landed
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // tile 0 visible (slot -1)
+    if (wm == 1) __builtin_amdgcn_s_barrier();    // wave row 1 runs one slot behind
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        // R(kk = 0) slot: request tile t+1 into the other buffer, fetch the first fragment set
+        if (t + 1 < nk) stage(buf ^ 1, (t + 1) * 64);
+        read_frags(buf, 0);
+        slot_end();
+        mfmas();                                  // M(kk = 0) slot
+        slot_end();
+        read_frags(buf, 1);                       // R(kk = 1) slot
+        if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 1: this barrier ends slot 4t+3
+        slot_end();
+        mfmas();                                  // M(kk = 1) slot
+        if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // row 0: this barrier ends slot 4t+3
+        slot_end();
+        buf ^= 1;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();    // matching count for the extra barrier of row 1
+    if constexpr (STAGED) {
+        __syncthreads();
+        constexpr bool ALL = C::LDS_BYTES >= size_t(C::NW) * C::FM * 4096;
+        float* scratch = reinterpret_cast<float*>(smem_raw) + wave * (ALL ? C::FM * 1024 : 1024);
+        gemm_store_tile_staged<C::FM, C::FN, C::TM, C::TN, ALL>(p, acc, m0, n0, wm, wn, lane, scratch);
+    } else {
+        gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_glds(const GemmArgs& p, hipStream_t stream) {
     using C = GldsCfg<BM, BN, WM, WN, NS>;
@@ -163,6 +285,30 @@ int launch_glds(const GemmArgs& p, hipStream_t stream) {
     return 0;
 }
 
+template <int BM, int BN, int WN, bool PRIO = false>
+int launch_pp(const GemmArgs& p, hipStream_t stream) {
+    using C = GldsCfg<BM, BN, 2, WN, 2>;
+    const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
+    const bool staged = C::TN == 64 && ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
+                        (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) &&
+                        ((p.glu ? p.N / 2 : p.N) % 4 == 0);
+    static bool attr_done[2] = {false, false};
+    auto kern = staged ? gemm_bf16_pp_kernel<BM, BN, WN, true, PRIO> : gemm_bf16_pp_kernel<BM, BN, WN, false, PRIO>;
+    if (!attr_done[staged]) {
+        INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_done[staged] = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    GemmArgs q = p;
+    if (q.group_m == 0) q.group_m = ((p.N + BN - 1) / BN >= 24 && (p.M + BM - 1) / BM >= 8) ? 8 : 1;
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
+    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
+                      (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, q);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 // cfg 11: 128x128 / 4 waves / 2 stages, cfg 12: 256x128 / 8 waves / 2 stages, cfg 13: 128x256 / 8 waves / 2 stages,
@@ -177,6 +323,9 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 15: return launch_glds<128, 128, 2, 2, 3>(p, stream);
         case 16: return launch_glds<128, 256, 2, 4, 3>(p, stream);
         case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
+        case 18: return launch_pp<256, 256, 4>(p, stream);           // 256x256, wave tile 128x64, ping-pong wave rows
+        case 19: return launch_pp<128, 256, 4>(p, stream);           // 128x256, wave tile 64x64, ping-pong wave rows
+        case 20: return launch_pp<256, 256, 4, true>(p, stream);     // cfg 18 + s_setprio(1) around the MFMA slots
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }
 }

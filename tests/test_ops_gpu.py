@@ -367,7 +367,7 @@ def test_bad_arguments_fail_loudly(ops):
         ops.attention(q, q, q)
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("M,N,K", [(300, 260, 320), (1000, 1280, 3456), (257, 4608, 3584), (130, 132, 64)])
 def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     """LDS-DMA staged kernels: ragged M/N edges (clamped rows), swizzled LDS, every epilogue term."""
@@ -380,7 +380,7 @@ def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     _close(out, ref, rtol=2e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (17, 5), (17, 0)])
+@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (17, 5), (17, 0), (18, 8), (19, 3)])
 def test_gemm_glds_grouped_tile_order(ops, cfg, group_m):
     """Grouped tile order (group_m row-tiles per group, ragged last group, auto rule at 0) is a pure re-ordering: same result as
     row-major, bit for bit, and equal to the fp32 reference."""

@@ -1,21 +1,22 @@
-"""Per-phase timing of one n1_dual bench step on the GPU box: S2 graph (6/7 envs), S1 graph (64 envs), D2H + host post-processing."""
+"""Per-phase timing of one n1_dual bench step on the GPU box: System-2 prefill / decode graphs (6/7 envs), System-1 graphs
+(64 / 57 / 7 envs), the decode || System-1 overlap, D2H + host post-processing."""
 import sys, time
 from pathlib import Path
 from types import SimpleNamespace
 
-import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench  # noqa: E402
 
-a = SimpleNamespace(envs=64)
+a = SimpleNamespace(envs=64, no_overlap=False, no_graph=False, overlap_at="decode")
 dev = torch.device("cuda:0")
 wl = bench.N1Dual(a, dev, 0)
 wl.capture()
 
 
 def t(fn, n=5):
+    fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n):
         fn()
@@ -23,8 +24,38 @@ def t(fn, n=5):
 
 
 for m, s in wl.s2.items():
-    print(f"S2 graph, {m} envs: {t(s['graph']):.1f} ms")
+    print(f"S2 whole graph, {m} envs: {t(s['graph']):.1f} ms   prefill graph {t(wl.gP[m]):.1f} ms   decode+latents graph {t(wl.gD[m]):.1f} ms")
 print(f"S1 graph, 64 envs: {t(wl.s1_graph):.1f} ms")
+for nA, g in wl.gA.items():
+    print(f"S1 graph, {nA} envs: {t(g):.1f} ms")
+for m, g in wl.gB.items():
+    print(f"S1 graph (small engine), {m} envs: {t(g):.1f} ms")
+m = max(wl.mb)
+nA = 64 - m
+
+
+def both():
+    wl.side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(wl.side):
+        wl.gA[nA]()
+    wl.gD[m]()
+    torch.cuda.current_stream().wait_stream(wl.side)
+
+
+print(f"decode+latents ({m} envs) || S1 ({nA} envs): {t(both):.1f} ms")
+
+
+def both3():
+    wl.side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(wl.side):
+        wl.gA[nA]()
+    wl.gD[m]()
+    wl.gB[m]()
+    torch.cuda.current_stream().wait_stream(wl.side)
+
+
+print(f"(decode+latents, S1 small) || S1 ({nA} envs): {t(both3):.1f} ms")
+print(f"full step (bench schedule): {t(lambda: wl.step(0)):.1f} ms")
 traj = wl.s1_graph()
 torch.cuda.synchronize()
 t0 = time.perf_counter(); tc = traj.cpu(); t1 = time.perf_counter()
