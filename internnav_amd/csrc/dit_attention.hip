@@ -14,7 +14,9 @@
 //     slice is transposed into its private LDS tile meanwhile;
 //   * phase B: Q / K MFMA fragments are loaded straight from global (L2 hits: phase A just read the rows) and normalised in
 //     registers; S^T = K . Q^T and O^T = V^T . P^T in the swapped-operand form of attention.hip (P never leaves its lane);
-//   * the condition V is consumed from a pre-transposed, key-permuted image V2T[env][head][64][64] built once per call.
+//   * the condition V is consumed from a pre-transposed, key-permuted image V2T[env][head][64][64] built once per call;
+//   * the kernel is latency-bound (few MFMAs per byte), so every load is hoisted: condition K / V fragments first, then all
+//     statistics-pass rows and the V1 slice in one batch, then all phase-B q / k slices in one batch.
 #include "common.h"
 #include "kernels.h"
 
@@ -27,11 +29,8 @@ __device__ __forceinline__ int dit_vt_pos(int kv_local) {
     return (sub << 5) + ((x >> 2) << 3) + (x & 3) + (t << 2);
 }
 
-// 8 consecutive bf16 of a row, LayerNorm-ed with the row's (mean, rstd) and the affine parameters of those 8 columns
-__device__ __forceinline__ bf16x8 ln_load8(const bf16* ptr, float mean, float rstd, const float* __restrict__ gam, const float* __restrict__ bet) {
-    const bf16x8 x = *reinterpret_cast<const bf16x8*>(ptr);
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gam), g1 = *reinterpret_cast<const f32x4*>(gam + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bet), b1 = *reinterpret_cast<const f32x4*>(bet + 4);
+// raw 8-element slice + LayerNorm with the row's (mean, rstd) and the 8 affine parameters of those columns
+__device__ __forceinline__ bf16x8 ln_apply8(bf16x8 x, float mean, float rstd, const f32x4& g0, const f32x4& g1, const f32x4& b0, const f32x4& b1) {
     bf16x8 y;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -42,9 +41,10 @@ __device__ __forceinline__ bf16x8 ln_load8(const bf16* ptr, float mean, float rs
 }
 
 template <int NH>
-__global__ __launch_bounds__(NH * 64) void dit_attn_kernel(DitAttnArgs p) {
+__global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
     constexpr int HD = 64, D = NH * HD, VT_LD = 40, CPL = NH / 2;   // CPL: 16-byte chunks per lane in the statistics pass
-    static_assert(NH % 2 == 0, "statistics pass covers a D-wide row with 16 lanes x NH/2 chunks");
+    static_assert(NH % 2 == 0 && 96 % (NH * 4) == 0, "statistics pass: 16 lanes x NH/2 chunks per row, 4 rows per wave pass");
+    constexpr int NPASS = 96 / (NH * 4);
     __shared__ float stats[3][32][2];
     __shared__ __attribute__((aligned(16))) bf16 Vt[NH][HD * VT_LD];
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -53,80 +53,130 @@ __global__ __launch_bounds__(NH * 64) void dit_attn_kernel(DitAttnArgs p) {
     const int T = p.T;
     const bf16* __restrict__ base = reinterpret_cast<const bf16*>(p.X) + (size_t)seq * T * p.ldx;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16* __restrict__ K2 = reinterpret_cast<const bf16*>(p.K2) + (size_t)env * p.k2_bs + h * HD;
+    const bf16* __restrict__ V2T = reinterpret_cast<const bf16*>(p.V2T) + ((size_t)env * NH + h) * HD * 64;
 
-    // ---- phase A: LayerNorm statistics of the q1 / k1 / q2 segment of every token (row r = s*32 + token, 4 rows per wave pass)
-    for (int r = h * 4 + g; r < 96; r += NH * 4) {
-        const int s = r >> 5, tok = r & 31, seg = s == 2 ? 3 : s;
-        float x[CPL * 8];
-        float sum = 0.f;
-        if (tok < T) {
-            const bf16* row = base + (size_t)tok * p.ldx + seg * D;
+    // ---- condition K / V fragments of this head: independent of everything else, requested first (L2 hits: shared by the env's
+    //      samples) so their latency hides under the statistics pass
+    bf16x8 k2f[4][2], v2f[2][4];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + (c * 16 + lq) * 8);
+    for (int t = 0; t < 4; ++t) {
+        const int key = t * 16 + lq;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { x[c * 8 + i] = (float)v[i]; sum += x[c * 8 + i]; }
-            }
-        } else {
+        for (int kk = 0; kk < 2; ++kk)
+            k2f[t][kk] = key < p.Lz ? *reinterpret_cast<const bf16x8*>(K2 + (size_t)key * p.k2_rs + g * 8 + kk * 32) : zero8;
+    }
 #pragma unroll
-            for (int i = 0; i < CPL * 8; ++i) x[i] = 0.f;
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) v2f[sb][nt] = *reinterpret_cast<const bf16x8*>(V2T + (size_t)(nt * 16 + lq) * 64 + sb * 32 + g * 8);
+
+    // ---- phase A: LayerNorm statistics of the q1 / k1 / q2 segment of every token (row r = s*32 + token, 4 rows per wave pass);
+    //      all passes' loads are issued before the first reduction
+    {
+        bf16x8 raw[NPASS][CPL];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * NH * 4 + h * 4 + g;
+            const int s = r >> 5, tok = r & 31, seg = s == 2 ? 3 : s;
+            const bf16* row = base + (size_t)(tok < T ? tok : 0) * p.ldx + seg * D;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) raw[ps][c] = *reinterpret_cast<const bf16x8*>(row + (c * 16 + lq) * 8);
+        }
+        // this wave's V1 head slice [32 keys x 64] -> transposed, key-permuted LDS tile
+        // (lane -> 8-column chunk c = lane & 7 of key rows {2m, 2m+1, 16+2m, 16+2m+1}, m = lane >> 3: neighbouring keys land on
+        //  neighbouring slots of the permuted image, so two keys go out per 32-bit LDS store)
+        bf16x8 vraw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i >> 1) * 16 + (lane >> 3) * 2 + (i & 1);
+            vraw[i] = row < T ? *reinterpret_cast<const bf16x8*>(base + (size_t)row * p.ldx + 2 * D + h * HD + (lane & 7) * 8) : zero8;
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float mean = sum * (1.0f / D);
-        float var = 0.f;
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = ps * NH * 4 + h * 4 + g;
+            float x[CPL * 8];
+            float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < CPL * 8; ++i) { const float d = x[i] - mean; var += d * d; }
+            for (int c = 0; c < CPL; ++c)
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
-        if (lq == 0) { stats[s][tok][0] = mean; stats[s][tok][1] = rsqrtf(var * (1.0f / D) + p.eps); }
-    }
-    // ---- this wave's V1 head slice [32 keys x 64] -> transposed, key-permuted LDS tile
-    {
+                for (int i = 0; i < 8; ++i) { x[c * 8 + i] = (float)raw[ps][c][i]; sum += x[c * 8 + i]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.0f / D);
+            float var = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL * 8; ++i) { const float d = x[i] - mean; var += d * d; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
+            if (lq == 0) { stats[r >> 5][r & 31][0] = mean; stats[r >> 5][r & 31][1] = rsqrtf(var * (1.0f / D) + p.eps); }
+        }
+        // image row d keeps its four 8-slot groups rotated by d >> 3 (the chunk index c): the 8 chunk lanes of a store then hit 8
+        // different bank groups instead of one
         bf16* vt = Vt[h];
         const int c = lane & 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = i * 8 + (lane >> 3);
-            const bf16x8 v = row < T ? *reinterpret_cast<const bf16x8*>(base + (size_t)row * p.ldx + 2 * D + h * HD + c * 8) : zero8;
-            const int pos = dit_vt_pos(row);
+        for (int i = 0; i < 2; ++i) {
+            const int pos = (dit_vt_pos(i * 16 + (lane >> 3) * 2) + 8 * c) & 31;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vt[(c * 8 + e) * VT_LD + pos] = v[e];
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<bf16x2*>(&vt[(c * 8 + e) * VT_LD + pos]) = bf16x2{vraw[2 * i][e], vraw[2 * i + 1][e]};
         }
     }
     __syncthreads();
 
     const float sc = p.scale * 1.4426950408889634f;   // exp2 domain
     const float gate = p.head_gate ? tanhf(p.head_gate[h]) : 1.0f;
-    const bf16* __restrict__ K2 = reinterpret_cast<const bf16*>(p.K2) + (size_t)env * p.k2_bs + h * HD;
-    const bf16* __restrict__ V2T = reinterpret_cast<const bf16*>(p.V2T) + ((size_t)env * NH + h) * HD * 64;
     bf16* __restrict__ O = reinterpret_cast<bf16*>(p.O) + (size_t)seq * T * p.ldo + h * HD;
     const int dcol = h * HD + g * 8;                     // first of this lane's 8 columns inside a 32-wide k step (+ kk*32)
 
-#pragma unroll 1
+    // ---- phase B loads (L2 hits: phase A just read these rows): raw q1 / q2 of both query tiles, raw k1 of both key tiles
+    bf16x8 q1r[2][2], q2r[2][2], k1r[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int tok = qt * 16 + lq;
+        const bf16* row = base + (size_t)(tok < T ? tok : 0) * p.ldx + dcol;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            q1r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + kk * 32);
+            k1r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + D + kk * 32);
+            q2r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + 3 * D + kk * 32);
+        }
+    }
+    // normalised K1 fragments (keys t*16 + lq)
+    bf16x8 k1f[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_k1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_k1 + dcol + kk * 32 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_k1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_k1 + dcol + kk * 32 + 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = t * 16 + lq;
+            k1f[t][kk] = key < T ? ln_apply8(k1r[t][kk], stats[1][key][0], stats[1][key][1], g0, g1, b0, b1) : zero8;
+        }
+    }
+
+#pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int tok = qt * 16 + lq;
         if (qt * 16 >= T) break;
         const bool qok = tok < T;
-        const bf16* qrow = base + (size_t)(qok ? tok : 0) * p.ldx;
         // ================= self-attention over the sequence's own tokens
         f32x4 o1[4];
         {
             bf16x8 qf[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                qf[kk] = qok ? ln_load8(qrow + dcol + kk * 32, stats[0][tok][0], stats[0][tok][1], p.g_q1 + dcol + kk * 32, p.b_q1 + dcol + kk * 32) : zero8;
+            for (int kk = 0; kk < 2; ++kk) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32 + 4);
+                qf[kk] = qok ? ln_apply8(q1r[qt][kk], stats[0][tok][0], stats[0][tok][1], g0, g1, b0, b1) : zero8;
+            }
             f32x4 s[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int key = t * 16 + lq;
                 s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = key < T ? ln_load8(base + (size_t)key * p.ldx + D + dcol + kk * 32, stats[1][key][0], stats[1][key][1],
-                                                         p.g_k1 + dcol + kk * 32, p.b_k1 + dcol + kk * 32) : zero8;
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
-                }
+                for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f[t][kk], qf[kk], s[t], 0, 0, 0);
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -155,7 +205,8 @@ __global__ __launch_bounds__(NH * 64) void dit_attn_kernel(DitAttnArgs p) {
             const float inv_l = 1.0f / l;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[h][(nt * 16 + lq) * VT_LD + g * 8]);
+                const int d = nt * 16 + lq;
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[h][d * VT_LD + ((g + (d >> 3)) & 3) * 8]);
                 o1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o1[nt][r] = (float)(bf16)(o1[nt][r] * inv_l);   // the unfused path stores bf16 here
@@ -165,18 +216,17 @@ __global__ __launch_bounds__(NH * 64) void dit_attn_kernel(DitAttnArgs p) {
         {
             bf16x8 qf[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                qf[kk] = qok ? ln_load8(qrow + 3 * D + dcol + kk * 32, stats[2][tok][0], stats[2][tok][1], p.g_q2 + dcol + kk * 32, p.b_q2 + dcol + kk * 32) : zero8;
+            for (int kk = 0; kk < 2; ++kk) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32 + 4);
+                qf[kk] = qok ? ln_apply8(q2r[qt][kk], stats[2][tok][0], stats[2][tok][1], g0, g1, b0, b1) : zero8;
+            }
             f32x4 s[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int key = t * 16 + lq;
                 s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const bf16x8 kf = key < p.Lz ? *reinterpret_cast<const bf16x8*>(K2 + (size_t)key * p.k2_rs + g * 8 + kk * 32) : zero8;
-                    s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
-                }
+                for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k2f[t][kk], qf[kk], s[t], 0, 0, 0);
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -214,10 +264,7 @@ __global__ __launch_bounds__(NH * 64) void dit_attn_kernel(DitAttnArgs p) {
                     pf[4 + r] = (bf16)s[2 * sb + 1][r];
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(V2T + (size_t)(nt * 16 + lq) * 64 + sb * 32 + g * 8);
-                    o2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o2[nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < 4; ++nt) o2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2f[sb][nt], pf, o2[nt], 0, 0, 0);
             }
             if (qok) {
 #pragma unroll

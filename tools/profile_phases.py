@@ -9,7 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench  # noqa: E402
 
 which, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3
-wl = bench.N1Dual(SimpleNamespace(envs=64), torch.device("cuda:0"), 0)
+wl = bench.N1Dual(SimpleNamespace(envs=64, no_overlap=True, no_graph=True), torch.device("cuda:0"), 0)
 m = max(wl.mb)
 wl.s2[m]["pv"].copy_(wl.pixel_values[:m].reshape(-1, 1176))
 for _ in range(n):
