@@ -16,6 +16,9 @@
 
 namespace {
 
+// V^T LDS image: row d holds the block's keys in the slot order vt_pos(key), with its 8-slot groups ROTATED by d >> 3 (mod KVB/8).
+// The transposing 2-byte stores of one wave instruction go to rows d = c*8 + i for 8-16 different chunks c: without the rotation
+// all of them fall on the same bank (row stride x 8 = 0 mod 32 dwords), a 16-way conflict on every store.
 __device__ __forceinline__ int vt_pos(int kv_local) {
     // key permutation inside each 32-key sub-block: MFMA k index g*8 + j  <->  key (j<4 ? g*4+j : 16+g*4+(j-4))
     int sub = kv_local >> 5, w = kv_local & 31;
@@ -78,24 +81,42 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     }
     const int kv_begin = (p.kv_start / KVB) * KVB;
 
+    // K / V blocks travel global -> registers -> LDS; the registers of block i+1 are requested right after block i is published,
+    // so the global latency runs under the MFMAs of block i
+    constexpr int NKI = (KVB * KCPR + NT - 1) / NT, NVI = (KVB * VCPR + NT - 1) / NT;
+    bf16x8 kreg[NKI], vreg[NVI];
+    auto fetch = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NKI; ++u) {
+            const int q = tid + u * NT, row = q / KCPR, c = q % KCPR, kv = kv0 + row;
+            kreg[u] = (q < KVB * KCPR && kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = tid + u * NT, row = q / VCPR, c = q % VCPR, kv = kv0 + row;
+            vreg[u] = (q < KVB * VCPR && kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
+        }
+    };
+    if (kv_begin < kv_end) fetch(kv_begin);
     for (int kv0 = kv_begin; kv0 < kv_end; kv0 += KVB) {
         __syncthreads();
-        // ---- stage K block (row-major, zero padded) and V block (transposed + permuted) into LDS
-        for (int q = tid; q < KVB * KCPR; q += NT) {
-            int row = q / KCPR, c = q % KCPR;
-            int kv = kv0 + row;
-            bf16x8 v = (kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
-            *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = v;
-        }
-        for (int q = tid; q < KVB * VCPR; q += NT) {
-            int row = q / VCPR, c = q % VCPR;
-            int kv = kv0 + row;
-            bf16x8 v = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
-            int pos = vt_pos(row);
+        // ---- publish K block (row-major, zero padded) and V block (transposed + permuted) in LDS
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + pos] = v[i];
+        for (int u = 0; u < NKI; ++u) {
+            const int q = tid + u * NT, row = q / KCPR, c = q % KCPR;
+            if (q < KVB * KCPR) *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = tid + u * NT, row = q / VCPR, c = q % VCPR;
+            if (q < KVB * VCPR) {
+                const int pos = vt_pos(row);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + ((pos + 8 * c) & (KVB - 1))] = vreg[u][i];   // rotated rows: see vt_pos
+            }
         }
         __syncthreads();
+        if (kv0 + KVB < kv_end) fetch(kv0 + KVB);
 
         // ---- S^T = K . Q^T
         f32x4 s[NST];
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
             }
 #pragma unroll
             for (int nt = 0; nt < NDT; ++nt) {
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + sb * 32 + g * 8]);
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + ((sb * 32 + g * 8 + 8 * ((nt * 16 + lq) >> 3)) & (KVB - 1))]);
                 acc_o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc_o[nt], 0, 0, 0);
             }
         }
@@ -231,7 +252,7 @@ __global__ __launch_bounds__(64) void attn_decode_split_kernel(AttnArgs p, float
             bf16x8 v = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
             int pos = vt_pos(row);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + pos] = v[i];
+            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + ((pos + 8 * c) & (KVB - 1))] = v[i];   // rotated rows: see vt_pos
         }
         __syncthreads();
         f32x4 s[NST];
@@ -283,7 +304,7 @@ __global__ __launch_bounds__(64) void attn_decode_split_kernel(AttnArgs p, float
             }
 #pragma unroll
             for (int nt = 0; nt < NDT; ++nt) {
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + sb * 32 + g * 8]);
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + ((sb * 32 + g * 8 + 8 * ((nt * 16 + lq) >> 3)) & (KVB - 1))]);
                 acc_o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc_o[nt], 0, 0, 0);
             }
         }
