@@ -192,6 +192,9 @@ class N1Dual:
             self.idxA = [torch.tensor([e for e in range(B) if not (int(self.mb_start[j]) <= e < int(self.mb_start[j]) + self.mb[j])],
                                       device=dev) for j in range(self.CADENCE)]
             self.traj = torch.empty(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
+            self.hostA = torch.empty(nA, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
+            self.hostB = torch.empty(mmax, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
+            self.idxA_host = [t.tolist() for t in self.idxA]
             self.gA, self.gB, self.gP, self.gD = {}, {}, {}, {}
             self.overlap_at = a.overlap_at
             self.ev, self.ev2 = torch.cuda.Event(), torch.cuda.Event()
@@ -297,10 +300,26 @@ class N1Dual:
         self.imgB[:m].copy_(self.images_dp[lo:lo + m])
         self.xB[:m].copy_(self.x_init[lo:lo + m])
         trajB = self.gB[m]()
-        main.wait_stream(self.side)
-        self.traj.index_copy_(0, idx, trajA)
-        self.traj[lo:lo + m].copy_(trajB)
-        return self._finish(self.traj)
+        # host post-processing (vln_utils.traj_to_actions, as the reference does per env) of the side-stream envs runs while the main
+        # stream is still busy with the System-2 decode passes and the System-1 call of the System-2 envs
+        acts = np.zeros((self.B, 4), dtype=np.int32)
+        with torch.cuda.stream(self.side):
+            self.hostA[:nA].copy_(trajA, non_blocking=True)
+        self.side.synchronize()
+        for k, b in enumerate(self.idxA_host[j]):
+            al = [x for x in self.traj_to_actions(self.hostA[k]) if x != 0][:4]
+            acts[b, :len(al)] = al
+        self.hostB[:m].copy_(trajB, non_blocking=True)
+        main.synchronize()
+        for k in range(m):
+            al = [x for x in self.traj_to_actions(self.hostB[k]) if x != 0][:4]
+            acts[lo + k, :len(al)] = al
+        if getattr(self, "freeze_noise", False):   # schedule check: keep the assembled trajectories
+            self.traj.index_copy_(0, idx, trajA)
+            self.traj[lo:lo + m].copy_(trajB)
+            self.last_traj = self.traj
+        self.actions.copy_(torch.from_numpy(acts))
+        return self.actions
 
     def step(self, i):
         if self.overlap:

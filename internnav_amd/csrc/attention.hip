@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     if (p.cu_q) { q_off = p.cu_q[b]; len_q = p.cu_q[b + 1] - q_off; }
     if (p.cu_k) { k_off = p.cu_k[kb]; len_k = p.cu_k[kb + 1] - k_off; }
     else if (p.k_len) len_k = min(p.k_len[kb], p.Lk);
-    const int qt0 = blockIdx.x * (NW * 16);
+    const int qt0 = (p.causal ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * (NW * 16);   // causal: longest query tiles first
     if (qt0 >= len_q) return;
 
     const bf16* __restrict__ Q = reinterpret_cast<const bf16*>(p.Q) + (size_t)b * p.q_bs + (size_t)q_off * p.q_rs + (size_t)h * p.q_hs;
