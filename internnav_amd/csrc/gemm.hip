@@ -179,7 +179,11 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
     INA_REQUIRE(!p.glu || (p.N % 32 == 0), "gemm: GLU mode needs N %% 32 == 0");
     // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
     // skinny M: HBM-bound weight streaming with split-K (gemm_skinny.hip) instead of an under-filled tile grid
-    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) return ina_launch_gemm_skinny(p, stream);
+    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) return ina_launch_gemm_skinny_fused(p, stream);
+    if (p.force_cfg == 31 || p.force_cfg == 32) {
+        INA_REQUIRE(p.M <= 64 && p.batch == 1, "gemm: skinny kernels need M <= 64, batch 1 (M=%d)", p.M);
+        return p.force_cfg == 31 ? ina_launch_gemm_skinny(p, stream) : ina_launch_gemm_skinny_fused(p, stream);
+    }
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     int cfg = p.force_cfg;
     if (cfg <= 0) {

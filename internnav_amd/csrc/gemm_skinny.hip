@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, float* __r
     auto load_w = [&](int k0, bf16x8 (&wf)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = k0 + g * 32 + s * 8;   // lane group g owns k in [k0 + g*32, k0 + g*32 + 32): 4 MFMA k-steps of 8 elements
+            const int k = k0 + s * 32 + g * 8;   // load s: the 4 lane groups of a row cover 64 contiguous bytes (natural MFMA k order)
             wf[s] = (wok && k < k_end) ? *reinterpret_cast<const bf16x8*>(wrow + k) : zero8;
         }
     };
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, float* __r
             const bf16* arow = A + (size_t)(m < p.M ? m : 0) * p.lda;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int k = k0 + g * 32 + s * 8;
+                const int k = k0 + s * 32 + g * 8;
                 af[i][s] = (m < p.M && k < k_end) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8;
             }
         }
@@ -146,7 +146,180 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue(GemmArgs p, const fl
     }
 }
 
+// ---- column-owner variant: a group of NW waves owns NT16 x 16 output columns for ALL of K (a workgroup holds NC such groups); the
+// group's waves take interleaved 128-wide K steps, keep a DEPTH-deep register ring of loads in flight, reduce their accumulators
+// through LDS (NW > 1) and apply the epilogue in the same kernel: no partial workspace, no second launch (a decode pass of the
+// 28-layer LLM is 4 such GEMMs per layer: the separate epilogue launches were ~0.8 ms of every pass). NW is chosen per shape so
+// the launch has a few thousand waves: 1 for the 152064-row lm_head (long-lived independent waves), 8 for a 3584-row projection.
+template <int MF, int NT16, int NW, int NC, int DEPTH>
+__global__ __launch_bounds__(NW * NC * 64) void gemm_skinny_fused_kernel(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[NW > 1 ? NC : 1][NW > 1 ? NW : 1][NT16][MF][64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = wave / NW, w = wave % NW;
+    const int n0 = (blockIdx.x * NC + grp) * (16 * NT16);
+    const int r16 = lane & 15, g = lane >> 4;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A);
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W);
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16* wrow[NT16];
+    bool wok[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        const int wn = n0 + t * 16 + r16;
+        wok[t] = wn < p.N;
+        wrow[t] = W + (size_t)(wok[t] ? wn : 0) * p.ldw;
+    }
+    const bf16* arow[MF];
+    bool aok[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = i * 16 + r16;
+        aok[i] = m < p.M;
+        arow[i] = A + (size_t)(aok[i] ? m : 0) * p.lda;
+    }
+    f32x4 acc[NT16][MF];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ksteps = (p.K + SK_BK - 1) / SK_BK;
+    const int nmine = w < ksteps ? (ksteps - w + NW - 1) / NW : 0;   // K steps w, w + NW, ...
+    bf16x8 wf[DEPTH][NT16][4], af[DEPTH][MF][4];
+    auto load = [&](int j, int slot) {
+        const int k0 = (w + j * NW) * SK_BK + g * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + s * 32;   // load s: the 4 lane groups of a row cover 64 contiguous bytes
+            const bool kok = j < nmine && k < p.K;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) wf[slot][t][s] = (kok && wok[t]) ? *reinterpret_cast<const bf16x8*>(wrow[t] + k) : zero8;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[slot][i][s] = (kok && aok[i]) ? *reinterpret_cast<const bf16x8*>(arow[i] + k) : zero8;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load(d, d);
+    for (int j0 = 0; j0 < nmine; j0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {      // static ring slots
+#pragma unroll
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[d][t][s], af[d][i][s], acc[t][i], 0, 0, 0);
+            load(j0 + d + DEPTH, d);
+        }
+    }
+    // ---- cross-wave reduction (NW > 1) + epilogue: wave w of a group owns row fragments w, w + NW, ... of every column tile
+    if constexpr (NW > 1) {
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int i = 0; i < MF; ++i) *reinterpret_cast<f32x4*>(&red[grp][w][t][i][lane * 4]) = acc[t][i];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        if (NW > 1 && (i % NW) != w) continue;
+        const int m = i * 16 + r16;
+        f32x4 sum[NT16];
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            if constexpr (NW > 1) {
+                sum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(&red[grp][ww][t][i][lane * 4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sum[t][r] += v[r];
+                }
+            } else {
+                sum[t] = acc[t][i];
+            }
+        }
+        const int n = n0 + g * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const float rs = p.rowscale ? p.rowscale[m / p.rowscale_div] : 1.0f;
+        float v[4];
+        int no = n;
+        if constexpr (NT16 == 2) {
+            // GLU: tile 0 = gate rows, tile 1 = up rows of the interleaved weight; output column block = pair index
+            no = (n0 >> 1) + g * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float gg = sum[0][r], uu = sum[1][r];
+                if (p.bias) { gg += p.bias[n + r]; uu += p.bias[n + 16 + r]; }
+                v[r] = ina_act(gg, p.act) * uu * rs;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = sum[0][r];
+                if (p.bias) x += p.bias[n + r];
+                x = ina_act(x, p.act);
+                if (p.colscale) x *= p.colscale[n + r];
+                v[r] = x * rs;
+            }
+            if (p.R) {
+                const size_t ro = (size_t)m * p.ldr + n;
+                if (p.res_dtype == INA_DT_BF16) {
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.R) + ro);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                } else {
+                    const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                }
+            }
+        }
+        const size_t co = (size_t)m * p.ldc + no;
+        if (p.out_dtype == INA_DT_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+template <int MF, int NT16>
+void launch_skinny_fused(const GemmArgs& p, hipStream_t stream) {
+    const int ksteps = (p.K + SK_BK - 1) / SK_BK;
+    const int tiles = (p.N + 16 * NT16 - 1) / (16 * NT16);
+    constexpr int DEEP = (MF * NT16 <= 2) ? 4 : 2;
+    int nw = tiles >= 2048 ? 1 : tiles >= 1024 ? 2 : tiles >= 512 ? 4 : 8;
+    while (nw > 1 && nw > ksteps) nw >>= 1;
+#define INA_SKF(NW_, NC_, D_) hipLaunchKernelGGL((gemm_skinny_fused_kernel<MF, NT16, NW_, NC_, D_>), dim3((tiles + NC_ - 1) / NC_), dim3(NW_ * NC_ * 64), 0, stream, p)
+    if (nw == 1) INA_SKF(1, 4, 2);
+    else if (nw == 2) INA_SKF(2, 2, 2);
+    else if (nw == 4) INA_SKF(4, 1, DEEP);
+    else INA_SKF(8, 1, DEEP);
+#undef INA_SKF
+}
+
 }  // namespace
+
+int ina_launch_gemm_skinny_fused(const GemmArgs& p, hipStream_t stream) {
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
+    InaProfScope prof(INA_PROF_GEMM_SKINNY, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
+    const int mf = (p.M + 15) / 16;
+    if (p.glu) {
+        switch (mf) {
+            case 1: launch_skinny_fused<1, 2>(p, stream); break;
+            case 2: launch_skinny_fused<2, 2>(p, stream); break;
+            case 3: launch_skinny_fused<3, 2>(p, stream); break;
+            default: launch_skinny_fused<4, 2>(p, stream); break;
+        }
+    } else {
+        switch (mf) {
+            case 1: launch_skinny_fused<1, 1>(p, stream); break;
+            case 2: launch_skinny_fused<2, 1>(p, stream); break;
+            case 3: launch_skinny_fused<3, 1>(p, stream); break;
+            default: launch_skinny_fused<4, 1>(p, stream); break;
+        }
+    }
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     const int tiles = (p.N + SK_BN - 1) / SK_BN;

@@ -26,6 +26,7 @@ using DitAttnArgs = ina_dit_attn_args;
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
 int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming split-K path
+int ina_launch_gemm_skinny_fused(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming, workgroup owns its columns for all K, fused epilogue
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
 int ina_launch_norm(const NormArgs& p, hipStream_t stream);
 int ina_launch_patchify(const PatchifyArgs& p, hipStream_t stream);

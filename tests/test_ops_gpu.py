@@ -396,29 +396,32 @@ def test_gemm_glds_grouped_tile_order(ops, cfg, group_m):
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]
 
 
+@pytest.mark.parametrize("cfg", [0, 31, 32])
 @pytest.mark.parametrize("M,N,K", SKINNY)
-def test_gemm_skinny_split_k(ops, M, N, K):
-    """M <= 64 goes through the weight-streaming split-K kernel (+ epilogue kernel): all epilogue terms, bf16 and f32 outputs."""
+def test_gemm_skinny_split_k(ops, M, N, K, cfg):
+    """M <= 64 goes through the weight-streaming kernels (0 = auto = 32: column-owner kernel with fused epilogue; 31: split-K
+    partials + epilogue kernel): all epilogue terms, bf16 and f32 outputs."""
     g = torch.Generator().manual_seed(M + N + K)
     x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
     bias, cs = torch.randn(N, generator=g).to(_dev()), torch.randn(N, generator=g).to(_dev())
     res = torch.randn(M, N, generator=g).to(_dev())
     ref = torch.nn.functional.gelu(x.float() @ w.float().t() + bias) * cs + res
-    out = ops.linear(x, w, bias=bias, act="gelu", colscale=cs, residual=res, out_dtype=torch.float32)
+    out = ops.linear(x, w, bias=bias, act="gelu", colscale=cs, residual=res, out_dtype=torch.float32, force_cfg=cfg)
     _close(out, ref, rtol=2e-3, atol=5e-3)
-    out_b = ops.linear(x, w, bias=bias)
+    out_b = ops.linear(x, w, bias=bias, force_cfg=cfg)
     _close(out_b, x.float() @ w.float().t() + bias)
     same = ops.linear(x, w, bias=bias, force_cfg=3 if N >= 128 else 4)  # tiled kernel on the same problem
     _close(same, out_b.float(), rtol=1.0 / 64, atol=3e-2)
 
 
-def test_gemm_skinny_glu(ops):
+@pytest.mark.parametrize("cfg,M", [(0, 7), (31, 7), (32, 7), (32, 35), (32, 64)])
+def test_gemm_skinny_glu(ops, cfg, M):
     g = torch.Generator().manual_seed(66)
-    M, K, I = 7, 3584, 2048
+    K, I = 3584, 2048
     x = _rand((M, K), g)
     wg, wu = _rand((I, K), g, scale=K ** -0.5), _rand((I, K), g, scale=K ** -0.5)
     w = torch.stack([wg.view(I // 16, 16, K), wu.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
-    out = ops.linear(x, w, act="silu", glu=True)
+    out = ops.linear(x, w, act="silu", glu=True, force_cfg=cfg)
     ref = torch.nn.functional.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t())
     _close(out, ref)
 

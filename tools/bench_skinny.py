@@ -31,12 +31,15 @@ for (M, N, K, glu) in [(7, 4608, 3584, 0), (7, 3584, 3584, 0), (7, 37888, 3584, 
     out = torch.empty(M, N // 2 if glu else N, device=dev, dtype=torch.bfloat16)
     i = [0]
 
-    def fn():
-        i[0] = (i[0] + 1) % len(ws)
-        ops.linear(x, ws[i[0]], out=out, act="silu" if glu else None, glu=bool(glu))
+    row = f"M={M:3d} N={N:6d} K={K:6d} glu={glu}:"
+    for cfg, name in ((31, "split-K + epilogue kernel"), (32, "column-owner fused")):
+        def fn():
+            i[0] = (i[0] + 1) % len(ws)
+            ops.linear(x, ws[i[0]], out=out, act="silu" if glu else None, glu=bool(glu), force_cfg=cfg)
 
-    t = timeit(fn)
-    print(f"M={M:3d} N={N:6d} K={K:6d} glu={glu}: {t*1e6:8.1f} us  {N*K*2/t*1e-12:5.2f} TB/s weights")
+        t = timeit(fn)
+        row += f"   {name}: {t*1e6:7.1f} us {N*K*2/t*1e-12:5.2f} TB/s"
+    print(row)
 lg = torch.randn(7, 152064, device=dev)
 o = torch.empty(7, dtype=torch.int32, device=dev)
 print(f"argmax 7 x 152064: {timeit(lambda: ops.argmax_rows(lg, o))*1e6:.1f} us")
