@@ -455,7 +455,7 @@ def main():
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         step_tflops = (value / world) * wl.f_alg / 1e12
         roofline = {
-            "bound": "mfma", "kernel": "gemm_bf16_glds_kernel (LDS-DMA tiled MFMA GEMM, all tile configs; + gemm_bf16_nt_kernel for K % 64 != 0)",
+            "bound": "mfma", "kernel": "gemm_bf16_pp_kernel / gemm_bf16_glds_kernel (LDS-DMA tiled MFMA GEMMs, all tile configs; + gemm_bf16_nt_kernel for K % 64 != 0)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": pmc_traffic(a.workload),
             "instrumented_pass": {"what": "one System-1 call over all envs" + (f" + one System-2 call over {extra} envs" if extra else ""),
