@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -277,6 +277,26 @@ typedef struct ina_select_args {
     int32_t B, S, T, k, _pad;
 } ina_select_args;
 int ina_select_traj(const ina_select_args* args, void* stream);
+
+/* ---- gemm_rownorm: row-block GEMM (N = 384) with the NextDiT gated-norm / residual / next-pre-norm epilogue:
+ *          P = A . W^T ;  X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma ;  H = rmsnorm(X) * gamma2 * (1 + mod_scale2[r/mod_div])
+ *      replaces attn2.to_out / feed_forward.linear_2 + norm2 / ffn_norm2 + gate + residual + ffn_norm1 / next norm1 of diffusers'
+ *      LuminaNextDiTBlock.forward (diffusers==0.33.1) as wired by nextdit_traj.py:121-188; the projection stays fp32 on chip. */
+typedef struct ina_gemm_rownorm_args {
+    const void* A;          /* bf16 [M,K], row stride lda */
+    const void* W;          /* bf16 [N,K], row stride ldw */
+    const float* gamma;     /* f32 [N] RMSNorm weight on the projection */
+    const float* gate;      /* f32 [M/mod_div, mod_ld] (tanh applied) or NULL */
+    float* X;               /* f32 [M,N] residual stream, updated in place, row stride ldx */
+    void* H;                /* bf16 [M,N] pre-norm output or NULL, row stride ldh */
+    const float* gamma2;    /* f32 [N] or NULL */
+    const float* mod_scale2;/* f32 [M/mod_div, mod_ld] or NULL */
+    int32_t M, N, K;
+    int32_t lda, ldw, ldx, ldh;
+    int32_t mod_div, mod_ld;
+    float eps;
+} ina_gemm_rownorm_args;
+int ina_gemm_rownorm_bf16(const ina_gemm_rownorm_args* args, void* stream);
 
 /* ---- dit_attention: the attention stage of one NextDiT block in one launch:
  *          O = SDPA(LN(q1), LN(k1), v1) + tanh(head_gate[h]) * SDPA(LN(q2), K2, V2)

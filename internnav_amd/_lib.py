@@ -143,6 +143,16 @@ class DitAttnArgs(C.Structure):
     ]
 
 
+class GemmRownormArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("gamma", c_void_p), ("gate", c_void_p), ("X", c_void_p), ("H", c_void_p),
+        ("gamma2", c_void_p), ("mod_scale2", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldw", c_int32), ("ldx", c_int32), ("ldh", c_int32),
+        ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float),
+    ]
+
+
 class SelectArgs(C.Structure):
     _fields_ = [
         ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
@@ -170,6 +180,7 @@ SYMBOLS = {
     "ina_mrope_table": (C.c_int, [C.POINTER(MropeTableArgs), c_void_p]),
     "ina_argmax_rows": (C.c_int, [C.POINTER(ArgmaxArgs), c_void_p]),
     "ina_dit_attention": (C.c_int, [C.POINTER(DitAttnArgs), c_void_p]),
+    "ina_gemm_rownorm_bf16": (C.c_int, [C.POINTER(GemmRownormArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),

@@ -22,6 +22,7 @@ using RopeArgs = ina_rope_args;
 using MropeTableArgs = ina_mrope_table_args;
 using ArgmaxArgs = ina_argmax_args;
 using DitAttnArgs = ina_dit_attn_args;
+using GemmRownormArgs = ina_gemm_rownorm_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
@@ -39,4 +40,5 @@ int ina_launch_gather(const GatherArgs& p, hipStream_t stream);
 int ina_launch_rope(const RopeArgs& p, hipStream_t stream);
 int ina_launch_mrope_table(const MropeTableArgs& p, hipStream_t stream);
 int ina_launch_argmax(const ArgmaxArgs& p, hipStream_t stream);
+int ina_launch_gemm_rownorm(const GemmRownormArgs& p, hipStream_t stream);  // N = 384 row-block GEMM + gated rmsnorm + residual + next pre-norm
 int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream);  // q/k-LayerNorm + self-attention + gated cross-attention of a NextDiT block

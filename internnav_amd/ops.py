@@ -402,3 +402,30 @@ def dit_attention(x: torch.Tensor, out: torch.Tensor, norms, kv2: torch.Tensor, 
     a.scale, a.eps = (scale if scale is not None else 64 ** -0.5), eps
     _lib.check(_lib.lib().ina_dit_attention(C.byref(a), _stream()), "dit_attention")
     return out
+
+
+def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
+                 h: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None,
+                 mod_div: int = 1, eps: float = 1e-5) -> torch.Tensor:
+    """x += tanh(gate[r // mod_div]) * rmsnorm(a_in @ w.T) * gamma;  h = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div]).
+
+    a_in bf16 [M, K], w bf16 [384, K], x f32 [M, 384] (in place), h bf16 [M, 384] or None. One launch: the projection stays on chip."""
+    assert a_in.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a_in.dim() == 2 and a_in.stride(1) == 1 and w.stride(1) == 1
+    M, K = a_in.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.dtype == torch.float32 and x.shape == (M, N) and x.stride(1) == 1
+    a = _lib.GemmRownormArgs()
+    a.A, a.W, a.gamma, a.X = a_in.data_ptr(), w.data_ptr(), _f32(gamma).data_ptr(), x.data_ptr()
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldx = M, N, K, a_in.stride(0), w.stride(0), x.stride(0)
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.stride(-1) == 1
+        a.gate, a.mod_ld = gate.data_ptr(), gate.stride(0)
+    if h is not None:
+        assert h.dtype == torch.bfloat16 and h.shape == (M, N) and h.stride(1) == 1
+        a.H, a.ldh, a.gamma2 = h.data_ptr(), h.stride(0), _ptr(_f32(gamma2))
+        if mod_scale2 is not None:
+            assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and a.mod_ld in (0, mod_scale2.stride(0))
+            a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
+    a.mod_div, a.eps = mod_div, eps
+    _lib.check(_lib.lib().ina_gemm_rownorm_bf16(C.byref(a), _stream()), "gemm_rownorm_bf16")
+    return x

@@ -524,3 +524,31 @@ def test_norm_chained_prenorm(ops, rms, C):
     x_c = base.clone()
     ops.norm(xin, g1, None, eps=1e-5, rms=rms, gate=gate, base=x_c, mod_div=div, out32=x_c, out2=h_a, gamma2=g2, mod_scale2=ms2)
     assert torch.equal(x_c, x_b)
+
+
+@pytest.mark.parametrize("M,K,with_h", [(300, 384, True), (4096 + 40, 1024, True), (128, 64, False), (1000, 384, False)])
+def test_gemm_rownorm_fused_block_epilogue(ops, M, K, with_h):
+    """row-block GEMM + gated rmsnorm + residual + chained pre-norm vs the fp32 formula and vs the two launches it replaces."""
+    N, div = 384, 100
+    g = torch.Generator().manual_seed(M + K)
+    a_in, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    x0 = torch.randn(M, N, generator=g).to(_dev())
+    g1, g2 = [(1.0 + 0.1 * torch.randn(N, generator=g)).to(_dev()) for _ in range(2)]
+    nb = (M + div - 1) // div
+    mod = (0.5 * torch.randn(nb, 2 * N, generator=g)).to(_dev())
+    gate, ms2 = mod[:, :N], mod[:, N:]
+    x = x0.clone()
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=_dev()) if with_h else None
+    ops.gemm_rownorm(a_in, w, g1, x, gate=gate, h=h, gamma2=g2, mod_scale2=ms2, mod_div=div)
+    rms = lambda t: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5)
+    rowb = torch.arange(M, device=_dev()) // div
+    proj = a_in.float() @ w.float().t()
+    x_ref = x0 + torch.tanh(gate[rowb]) * rms(proj) * g1
+    _close(x, x_ref, rtol=2e-3, atol=5e-3)
+    if with_h:
+        _close(h, rms(x_ref) * g2 * (1.0 + ms2[rowb]), rtol=1.0 / 128, atol=1e-2)
+    # the unfused launch pair (bf16 projection in between)
+    pj = ops.linear(a_in, w)
+    xu, hu = x0.clone(), torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
+    ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
+    _close(x, xu, rtol=1.0 / 128, atol=2e-2)
