@@ -17,8 +17,10 @@ available offline), inputs synthetic and resident in HBM before the timed region
 with no data-path exchange ("scaling": "weak"); the only collective is the all_gather of per-env actions over RCCL/xGMI per step.
 
 Timed region: W warm-up steps, then exactly K steps bracketed by barrier + device synchronise, max over ranks. Each engine call
-replays one hipGraph (System-1 over 64 envs; System-2 over a 6- or 7-env micro-batch incl. ViT, prefill, decode, latent queries);
-noise draw, micro-batch gather/scatter, D2H of the trajectories and the host post-processing (traj_to_actions) are inside the step.
+replays a hipGraph: System-2 ViT + prefill of the 6- or 7-env micro-batch; then its decode + latent-query passes on the main stream
+concurrently with System-1 of the 57-58 other envs on a side stream; then System-1 of the micro-batch's envs (same results as the
+single-stream order, checked before the timed region). Noise draw, micro-batch gather/scatter, D2H of the trajectories and the host
+post-processing (traj_to_actions; for the side-stream envs it runs while the GPU finishes the main stream) are inside the step.
 After the timed region rank 0 runs ONE instrumented eager pass with per-launch HIP events (ina_prof_*) to attribute time and
 algorithmic FLOPs to kernel classes for the "roofline" object, and (N = 1 only) times the CPU oracle on a bounded sample.
 """
@@ -30,6 +32,8 @@ import os
 import sys
 import time
 from pathlib import Path
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL / cross-process tensors) on this driver
 
 import numpy as np
 import torch

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
 // t+1's DMA at the start of its R(2t) slot (4t / 4t+1; the buffer's last reader finished in slot 4t-1 and retired its reads with
 // lgkmcnt(0) before that slot's barrier) and retires it (vmcnt(0)) before the barrier that ends slot 4t+3, one slot before the
 // first read of tile t+1.
-template <int BM, int BN, int WN, bool STAGED, bool PRIO>
+template <int BM, int BN, int WN, bool STAGED>
 __global__ __launch_bounds__(2 * WN * 64) void gemm_bf16_pp_kernel(GemmArgs p) {
     constexpr int WM = 2, NS = 2;
     using C = GldsCfg<BM, BN, WM, WN, NS>;
@@ -212,12 +212,10 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_bf16_pp_kernel(GemmArgs p) {
         for (int i = 0; i < C::FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(as + i * 16 * 64 + chunk);
     };
     auto mfmas = [&]() {
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < C::FM; ++i)
 #pragma unroll
             for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto slot_end = [&]() {   // close a slot: nothing moves across, LDS reads of this slot have landed
         __builtin_amdgcn_sched_barrier(0);
@@ -285,7 +283,7 @@ int launch_glds(const GemmArgs& p, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int WN, bool PRIO = false>
+template <int BM, int BN, int WN>
 int launch_pp(const GemmArgs& p, hipStream_t stream) {
     using C = GldsCfg<BM, BN, 2, WN, 2>;
     const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
@@ -293,7 +291,7 @@ int launch_pp(const GemmArgs& p, hipStream_t stream) {
                         (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) &&
                         ((p.glu ? p.N / 2 : p.N) % 4 == 0);
     static bool attr_done[2] = {false, false};
-    auto kern = staged ? gemm_bf16_pp_kernel<BM, BN, WN, true, PRIO> : gemm_bf16_pp_kernel<BM, BN, WN, false, PRIO>;
+    auto kern = staged ? gemm_bf16_pp_kernel<BM, BN, WN, true> : gemm_bf16_pp_kernel<BM, BN, WN, false>;
     if (!attr_done[staged]) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
         attr_done[staged] = true;
@@ -312,7 +310,9 @@ int launch_pp(const GemmArgs& p, hipStream_t stream) {
 }  // namespace
 
 // cfg 11: 128x128 / 4 waves / 2 stages, cfg 12: 256x128 / 8 waves / 2 stages, cfg 13: 128x256 / 8 waves / 2 stages,
-// cfg 14: 256x128 / 8 waves / 3 stages, cfg 15: 128x128 / 4 waves / 3 stages, cfg 16: 128x256 / 8 waves / 3 stages
+// cfg 14: 256x128 / 8 waves / 3 stages, cfg 15: 128x128 / 4 waves / 3 stages, cfg 16: 128x256 / 8 waves / 3 stages,
+// cfg 17: 256x256 / 8 waves / 2 stages (lock-step), cfg 18 / 19: ping-pong kernels (s_setprio(1) around their MFMA slots was
+// measured and is within noise: 1351 vs 1391 TF/s at 8192^3, 1196 vs 1234 on the gate/up GEMM)
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
     INA_REQUIRE(p.K % 64 == 0, "gemm(glds): K=%d must be a multiple of 64", p.K);
     switch (cfg) {
@@ -325,7 +325,6 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
         case 18: return launch_pp<256, 256, 4>(p, stream);           // 256x256, wave tile 128x64, ping-pong wave rows
         case 19: return launch_pp<128, 256, 4>(p, stream);           // 128x256, wave tile 64x64, ping-pong wave rows
-        case 20: return launch_pp<256, 256, 4, true>(p, stream);     // cfg 18 + s_setprio(1) around the MFMA slots
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }
 }

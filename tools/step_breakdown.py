@@ -55,6 +55,22 @@ def both3():
 
 
 print(f"(decode+latents, S1 small) || S1 ({nA} envs): {t(both3):.1f} ms")
+# timeline of the concurrent phase: when does each chain end?
+ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "dec", "s1b", "s1a")}
+torch.cuda.synchronize()
+main = torch.cuda.current_stream()
+ev["start"].record(main)
+wl.side.wait_stream(main)
+with torch.cuda.stream(wl.side):
+    wl.gA[nA]()
+    ev["s1a"].record(wl.side)
+wl.gD[m]()
+ev["dec"].record(main)
+wl.gB[m]()
+ev["s1b"].record(main)
+torch.cuda.synchronize()
+print("concurrent phase timeline: decode+latents ends at %.1f ms, S1(small) at %.1f ms (main stream); S1(%d envs, side stream) at %.1f ms"
+      % (ev["start"].elapsed_time(ev["dec"]), ev["start"].elapsed_time(ev["s1b"]), nA, ev["start"].elapsed_time(ev["s1a"])))
 print(f"full step (bench schedule): {t(lambda: wl.step(0)):.1f} ms")
 traj = wl.s1_graph()
 torch.cuda.synchronize()
