@@ -285,13 +285,14 @@ template <int MF, int NT16>
 void launch_skinny_fused(const GemmArgs& p, hipStream_t stream) {
     const int ksteps = (p.K + SK_BK - 1) / SK_BK;
     const int tiles = (p.N + 16 * NT16 - 1) / (16 * NT16);
-    constexpr int DEEP = (MF * NT16 <= 2) ? 4 : 2;
-    int nw = tiles >= 2048 ? 1 : tiles >= 1024 ? 2 : tiles >= 512 ? 4 : 8;
+    // waves per column group: enough to put >= ~4096 waves in flight (16 per CU), never more than there are K steps
+    constexpr int DEEP = (MF <= 2 && NT16 == 1) ? 4 : 2;
+    int nw = tiles >= 4096 ? 1 : tiles >= 2048 ? 2 : tiles >= 1024 ? 4 : 8;   // (16 waves on the K = 18944 down projection: no gain)
     while (nw > 1 && nw > ksteps) nw >>= 1;
 #define INA_SKF(NW_, NC_, D_) hipLaunchKernelGGL((gemm_skinny_fused_kernel<MF, NT16, NW_, NC_, D_>), dim3((tiles + NC_ - 1) / NC_), dim3(NW_ * NC_ * 64), 0, stream, p)
     if (nw == 1) INA_SKF(1, 4, 2);
     else if (nw == 2) INA_SKF(2, 2, 2);
-    else if (nw == 4) INA_SKF(4, 1, DEEP);
+    else if (nw == 4) INA_SKF(4, 1, 2);
     else INA_SKF(8, 1, DEEP);
 #undef INA_SKF
 }
