@@ -242,17 +242,32 @@ __global__ __launch_bounds__(64) void attn_decode_split_kernel(AttnArgs p, float
             int d = kk * 32 + g * 8;
             qf[kk] = (live && d < p.D) ? *reinterpret_cast<const bf16x8*>(Q + d) : zero8;
         }
-        for (int q = lane; q < KVB * KCPR; q += 64) {
-            int row = q / KCPR, c = q % KCPR, kv = kv0 + row;
-            bf16x8 v = (kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
-            *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = v;
-        }
-        for (int q = lane; q < KVB * VCPR; q += 64) {
-            int row = q / VCPR, c = q % VCPR, kv = kv0 + row;
-            bf16x8 v = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
-            int pos = vt_pos(row);
+        // the whole K / V chunk is requested before the first LDS store: one memory latency per workgroup instead of one per 16-byte
+        // piece (this one-wave kernel has nothing else to hide it behind)
+        constexpr int NKI = KVB * KCPR / 64, NVI = KVB * VCPR / 64;
+        static_assert((KVB * KCPR) % 64 == 0 && (KVB * VCPR) % 64 == 0, "chunk pieces must divide evenly over the wave");
+        bf16x8 kreg[NKI], vreg[NVI];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + ((pos + 8 * c) & (KVB - 1))] = v[i];   // rotated rows: see vt_pos
+        for (int u = 0; u < NKI; ++u) {
+            const int q = lane + u * 64, row = q / KCPR, c = q % KCPR, kv = kv0 + row;
+            kreg[u] = (kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = lane + u * 64, row = q / VCPR, c = q % VCPR, kv = kv0 + row;
+            vreg[u] = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < NKI; ++u) {
+            const int q = lane + u * 64, row = q / KCPR, c = q % KCPR;
+            *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = lane + u * 64, row = q / VCPR, c = q % VCPR;
+            const int pos = vt_pos(row);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + ((pos + 8 * c) & (KVB - 1))] = vreg[u][i];   // rotated rows: see vt_pos
         }
         __syncthreads();
         f32x4 s[NST];
@@ -325,19 +340,31 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(AttnArgs p, con
     const int rt = R / 16, lq = R % 16;
     const int head = kh * G + R / p.Lq, qpos = R % p.Lq;
     const float* base = ws + (((size_t)b * p.Hkv + kh) * rtiles + rt) * nsplit * (size_t)(16 * (DV + 2)) + (size_t)lq * (DV + 2);
+    // slice statistics: lane s holds (m, l) of slice s (+64, ...): one load per lane instead of a serial chain over the slices
+    const size_t sstride = (size_t)16 * (DV + 2);
     float m = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, base[(size_t)s * 16 * (DV + 2) + DV]);
+    for (int s0 = 0; s0 < nsplit; s0 += 64) {
+        const int s = s0 + lane;
+        m = fmaxf(m, s < nsplit ? base[s * sstride + DV] : -INFINITY);
+    }
+    m = wave_max(m);
     const float m_use = (m == -INFINITY) ? 0.f : m;
     float l = 0.f, o0 = 0.f, o1 = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float* q = base + (size_t)s * 16 * (DV + 2);
-        const float ms = q[DV];
-        if (ms == -INFINITY) continue;
-        const float w = exp2f(ms - m_use);
-        l += q[DV + 1] * w;
-        if (lane < DV) o0 += q[lane] * w;
-        if (lane + 64 < DV) o1 += q[lane + 64] * w;
+    for (int s0 = 0; s0 < nsplit; s0 += 64) {
+        const int s = s0 + lane;
+        const float ms = s < nsplit ? base[s * sstride + DV] : -INFINITY;
+        const float wl = (ms == -INFINITY) ? 0.f : exp2f(ms - m_use);
+        l += s < nsplit ? base[s * sstride + DV + 1] * wl : 0.f;
+        const int cnt = min(64, nsplit - s0);
+#pragma unroll 8
+        for (int j = 0; j < cnt; ++j) {
+            const float w = __shfl(wl, j);
+            const float* q = base + (size_t)(s0 + j) * sstride;
+            if (lane < DV) o0 += q[lane] * w;
+            if (lane + 64 < DV) o1 += q[lane + 64] * w;
+        }
     }
+    l = wave_sum(l);
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     bf16* O = reinterpret_cast<bf16*>(p.O) + (size_t)b * p.o_bs + (size_t)qpos * p.o_rs + (size_t)head * p.o_hs;
     if (lane < p.D) O[lane] = (bf16)(o0 * inv);

@@ -43,3 +43,12 @@ cu = torch.arange(0, Np + 1, 64, dtype=torch.int32, device=dev)
 o = torch.empty(Np, H, D, device=dev, dtype=torch.bfloat16)
 us = timeit(lambda: ops.attention(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_q=cu, cu_k=cu, max_q=64, max_k=64, out=o))
 print(f"{'ViT windows 343x64 16 x80':34s} {us:8.1f} us  {4.0 * (Np // 64) * H * 64 * 64 * D / us / 1e6:7.1f} TF/s")
+# decode: 1 and 5 query tokens against the KV cache (GQA-packed split-KV kernel + merge)
+for Lq in (1, 5):
+    B, Lk, H, Hkv, D = 7, 927 + Lq, 28, 4, 128
+    q = torch.randn(B, Lq, H, D, device=dev).to(torch.bfloat16)
+    k = torch.randn(B, Lk, Hkv, D, device=dev).to(torch.bfloat16)
+    v = torch.randn(B, Lk, Hkv, D, device=dev).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    us = timeit(lambda: ops.attention(q, k, v, causal=True, out=o), iters=50)
+    print(f"{'decode 7 x ' + str(Lq) + ' vs ' + str(Lk) + ' keys 28/4 x128':34s} {us:8.1f} us  ({2.0 * B * Hkv * Lk * D * 2 * 2 / us / 1e6:5.2f} TB/s of KV)")
