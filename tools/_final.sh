@@ -1,4 +1,4 @@
-# round-end validation on the GPU box: tests, smoke, both bench workloads, rocprof kernel stats, PMC HBM traffic (all outputs -> gpurun_out/)
+# round-end validation on the GPU box: tests, smoke, both bench workloads, rocprof kernel stats (all outputs -> gpurun_out/)
 export TMPDIR=/tmp
 R=$PWD
 TAG=${1:-r01}
@@ -11,8 +11,9 @@ cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/kt.log 2>&1
 python $R/tools/rocprof_summary.py $R/gpurun_out/kt/kt_results.db 45 > $R/gpurun_out/${TAG}_n1_dual_b64_kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/kt
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pf -o f -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $R/gpurun_out/pf.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pw -o w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-graph > $R/gpurun_out/pw.log 2>&1
-python $R/tools/pmc_summary.py $R/gpurun_out/pf/f_results.db $R/gpurun_out/pw/w_results.db 16 > $R/gpurun_out/${TAG}_pmc_hbm_traffic_n1_dual.txt 2>&1
-rm -rf $R/gpurun_out/pf $R/gpurun_out/pw
+for w in s1 s2; do
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_$w -o kt -- python $R/tools/profile_phases.py $w 3 > $R/gpurun_out/kt_$w.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/kt_$w/*.db | head -1) 40 > $R/gpurun_out/${TAG}_${w}_3calls_kernel_stats.txt 2>&1
+rm -rf $R/gpurun_out/kt_$w
+done
 tail -2 $R/gpurun_out/${TAG}_pytest_gpu.log
