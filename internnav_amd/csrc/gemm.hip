@@ -195,7 +195,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
     if (p.force_cfg <= 0 && cfg == 1 && p.K % 64 == 0) {
         // K multiple of 64: LDS-DMA staged kernels. Pick the tile shape by a small cost model: rounds of workgroups over the 256 CUs
         // (tile quantisation) x tile area / measured relative per-CU rate (profiles/r01f_gemm_tile_sweep.log):
-        //   11: 128x128, 2 WG/CU, rate 0.85 | 14: 256x128 x 3 stages, 1 WG/CU, 0.92 | 18: 256x256 ping-pong, 1 WG/CU, 1.18 (long K only)
+        //   11: 128x128, 2 WG/CU, rate 0.85 | 14: 256x128 x 3 stages, 1 WG/CU, 0.92 | 18: 256x256 ping-pong, 1 WG/CU, 1.18 | 21: 192x256 ping-pong, 0.97 (long K only)
         cfg = 11;
         if (p.K >= 768) {
             auto cost = [&](int bm, int bn, int wg_per_cu, double rate) {
@@ -204,7 +204,10 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
                 return (double)((tiles + slots - 1) / slots) * wg_per_cu * (bm / 128.0) * (bn / 128.0) / rate;
             };
             const double c11 = cost(128, 128, 2, 0.85), c14 = cost(256, 128, 1, 0.92), c18 = cost(256, 256, 1, 1.18);
+            const double c21 = cost(192, 256, 1, 0.97);   // 192-row ping-pong tiles: the row counts of 6 / 7 prompts (5520 / 6440) round better
             cfg = (c18 < c14 && c18 < c11) ? 18 : (c14 < c11 ? 14 : 11);
+            const double best = cfg == 18 ? c18 : cfg == 14 ? c14 : c11;
+            if (c21 < best) cfg = 21;
         }
     }
     switch (cfg) {
@@ -216,7 +219,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

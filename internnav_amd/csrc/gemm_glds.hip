@@ -325,6 +325,7 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
         case 18: return launch_pp<256, 256, 4>(p, stream);           // 256x256, wave tile 128x64, ping-pong wave rows
         case 19: return launch_pp<128, 256, 4>(p, stream);           // 128x256, wave tile 64x64, ping-pong wave rows
+        case 21: return launch_pp<192, 256, 4>(p, stream);           // 192x256, wave tile 96x64: finer row quantisation for M = 5520 / 6440
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }
 }

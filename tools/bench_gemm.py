@@ -25,6 +25,8 @@ dev = torch.device("cuda:0")
 import os
 ACT = int(os.environ.get('GEMM_ACT', '0'))
 shapes = [
+    (5520, 4608, 3584, "bf16"), (5520, 3584, 3584, "f32r"), (5520, 37888, 3584, "glu"), (5520, 3584, 18944, "f32r"),
+    (21952, 6912, 1280, "glu"), (21952, 1280, 3456, "f32r"), (18816, 3840, 1280, "bf16"), (18816, 6912, 1280, "glu"),
     (6440, 4608, 3584, "bf16"), (6440, 3584, 3584, "f32r"), (6440, 37888, 3584, "glu"), (6440, 3584, 18944, "f32r"),
     (21952, 3840, 1280, "bf16"), (21952, 1280, 1280, "f32r"), (21952, 6848, 1280, "glu"), (21952, 1280, 3424, "f32r"),
     (65536, 1536, 384, "bf16"), (65536, 384, 384, "f32r"), (65536, 2048, 384, "glu"), (65536, 384, 1024, "f32r"),
