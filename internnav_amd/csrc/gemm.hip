@@ -197,7 +197,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         // (tile quantisation) x tile area / measured relative per-CU rate (profiles/r01f_gemm_tile_sweep.log):
         //   11: 128x128, 2 WG/CU, rate 0.85 | 14: 256x128 x 3 stages, 1 WG/CU, 0.92 | 18: 256x256 ping-pong, 1 WG/CU, 1.18 | 21: 192x256 ping-pong, 0.97 (long K only)
         cfg = 11;
-        if (p.K >= 768) {
+        if (p.K >= 768 && p.N > 512) {   // narrow outputs (N = 384 heads): 128x128 measured 6-15 % ahead of 256x128 at K = 1024 / 1536
             auto cost = [&](int bm, int bn, int wg_per_cu, double rate) {
                 const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch;
                 const long slots = 256L * wg_per_cu;

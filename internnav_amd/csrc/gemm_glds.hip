@@ -6,8 +6,8 @@
 //   * the DMA writes lane-linearly, so the bank-conflict fix is an XOR swizzle applied on the SOURCE side: the lane that lands on
 //     physical 16-byte chunk cp of row r fetches logical chunk cp ^ (r & 7) (all 8 lanes of a row still cover one 128-byte line),
 //     and the MFMA fragment reads apply the same involution (ds_read_b128 of chunk c ^ (r & 7));
-//   * 2 stages, one barrier per K tile: tile t+1's DMA is issued right after the barrier that publishes tile t and stays in
-//     flight under the 32 MFMAs per wave of tile t (`s_waitcnt vmcnt(0)` only just before the next barrier).
+//   * NS stages, one barrier per K tile: the first NS tiles are requested up front, then tile t+NS-1's DMA is issued right after
+//     the barrier that publishes tile t and stays in flight under the MFMAs (counted `s_waitcnt vmcnt`, raw `s_barrier`).
 // Rows beyond M / N are clamped to the last valid row (their accumulators are never stored) - the DMA has no predication.
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -90,18 +90,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     // has to have landed: the newer tiles' INST wave-instructions may stay outstanding) and the barrier is a raw s_barrier -
     // __syncthreads() would emit vmcnt(0) for the pending LDS-DMA writes and drain the ring (guide 5, glds "span a barrier").
     constexpr int INST = C::A_INST + C::B_INST;
+    // all NS buffers are free at kernel start: request the first NS tiles at once (a K = 384 GEMM has only 6 tiles per output tile -
+    // serialising the first two DMA latencies was ~10 % of its time); from iteration 1 on the buffer read in iteration t - 1 is refilled
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
+    for (int s = 0; s < NS; ++s)
         if (s < nk) stage(s, s * 64);
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
-        // number of newer tiles already issued: min(NS - 2, nk - 1 - t)
-        const int newer = (nk - 1 - t) < (NS - 2) ? (nk - 1 - t) : (NS - 2);
-        if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INST) : "memory");
+        // newer tiles in flight at this point: tiles 1 .. NS-1 in iteration 0, tiles t+1 .. t+NS-2 afterwards
+        const int ahead = (t == 0) ? (NS - 1) : (NS - 2);
+        const int newer = (nk - 1 - t) < ahead ? (nk - 1 - t) : ahead;
+        if (NS >= 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * INST) : "memory");
+        else if (newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INST) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // tile t visible to all waves; all waves done with the buffer refilled below
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        {
+        if (t >= 1) {
             const int nt = t + NS - 1;                       // next tile to request goes into the buffer read in iteration t - 1
             int nb = buf + NS - 1;
             if (nb >= NS) nb -= NS;
