@@ -10,8 +10,9 @@
 // read-modify-write of the output): 650 MB of HBM traffic per block at 65536 rows. Here the projection row is read once and the
 // output written once (250 MB), in one launch:
 //   * one workgroup = one sequence, one wave per head;
-//   * phase A: per-(token, segment) LayerNorm statistics -> LDS (16 lanes per row, fp32, two-pass variance); the wave's V1 head
-//     slice is transposed into its private LDS tile meanwhile;
+//   * phase A: per-(token, segment) LayerNorm statistics -> LDS, computed with MFMAs (row sums = X . 1^T, sums of squares =
+//     diag(X . X^T); the kernel was VALU-issue bound: PMC 1981 VALU instructions per wave); the wave's V1 head slice is
+//     transposed into its private LDS tile meanwhile;
 //   * phase B: Q / K MFMA fragments are loaded straight from global (L2 hits: phase A just read the rows) and normalised in
 //     registers; S^T = K . Q^T and O^T = V^T . P^T in the swapped-operand form of attention.hip (P never leaves its lane);
 //   * the condition V is consumed from a pre-transposed, key-permuted image V2T[env][head][64][64] built once per call;
@@ -30,6 +31,7 @@ __device__ __forceinline__ int dit_vt_pos(int kv_local) {
 }
 
 // raw 8-element slice + LayerNorm with the row's (mean, rstd) and the 8 affine parameters of those columns
+// (scalar fp32 ops on purpose: the packed v_pk_* form measured 15 % slower here, next to the MFMAs)
 __device__ __forceinline__ bf16x8 ln_apply8(bf16x8 x, float mean, float rstd, const f32x4& g0, const f32x4& g1, const f32x4& b0, const f32x4& b1) {
     bf16x8 y;
 #pragma unroll
@@ -42,9 +44,7 @@ __device__ __forceinline__ bf16x8 ln_apply8(bf16x8 x, float mean, float rstd, co
 
 template <int NH>
 __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
-    constexpr int HD = 64, D = NH * HD, VT_LD = 40, CPL = NH / 2;   // CPL: 16-byte chunks per lane in the statistics pass
-    static_assert(NH % 2 == 0 && 96 % (NH * 4) == 0, "statistics pass: 16 lanes x NH/2 chunks per row, 4 rows per wave pass");
-    constexpr int NPASS = 96 / (NH * 4);
+    constexpr int HD = 64, D = NH * HD, VT_LD = 40;
     __shared__ float stats[3][32][2];
     __shared__ __attribute__((aligned(16))) bf16 Vt[NH][HD * VT_LD];
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -66,22 +66,20 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
         for (int kk = 0; kk < 2; ++kk)
             k2f[t][kk] = key < p.Lz ? *reinterpret_cast<const bf16x8*>(K2 + (size_t)key * p.k2_rs + g * 8 + kk * 32) : zero8;
     }
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) v2f[sb][nt] = *reinterpret_cast<const bf16x8*>(V2T + (size_t)(nt * 16 + lq) * 64 + sb * 32 + g * 8);
 
-    // ---- phase A: LayerNorm statistics of the q1 / k1 / q2 segment of every token (row r = s*32 + token, 4 rows per wave pass);
-    //      all passes' loads are issued before the first reduction
+    // ---- phase A: LayerNorm statistics of the q1 / k1 / q2 segment of every token ON THE MATRIX CORES: wave h owns one
+    //      (segment, 16-token tile) unit; with X = its [16 tokens x D] slice, X . 1^T gives the row sums and diag(X . X^T) the row sums
+    //      of squares (bf16 products are exact in fp32), 2 x D/32 MFMAs instead of ~500 VALU instructions per wave
     {
-        bf16x8 raw[NPASS][CPL];
+        static_assert(NH == 6, "one (segment, token tile) unit per wave: 3 segments x 2 tiles");
+        constexpr int NCH = D / 32;
+        const int us = h >> 1, utt = h & 1, useg = us == 2 ? 3 : us;
+        const int utok = utt * 16 + lq;
+        bf16x8 raw[NCH];
+        {
+            const bf16* row = base + (size_t)(utok < T ? utok : 0) * p.ldx + useg * D + g * 8;
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * NH * 4 + h * 4 + g;
-            const int s = r >> 5, tok = r & 31, seg = s == 2 ? 3 : s;
-            const bf16* row = base + (size_t)(tok < T ? tok : 0) * p.ldx + seg * D;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c) raw[ps][c] = *reinterpret_cast<const bf16x8*>(row + (c * 16 + lq) * 8);
+            for (int c = 0; c < NCH; ++c) raw[c] = *reinterpret_cast<const bf16x8*>(row + c * 32);
         }
         // this wave's V1 head slice [32 keys x 64] -> transposed, key-permuted LDS tile
         // (lane -> 8-column chunk c = lane & 7 of key rows {2m, 2m+1, 16+2m, 16+2m+1}, m = lane >> 3: neighbouring keys land on
@@ -92,24 +90,24 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             const int row = (i >> 1) * 16 + (lane >> 3) * 2 + (i & 1);
             vraw[i] = row < T ? *reinterpret_cast<const bf16x8*>(base + (size_t)row * p.ldx + 2 * D + h * HD + (lane & 7) * 8) : zero8;
         }
+        {
+            const bf16 one = (bf16)1.0f;
+            const bf16x8 ones = {one, one, one, one, one, one, one, one};
+            f32x4 asum = {0.f, 0.f, 0.f, 0.f}, asq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-            const int r = ps * NH * 4 + h * 4 + g;
-            float x[CPL * 8];
-            float sum = 0.f;
-#pragma unroll
-            for (int c = 0; c < CPL; ++c)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { x[c * 8 + i] = (float)raw[ps][c][i]; sum += x[c * 8 + i]; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * (1.0f / D);
-            float var = 0.f;
-#pragma unroll
-            for (int i = 0; i < CPL * 8; ++i) { const float d = x[i] - mean; var += d * d; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) var += __shfl_xor(var, o);
-            if (lq == 0) { stats[r >> 5][r & 31][0] = mean; stats[r >> 5][r & 31][1] = rsqrtf(var * (1.0f / D) + p.eps); }
+            for (int c = 0; c < NCH; ++c) {
+                asum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, raw[c], asum, 0, 0, 0);     // D[i][j] = sum_k X[j][k]
+                asq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(raw[c], raw[c], asq, 0, 0, 0);      // D[i][j] = X[i] . X[j]
+            }
+            // lane (lq, g) holds D[i = g*4 + r][j = lq]: the diagonal entry of token lq sits in lane group g = lq >> 2, element lq & 3
+            if (g == (lq >> 2)) {
+                const int r = lq & 3;
+                const float ss = r == 0 ? asq[0] : r == 1 ? asq[1] : r == 2 ? asq[2] : asq[3];
+                const float mean = asum[0] * (1.0f / D);
+                const float var = fmaxf(ss * (1.0f / D) - mean * mean, 0.f);
+                stats[us][utok][0] = mean;
+                stats[us][utok][1] = rsqrtf(var + p.eps);
+            }
         }
         // image row d keeps its four 8-slot groups rotated by d >> 3 (the chunk index c): the 8 chunk lanes of a store then hit 8
         // different bank groups instead of one
@@ -131,18 +129,19 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
     const int dcol = h * HD + g * 8;                     // first of this lane's 8 columns inside a 32-wide k step (+ kk*32)
 
     // ---- phase B loads (L2 hits: phase A just read these rows): raw q1 / q2 of both query tiles, raw k1 of both key tiles
-    bf16x8 q1r[2][2], q2r[2][2], k1r[2][2];
+    bf16x8 k1r[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int tok = qt * 16 + lq;
         const bf16* row = base + (size_t)(tok < T ? tok : 0) * p.ldx + dcol;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            q1r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + kk * 32);
-            k1r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + D + kk * 32);
-            q2r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + 3 * D + kk * 32);
-        }
+        for (int kk = 0; kk < 2; ++kk) k1r[qt][kk] = *reinterpret_cast<const bf16x8*>(row + D + kk * 32);
     }
+    // condition V fragments (requested here rather than with K2: 32 fewer live registers across the statistics pass, no spills)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) v2f[sb][nt] = *reinterpret_cast<const bf16x8*>(V2T + (size_t)(nt * 16 + lq) * 64 + sb * 32 + g * 8);
     // normalised K1 fragments (keys t*16 + lq)
     bf16x8 k1f[2][2];
 #pragma unroll
@@ -156,11 +155,20 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
         }
     }
 
-#pragma unroll
+#pragma unroll 1
     for (int qt = 0; qt < 2; ++qt) {
         const int tok = qt * 16 + lq;
         if (qt * 16 >= T) break;
         const bool qok = tok < T;
+        bf16x8 q1r[2], q2r[2];
+        {
+            const bf16* row = base + (size_t)(qok ? tok : 0) * p.ldx + dcol;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                q1r[kk] = *reinterpret_cast<const bf16x8*>(row + kk * 32);
+                q2r[kk] = *reinterpret_cast<const bf16x8*>(row + 3 * D + kk * 32);
+            }
+        }
         // ================= self-attention over the sequence's own tokens
         f32x4 o1[4];
         {
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             for (int kk = 0; kk < 2; ++kk) {
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32 + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32 + 4);
-                qf[kk] = qok ? ln_apply8(q1r[qt][kk], stats[0][tok][0], stats[0][tok][1], g0, g1, b0, b1) : zero8;
+                qf[kk] = qok ? ln_apply8(q1r[kk], stats[0][tok][0], stats[0][tok][1], g0, g1, b0, b1) : zero8;
             }
             f32x4 s[2];
 #pragma unroll
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[t][r] - mx);
+                    const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
                     l += e;
                     pf[t * 4 + r] = (bf16)e;
                 }
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             for (int kk = 0; kk < 2; ++kk) {
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32 + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32 + 4);
-                qf[kk] = qok ? ln_apply8(q2r[qt][kk], stats[2][tok][0], stats[2][tok][1], g0, g1, b0, b1) : zero8;
+                qf[kk] = qok ? ln_apply8(q2r[kk], stats[2][tok][0], stats[2][tok][1], g0, g1, b0, b1) : zero8;
             }
             f32x4 s[4];
 #pragma unroll
@@ -228,13 +236,14 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k2f[t][kk], qf[kk], s[t], 0, 0, 0);
             }
+            // keys of this lane: t*16 + g*4 + r; Lz - g*4 is the per-lane bound on t*16 + r (one compare per element, no index math)
+            const int lim = p.Lz - g * 4;
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kv = t * 16 + g * 4 + r;
-                    const float v = kv < p.Lz ? s[t][r] * sc : -INFINITY;
+                    const float v = (t * 16 + r) < lim ? s[t][r] * sc : -INFINITY;
                     s[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = exp2f(s[t][r] - mx);
+                    const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
                     s[t][r] = e;
                     l += e;
                 }
