@@ -52,7 +52,8 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
     const int seq = blockIdx.x, env = seq / p.seq_per_env;
     const int T = p.T;
     const bf16* __restrict__ base = reinterpret_cast<const bf16*>(p.X) + (size_t)seq * T * p.ldx;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Rows / keys beyond T or Lz are read from a clamped (valid) row instead of being predicated: their scores are masked to -inf and
+    // their outputs never stored, and no load needs an exec-mask branch.
     const bf16* __restrict__ K2 = reinterpret_cast<const bf16*>(p.K2) + (size_t)env * p.k2_bs + h * HD;
     const bf16* __restrict__ V2T = reinterpret_cast<const bf16*>(p.V2T) + ((size_t)env * NH + h) * HD * 64;
 
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
         const int key = t * 16 + lq;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-            k2f[t][kk] = key < p.Lz ? *reinterpret_cast<const bf16x8*>(K2 + (size_t)key * p.k2_rs + g * 8 + kk * 32) : zero8;
+            k2f[t][kk] = *reinterpret_cast<const bf16x8*>(K2 + (size_t)min(key, p.Lz - 1) * p.k2_rs + g * 8 + kk * 32);
     }
 
     // ---- phase A: LayerNorm statistics of the q1 / k1 / q2 segment of every token ON THE MATRIX CORES: wave h owns one
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i >> 1) * 16 + (lane >> 3) * 2 + (i & 1);
-            vraw[i] = row < T ? *reinterpret_cast<const bf16x8*>(base + (size_t)row * p.ldx + 2 * D + h * HD + (lane & 7) * 8) : zero8;
+            vraw[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)min(row, T - 1) * p.ldx + 2 * D + h * HD + (lane & 7) * 8);
         }
         {
             const bf16 one = (bf16)1.0f;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = t * 16 + lq;
-            k1f[t][kk] = key < T ? ln_apply8(k1r[t][kk], stats[1][key][0], stats[1][key][1], g0, g1, b0, b1) : zero8;
+            k1f[t][kk] = ln_apply8(k1r[t][kk], stats[1][key][0], stats[1][key][1], g0, g1, b0, b1);
         }
     }
 
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             for (int kk = 0; kk < 2; ++kk) {
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32 + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32 + 4);
-                qf[kk] = qok ? ln_apply8(q1r[kk], stats[0][tok][0], stats[0][tok][1], g0, g1, b0, b1) : zero8;
+                qf[kk] = ln_apply8(q1r[kk], stats[0][tok][0], stats[0][tok][1], g0, g1, b0, b1);
             }
             f32x4 s[2];
 #pragma unroll
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
             for (int kk = 0; kk < 2; ++kk) {
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32 + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32 + 4);
-                qf[kk] = qok ? ln_apply8(q2r[kk], stats[2][tok][0], stats[2][tok][1], g0, g1, b0, b1) : zero8;
+                qf[kk] = ln_apply8(q2r[kk], stats[2][tok][0], stats[2][tok][1], g0, g1, b0, b1);
             }
             f32x4 s[4];
 #pragma unroll
