@@ -395,6 +395,8 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
         (p.H / p.Hkv) * p.Lq <= 48 && p.Lq <= 8 && DV <= 128)
         return launch_decode<DP, DV>(p, stream);
     // short query sequences: fewer waves per workgroup; short key sequences: 32-key blocks
+    // (two query tiles per wave - every K / V^T fragment read feeding two MFMAs - was measured and is slower: 238 VGPRs at d = 128
+    //  leave one workgroup per CU, 351 vs 184 us on the LLM prefill shape; equal at d = 80, slower at d = 64)
     const bool small_k = p.Lk <= 48;
     int nw = (p.Lq <= 16) ? 1 : (p.Lq <= 32 ? 2 : 4);
     dim3 grid((p.Lq + nw * 16 - 1) / (nw * 16), p.H, p.B);
