@@ -90,6 +90,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     // has to have landed: the newer tiles' INST wave-instructions may stay outstanding) and the barrier is a raw s_barrier -
     // __syncthreads() would emit vmcnt(0) for the pending LDS-DMA writes and drain the ring (guide 5, glds "span a barrier").
     constexpr int INST = C::A_INST + C::B_INST;
+    if constexpr (NS == 1) {
+        // single buffer, no software pipeline: 32 KiB of LDS per 128 x 128 workgroup, so 4 workgroups share a CU and hide each other's
+        // DMA latency (occupancy instead of prefetch depth; for the 6-K-tile GEMMs of the d = 384 heads)
+        for (int t = 0; t < nk; ++t) {
+            stage(0, t * 64);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bf16* as = As + (wm * C::TM + frow) * 64;
+            const bf16* bs = Bs + (wn * C::TN + frow) * 64;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = ((kk * 4 + g) ^ sw) << 3;
+                bf16x8 fa[C::FM], fb[C::FN];
+#pragma unroll
+                for (int i = 0; i < C::FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(as + i * 16 * 64 + chunk);
+#pragma unroll
+                for (int j = 0; j < C::FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 16 * 64 + chunk);
+#pragma unroll
+                for (int i = 0; i < C::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // everyone is done reading before the buffer is overwritten
+        }
+    } else {
     // all NS buffers are free at kernel start: request the first NS tiles at once (a K = 384 GEMM has only 6 tiles per output tile -
     // serialising the first two DMA latencies was ~10 % of its time); from iteration 1 on the buffer read in iteration t - 1 is refilled
 #pragma unroll
@@ -127,6 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
                 for (int j = 0; j < C::FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
         if (++buf == NS) buf = 0;
+    }
     }
     if constexpr (STAGED) {
         __syncthreads();   // every wave is done with the stage buffers: the whole LDS becomes the per-wave transpose scratch
@@ -327,6 +354,7 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 15: return launch_glds<128, 128, 2, 2, 3>(p, stream);
         case 16: return launch_glds<128, 256, 2, 4, 3>(p, stream);
         case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
+        case 22: return launch_glds<128, 128, 2, 2, 1>(p, stream);   // 128x128 single buffer, 4 workgroups per CU
         case 18: return launch_pp<256, 256, 4>(p, stream);           // 256x256, wave tile 128x64, ping-pong wave rows
         case 19: return launch_pp<128, 256, 4>(p, stream);           // 128x256, wave tile 64x64, ping-pong wave rows
         case 21: return launch_pp<192, 256, 4>(p, stream);           // 192x256, wave tile 96x64: finer row quantisation for M = 5520 / 6440
