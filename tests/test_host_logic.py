@@ -237,3 +237,29 @@ def test_agent_batches_s2_by_prompt_length_and_falls_back_to_stop_on_failure():
     model.fail_b = 1                          # the singleton length group (env 2) fails inside generate()
     out = ag.step(obs)
     assert [o["action"] for o in out] == [[3], [3], [0]]
+
+
+def test_bench_accounting_is_consistent():
+    """bench.py's algorithmic-FLOP accounting and the committed PMC traffic table: recomputed from the configs, the policy
+    step is S1 + S2 / 10, the micro-batches of 10 consecutive steps cover every env exactly once, and roofline.traffic resolves."""
+    import importlib
+
+    import numpy as np
+
+    bench = importlib.import_module("bench")
+    from internnav_amd import flops, synthetic
+
+    q, s = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_CFG
+    f2 = flops.s2_call_flops(920, [(1, 28, 28)] * 4, 8, q)["total"]
+    f1 = flops.nextdit_s1_flops_per_env(s)["total"]
+    assert abs(f2 / 1e12 - 16.46) < 0.1 and abs(f1 / 1e12 - 0.53) < 0.02          # SURVEY 8d: 16.46 / 0.53 TFLOP
+    assert abs((f1 + f2 / 10) / 1e12 - 2.18) < 0.03                                # policy step 2.18 TFLOP per env
+    B, C = 64, bench.N1Dual.CADENCE
+    mb = [B // C + (1 if j < B % C else 0) for j in range(C)]
+    assert sum(mb) == B and max(mb) - min(mb) <= 1
+    starts = np.concatenate([[0], np.cumsum(mb)])
+    covered = sorted(e for j in range(C) for e in range(int(starts[j]), int(starts[j]) + mb[j]))
+    assert covered == list(range(B))
+    for wl in ("n1_dual", "navdp_s1"):
+        t = bench.pmc_traffic(wl)
+        assert t and t["bytes_per_launch"] > 0 and (bench.ROOT / t["source"].split(" ")[0]).exists()
