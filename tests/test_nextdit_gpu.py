@@ -27,14 +27,16 @@ def test_pool_act(built_lib):
     assert torch.allclose(o2.float(), torch.nn.functional.silu(t + pos), atol=2e-2, rtol=1e-2)
 
 
-def test_nextdit_generate_traj_vs_reference_fixture(built_lib):
+@pytest.mark.parametrize("fuse_rownorm", [False, True])
+def test_nextdit_generate_traj_vs_reference_fixture(built_lib, fuse_rownorm):
+    """fuse_rownorm: attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + pre-norm epilogue (gemm_rownorm)."""
     from internnav_amd.nextdit import NextDiTSystem1
 
     gold = torch.load(Path(__file__).resolve().parent / "golden" / "n1_nextdit.pt", weights_only=True)
     B = gold["B"]
     sd = W.n1_nextdit_state_dict(seed=gold["seed"])
     inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
-    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B)
+    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B, fuse_rownorm=fuse_rownorm)
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), inp["images"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV))
     d = (out.float().cpu() - gold["latents"]).abs()
     ref = gold["latents"].abs().max().item()
