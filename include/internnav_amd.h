@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -277,6 +277,40 @@ typedef struct ina_select_args {
     int32_t B, S, T, k, _pad;
 } ina_select_args;
 int ina_select_traj(const ina_select_args* args, void* stream);
+
+/* ---- frame pre-processing on the device, bit-exact with the host path of the reference:
+ *      resize_u8: one axis of PIL's 8-bit ImagingResample (Pillow libImaging/Resample.c): tensor [outer, n_in, inner] -> [outer, n_out,
+ *      inner], out = clip8((2^21 + sum_x in[xmin + x] * coefs[xx][x]) >> 22); bounds / coefs are PIL's precompute_coeffs +
+ *      normalize_coeffs_8bpc tables (internnav_amd/preprocess.py builds them). Image.resize = W pass, then H pass.
+ *      reference: internvla_n1_policy.py:105-116, internvla_n1_agent.py:309-320, HF Qwen2VLImageProcessor.resize. */
+typedef struct ina_resize_u8_args {
+    const void* in;         /* u8 [outer, n_in, inner] */
+    void* out;              /* u8 [outer, n_out, inner] */
+    const int32_t* bounds;  /* int32 [n_out, 2] = (xmin, count) */
+    const int32_t* coefs;   /* int32 [n_out, ksize] 22-bit fixed point */
+    int32_t outer, n_in, n_out, inner, ksize, _pad;
+} ina_resize_u8_args;
+int ina_resize_u8(const ina_resize_u8_args* args, void* stream);
+
+/*      qwen_patchify_u8: HF Qwen2VLImageProcessor rescale + normalize (as a 3 x 256 fp32 table computed with the processor's own
+ *      arithmetic) + patchify: rows (grid_h/merge, grid_w/merge, merge, merge), columns (C, tdup copies, ps, ps); bf16 out.
+ *      reference: transformers image_processing_qwen2_vl.py (_preprocess / patchify), called at internvla_n1_policy.py:163-165. */
+typedef struct ina_qwen_patchify_args {
+    const void* img;        /* u8 [n, H, W, 3] */
+    void* out;              /* bf16 [n * (H/ps) * (W/ps), ldo] */
+    const float* lut;       /* f32 [3, 256] */
+    int32_t n, H, W, ps, merge, tdup, ldo, _pad;
+} ina_qwen_patchify_args;
+int ina_qwen_patchify_u8(const ina_qwen_patchify_args* args, void* stream);
+
+/*      u8_lut: out[i] = bf16(lut[in[i]])  (np.array(img) / 255.0 of the System-1 frames, internvla_n1_agent.py:309-317). */
+typedef struct ina_u8_lut_args {
+    const void* in;         /* u8 [n] */
+    void* out;              /* bf16 [n] */
+    const float* lut;       /* f32 [256] */
+    int64_t n;
+} ina_u8_lut_args;
+int ina_u8_lut(const ina_u8_lut_args* args, void* stream);
 
 /* ---- gemm_rownorm: row-block GEMM (N = 384) with the NextDiT gated-norm / residual / next-pre-norm epilogue:
  *          P = A . W^T ;  X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma ;  H = rmsnorm(X) * gamma2 * (1 + mod_scale2[r/mod_div])

@@ -153,6 +153,20 @@ class GemmRownormArgs(C.Structure):
     ]
 
 
+class ResizeU8Args(C.Structure):
+    _fields_ = [("in_", c_void_p), ("out", c_void_p), ("bounds", c_void_p), ("coefs", c_void_p),
+                ("outer", c_int32), ("n_in", c_int32), ("n_out", c_int32), ("inner", c_int32), ("ksize", c_int32), ("_pad", c_int32)]
+
+
+class QwenPatchifyArgs(C.Structure):
+    _fields_ = [("img", c_void_p), ("out", c_void_p), ("lut", c_void_p),
+                ("n", c_int32), ("H", c_int32), ("W", c_int32), ("ps", c_int32), ("merge", c_int32), ("tdup", c_int32), ("ldo", c_int32), ("_pad", c_int32)]
+
+
+class U8LutArgs(C.Structure):
+    _fields_ = [("in_", c_void_p), ("out", c_void_p), ("lut", c_void_p), ("n", c_int64)]
+
+
 class SelectArgs(C.Structure):
     _fields_ = [
         ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
@@ -181,6 +195,9 @@ SYMBOLS = {
     "ina_argmax_rows": (C.c_int, [C.POINTER(ArgmaxArgs), c_void_p]),
     "ina_dit_attention": (C.c_int, [C.POINTER(DitAttnArgs), c_void_p]),
     "ina_gemm_rownorm_bf16": (C.c_int, [C.POINTER(GemmRownormArgs), c_void_p]),
+    "ina_resize_u8": (C.c_int, [C.POINTER(ResizeU8Args), c_void_p]),
+    "ina_qwen_patchify_u8": (C.c_int, [C.POINTER(QwenPatchifyArgs), c_void_p]),
+    "ina_u8_lut": (C.c_int, [C.POINTER(U8LutArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),

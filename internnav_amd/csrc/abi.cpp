@@ -134,7 +134,7 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
 }
 
 /* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify,
- * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm */
+ * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut */
 int ina_struct_size(int k) {
     switch (k) {
         case 0: return (int)sizeof(ina_gemm_args);
@@ -152,6 +152,9 @@ int ina_struct_size(int k) {
         case 12: return (int)sizeof(ina_argmax_args);
         case 13: return (int)sizeof(ina_dit_attn_args);
         case 14: return (int)sizeof(ina_gemm_rownorm_args);
+        case 15: return (int)sizeof(ina_resize_u8_args);
+        case 16: return (int)sizeof(ina_qwen_patchify_args);
+        case 17: return (int)sizeof(ina_u8_lut_args);
         default: return -1;
     }
 }
@@ -172,6 +175,9 @@ INA_ENTRY(ina_rope_bf16, ina_rope_args, ina_launch_rope)
 INA_ENTRY(ina_mrope_table, ina_mrope_table_args, ina_launch_mrope_table)
 INA_ENTRY(ina_dit_attention, ina_dit_attn_args, ina_launch_dit_attention)
 INA_ENTRY(ina_gemm_rownorm_bf16, ina_gemm_rownorm_args, ina_launch_gemm_rownorm)
+INA_ENTRY(ina_resize_u8, ina_resize_u8_args, ina_launch_resize_u8)
+INA_ENTRY(ina_qwen_patchify_u8, ina_qwen_patchify_args, ina_launch_qwen_patchify_u8)
+INA_ENTRY(ina_u8_lut, ina_u8_lut_args, ina_launch_u8_lut)
 INA_ENTRY(ina_argmax_rows, ina_argmax_args, ina_launch_argmax)
 #undef INA_ENTRY
 

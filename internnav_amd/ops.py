@@ -429,3 +429,46 @@ def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: to
     a.mod_div, a.eps = mod_div, eps
     _lib.check(_lib.lib().ina_gemm_rownorm_bf16(C.byref(a), _stream()), "gemm_rownorm_bf16")
     return x
+
+
+def resize_u8(x: torch.Tensor, out: torch.Tensor, bounds: torch.Tensor, coefs: torch.Tensor, axis: int) -> torch.Tensor:
+    """one axis of PIL's 8-bit bicubic resample: x u8 contiguous, out the same shape with `axis` resized to bounds.shape[0];
+    bounds int32 [n_out, 2], coefs int32 [n_out, ksize] (internnav_amd.preprocess builds PIL's tables)."""
+    assert x.dtype == torch.uint8 and out.dtype == torch.uint8 and x.is_contiguous() and out.is_contiguous()
+    assert bounds.dtype == torch.int32 and coefs.dtype == torch.int32 and bounds.is_contiguous() and coefs.is_contiguous()
+    n_out = bounds.shape[0]
+    outer = 1
+    for d in x.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in x.shape[axis + 1:]:
+        inner *= d
+    assert out.shape[axis] == n_out and out.numel() == outer * n_out * inner and coefs.shape[0] == n_out
+    a = _lib.ResizeU8Args()
+    a.in_, a.out, a.bounds, a.coefs = x.data_ptr(), out.data_ptr(), bounds.data_ptr(), coefs.data_ptr()
+    a.outer, a.n_in, a.n_out, a.inner, a.ksize = outer, x.shape[axis], n_out, inner, coefs.shape[1]
+    _lib.check(_lib.lib().ina_resize_u8(C.byref(a), _stream()), "resize_u8")
+    return out
+
+
+def qwen_patchify_u8(img: torch.Tensor, out: torch.Tensor, lut: torch.Tensor, ps: int = 14, merge: int = 2, tdup: int = 2) -> torch.Tensor:
+    """img u8 [n, H, W, 3] -> out bf16 [n * (H/ps) * (W/ps), 3*tdup*ps*ps] in the HF Qwen2-VL patch layout; lut f32 [3, 256]."""
+    assert img.dtype == torch.uint8 and img.is_contiguous() and img.dim() == 4 and img.shape[3] == 3
+    assert out.dtype == torch.bfloat16 and out.dim() == 2 and out.stride(1) == 1 and lut.dtype == torch.float32 and lut.is_contiguous() and lut.numel() == 768
+    n, H, W = img.shape[:3]
+    assert out.shape[0] == n * (H // ps) * (W // ps) and out.shape[1] == 3 * tdup * ps * ps
+    a = _lib.QwenPatchifyArgs()
+    a.img, a.out, a.lut = img.data_ptr(), out.data_ptr(), lut.data_ptr()
+    a.n, a.H, a.W, a.ps, a.merge, a.tdup, a.ldo = n, H, W, ps, merge, tdup, out.stride(0)
+    _lib.check(_lib.lib().ina_qwen_patchify_u8(C.byref(a), _stream()), "qwen_patchify_u8")
+    return out
+
+
+def u8_lut(x: torch.Tensor, out: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    """out[i] = bf16(lut[x[i]]); x u8, lut f32 [256]."""
+    assert x.dtype == torch.uint8 and x.is_contiguous() and out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == x.numel()
+    assert lut.dtype == torch.float32 and lut.is_contiguous() and lut.numel() == 256
+    a = _lib.U8LutArgs()
+    a.in_, a.out, a.lut, a.n = x.data_ptr(), out.data_ptr(), lut.data_ptr(), x.numel()
+    _lib.check(_lib.lib().ina_u8_lut(C.byref(a), _stream()), "u8_lut")
+    return out

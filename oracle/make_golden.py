@@ -12,6 +12,7 @@ from __future__ import annotations
 import argparse
 from pathlib import Path
 
+import numpy as np
 import torch
 
 from . import dinov2 as o_dino
@@ -347,7 +348,40 @@ def lookdown_inputs(cfg):
     return W.qwen_lookdown_inputs(cfg)
 
 
-UNITS = {"vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_preprocess():
+    """Frame pre-processing as the reference's host path runs it: PIL itself (Image.resize, bicubic 8-bit) and the installed
+    transformers Qwen2VLImageProcessorPil on seeded camera-sized frames (small geometry so the fixture stays small):
+    policy resize 80x60 -> 56x56 (internvla_n1_policy.py:105-116), processor (smart_resize -> 56x56, rescale, normalize, patchify),
+    look-down pair resize to 32x32 then / 255.0 (internvla_n1_agent.py:309-317), plus an up-scaling and a non-square case."""
+    from PIL import Image
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+
+    from oracle import preprocess as o_pp
+
+    rng = np.random.default_rng(2024)
+    frames = rng.integers(0, 256, (3, 60, 80, 3), dtype=np.uint8)
+    frames[1] = (np.linspace(0, 255, 60 * 80 * 3).reshape(60, 80, 3) % 256).astype(np.uint8)       # smooth ramp: exercises the rounding
+    rw = rh = 56
+    resized = np.stack([np.array(Image.fromarray(f).resize((rw, rh))) for f in frames])
+    proc = Qwen2VLImageProcessorPil()
+    hf = proc(images=[Image.fromarray(f) for f in resized], return_tensors="np")
+    s1 = np.stack([np.array(Image.fromarray(f).resize((32, 32))) / 255.0 for f in frames])
+    extra = [(frames[0], 100, 37), (frames[2][:33, :17], 40, 33)]                                    # (image, w, h): up-scale, identity height
+    extra_out = [np.array(Image.fromarray(np.ascontiguousarray(im)).resize((w, h))) for im, w, h in extra]
+    pv, grid = o_pp.qwen_pixel_values(frames, rw, rh)
+    diffs = [np.abs(o_pp.pil_resize(f, rw, rh).astype(int) - r.astype(int)).max() for f, r in zip(frames, resized)]
+    diffs += [np.abs(o_pp.pil_resize(np.ascontiguousarray(im), w, h).astype(int) - o.astype(int)).max() for (im, w, h), o in zip(extra, extra_out)]
+    diffs += [float(np.abs(pv - hf["pixel_values"]).max()), float(np.abs(o_pp.s1_frames(frames, 32) - s1).max())]
+    assert (grid == hf["image_grid_thw"]).all()
+    return dict(frames=torch.from_numpy(frames), resize_w=rw, resize_h=rh, resized=torch.from_numpy(resized),
+                pixel_values=torch.from_numpy(hf["pixel_values"]), image_grid_thw=torch.from_numpy(np.asarray(hf["image_grid_thw"])),
+                s1_size=32, s1=torch.from_numpy(s1),
+                extra=[dict(image=torch.from_numpy(np.ascontiguousarray(im)), w=w, h=h, out=torch.from_numpy(o)) for (im, w, h), o in zip(extra, extra_out)],
+                pillow=__import__("PIL").__version__, transformers=__import__("transformers").__version__,
+                oracle_max_abs_diff=float(max(diffs)))
+
+
+UNITS = {"preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

@@ -1,0 +1,103 @@
+"""Frame pre-processing: PIL 8-bit bicubic resize + HF Qwen2-VL rescale / normalize / patchify + the System-1 0..1
+frames, byte / integer work -> BIT-EXACT bar. Oracle = oracle/preprocess.py (numpy), pinned against tests/golden/preprocess.pt
+(outputs of PIL and the installed transformers image processor, oracle/make_golden.py) and against PIL itself when it is importable;
+the device kernels (internnav_amd.preprocess.FramePreprocessor) are compared with both."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess as o_pp
+
+GOLD = Path(__file__).resolve().parent / "golden" / "preprocess.pt"
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return torch.load(GOLD, weights_only=True)
+
+
+def test_oracle_reproduces_pil_and_hf_processor_fixture(gold):
+    frames = gold["frames"].numpy()
+    rw, rh = gold["resize_w"], gold["resize_h"]
+    for f, r in zip(frames, gold["resized"].numpy()):
+        assert np.array_equal(o_pp.pil_resize(f, rw, rh), r)
+    for e in gold["extra"]:
+        assert np.array_equal(o_pp.pil_resize(e["image"].numpy(), e["w"], e["h"]), e["out"].numpy())
+    pv, grid = o_pp.qwen_pixel_values(frames, rw, rh)
+    assert np.array_equal(pv, gold["pixel_values"].numpy()) and np.array_equal(grid, gold["image_grid_thw"].numpy())
+    assert np.array_equal(o_pp.s1_frames(frames, gold["s1_size"]), gold["s1"].numpy())
+
+
+def test_oracle_matches_live_pil_at_camera_size():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(7)
+    f = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    a = np.array(Image.fromarray(f).resize((384, 384)))
+    assert np.array_equal(o_pp.pil_resize(f, 384, 384), a)
+    assert o_pp.smart_resize(384, 384) == (392, 392) and o_pp.smart_resize(480, 640) == (476, 644)
+    assert np.array_equal(o_pp.pil_resize(a, 392, 392), np.array(Image.fromarray(a).resize((392, 392), resample=Image.BICUBIC)))
+    assert np.array_equal(o_pp.pil_resize(f, 224, 224), np.array(Image.fromarray(f).resize((224, 224))))
+
+
+def test_product_tables_are_the_oracle_tables():
+    """the host side of the product (coefficient tables, smart_resize, normalisation table) equals the oracle's restatement."""
+    from internnav_amd import preprocess as pp
+
+    for n_in, n_out in [(640, 384), (480, 384), (384, 392), (640, 224), (80, 56), (17, 40), (33, 33), (5, 64)]:
+        b, k = pp.pil_bicubic_tables(n_in, n_out)
+        ob, ok = o_pp.precompute_coeffs(n_in, n_out)
+        assert np.array_equal(b, np.asarray(ob, dtype=np.int32)) and np.array_equal(k, np.asarray(ok, dtype=np.int32))
+    for hw in [(384, 384), (480, 640), (30, 30), (3000, 4000), (56, 57)]:
+        assert pp.smart_resize(*hw) == o_pp.smart_resize(*hw)
+    v = (np.arange(256, dtype=np.float64) * (1 / 255)).astype(np.float32)
+    lut = pp.qwen_normalize_table()
+    for c in range(3):
+        assert np.array_equal(lut[c], (v - np.float32(o_pp.CLIP_MEAN[c])) / np.float32(o_pp.CLIP_STD[c]))
+
+
+@pytest.mark.gpu
+def test_device_resize_is_bit_exact(built_lib, gold):
+    from internnav_amd.preprocess import FramePreprocessor
+
+    pre = FramePreprocessor(DEV, resize_w=gold["resize_w"], resize_h=gold["resize_h"])
+    out = pre.resize(gold["frames"].to(DEV), gold["resize_w"], gold["resize_h"])
+    assert torch.equal(out.cpu(), gold["resized"])
+    for e in gold["extra"]:
+        o = pre.resize(e["image"][None].contiguous().to(DEV), e["w"], e["h"])
+        assert torch.equal(o[0].cpu(), e["out"])
+    # camera-sized frames, both passes down- and up-scaling, against the oracle (and PIL when present)
+    rng = np.random.default_rng(3)
+    f = rng.integers(0, 256, (2, 480, 640, 3), dtype=np.uint8)
+    for (w, h) in [(384, 384), (224, 224), (644, 476), (700, 500)]:
+        dev = pre.resize(torch.from_numpy(f).to(DEV), w, h).cpu().numpy()
+        ref = np.stack([o_pp.pil_resize(x, w, h) for x in f])
+        assert np.array_equal(dev, ref), (w, h)
+    try:
+        from PIL import Image
+
+        assert np.array_equal(pre.resize(torch.from_numpy(f).to(DEV), 384, 384).cpu().numpy()[0], np.array(Image.fromarray(f[0]).resize((384, 384))))
+    except ImportError:
+        pass
+
+
+@pytest.mark.gpu
+def test_device_qwen_pixel_values_and_s1_frames_are_bit_exact(built_lib, gold):
+    from internnav_amd.preprocess import FramePreprocessor
+
+    pre = FramePreprocessor(DEV, resize_w=gold["resize_w"], resize_h=gold["resize_h"])
+    pv, grid = pre.qwen_pixel_values(gold["frames"].to(DEV))
+    assert torch.equal(grid, gold["image_grid_thw"].to(torch.int64))
+    assert torch.equal(pv.cpu(), gold["pixel_values"].to(torch.bfloat16))          # the policy casts the processor output to bf16
+    s1 = pre.s1_frames(gold["frames"].to(DEV), gold["s1_size"])
+    assert torch.equal(s1.cpu(), gold["s1"].to(torch.bfloat16))
+    # full geometry of the deployment: 480x640 camera frame -> 384x384 -> 392x392 -> 784 patches x 1176
+    rng = np.random.default_rng(5)
+    f = rng.integers(0, 256, (1, 480, 640, 3), dtype=np.uint8)
+    full = FramePreprocessor(DEV)
+    pv2, grid2 = full.qwen_pixel_values(torch.from_numpy(f).to(DEV))
+    ref, gref = o_pp.qwen_pixel_values(f, 384, 384)
+    assert grid2.tolist() == gref.tolist() == [[1, 28, 28]]
+    assert torch.equal(pv2.cpu(), torch.from_numpy(ref).to(torch.bfloat16))
