@@ -42,9 +42,10 @@ class _EnvState:
 
 
 class InternVLAN1Agent:
-    def __init__(self, config, model=None, processor=None, policy_factory=None):
+    def __init__(self, config, model=None, processor=None, policy_factory=None, frame_preprocessor=None):
         """config: AgentCfg-like (attribute or dict `model_settings` with mode / infer_mode, sys2_max_forward_step, num_history,
-        resize_w/h, continuous_traj, device ...). `model` + `processor` (or a `policy_factory() -> InternVLAN1Net`) supply the policy."""
+        resize_w/h, continuous_traj, device ...). `model` + `processor` (or a `policy_factory() -> InternVLAN1Net`) supply the policy.
+        frame_preprocessor (internnav_amd.preprocess.FramePreprocessor): System-2 image pre-processing on the device."""
         self.config = config
         ms = getattr(config, "model_settings", None) or (config.get("model_settings") if isinstance(config, dict) else {}) or {}
         self.mode = ms.get("infer_mode", "sync")
@@ -57,7 +58,8 @@ class InternVLAN1Agent:
 
             def policy_factory():
                 return InternVLAN1Net(model, processor, num_history=ms.get("num_history", 8), resize_w=ms.get("resize_w", 384),
-                                      resize_h=ms.get("resize_h", 384), continuous_traj=ms.get("continuous_traj", True))
+                                      resize_h=ms.get("resize_h", 384), continuous_traj=ms.get("continuous_traj", True),
+                                      frame_preprocessor=frame_preprocessor)
         self._factory = policy_factory
         self.model = model
         self.envs: List[_EnvState] = []

@@ -283,8 +283,11 @@ class InternVLAN1Net:
     ACTIONS2IDX = OrderedDict({"STOP": [0], "↑": [1], "←": [2], "→": [3], "↓": [5]})
 
     def __init__(self, model: InternVLAN1ForCausalLM, processor, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
-                 continuous_traj: bool = True):
-        self.model, self.processor = model, processor
+                 continuous_traj: bool = True, frame_preprocessor=None):
+        """frame_preprocessor: an internnav_amd.preprocess.FramePreprocessor - the PIL resizes and the HF image processor then run on
+        the device from raw uint8 frames (bit-exact with the host path); the injected processor is only used for the chat template and
+        its tokenizer."""
+        self.model, self.processor, self.pre = model, processor, frame_preprocessor
         self.num_history, self.resize_w, self.resize_h, self.continuous_traj = num_history, resize_w, resize_h, continuous_traj
         self.device = model.device
         self.reset()
@@ -304,6 +307,9 @@ class InternVLAN1Net:
         return list(itertools.chain.from_iterable(self.ACTIONS2IDX[m] for m in regex.findall(output)))
 
     def _to_image(self, rgb, resize: bool):
+        if self.pre is not None:   # device path: uint8 [H, W, 3] tensors instead of PIL images
+            frame = torch.from_numpy(np.ascontiguousarray(np.asarray(rgb)[..., :3], dtype=np.uint8)).to(self.pre.device)
+            return self.pre.resize(frame[None], self.resize_w, self.resize_h)[0] if resize else frame
         from PIL import Image
 
         image = Image.fromarray(rgb).convert("RGB")
@@ -344,7 +350,20 @@ class InternVLAN1Net:
                 content.append({"type": "text", "text": part})
         self.conversation_history.append({"role": "user", "content": content})
         chat = self.processor.apply_chat_template(self.conversation_history, tokenize=False, add_generation_prompt=True)
-        return self.processor(text=[chat], images=self.input_images, return_tensors="pt")
+        if self.pre is None:
+            return self.processor(text=[chat], images=self.input_images, return_tensors="pt")
+        # device pre-processing: pixel_values / grid from the raw frames; the text side restates Qwen2VLProcessor.__call__ - every
+        # image placeholder is expanded to grid.prod() / merge^2 image tokens before tokenisation
+        pixel_values, grid = self.pre.processor_pixel_values(self.input_images)
+        tok = getattr(self.processor, "image_token", "<|image_pad|>")
+        merge2 = self.pre.merge ** 2
+        parts = chat.split(tok)
+        assert len(parts) == len(self.input_images) + 1, "chat template and image list disagree on the number of images"
+        expanded = parts[0]
+        for g, rest in zip(grid.tolist(), parts[1:]):
+            expanded += tok * (g[0] * g[1] * g[2] // merge2) + rest
+        enc = self.processor.tokenizer([expanded], return_tensors="pt")
+        return {"input_ids": enc["input_ids"], "pixel_values": pixel_values, "image_grid_thw": grid}
 
     def finish_s2(self, inputs, output_ids, latents_fn) -> S2Output:
         """steps 3-4 of s2_step (internvla_n1_policy.py:177-197): decode text, pixel goal -> latents, else discrete actions."""

@@ -128,6 +128,22 @@ class FramePreprocessor:
         ops.qwen_patchify_u8(x, pv, self.qwen_lut, self.ps, self.merge, self.tdup)
         return pv, torch.tensor([[1, gh, gw]] * n, dtype=torch.int64)
 
+    def processor_pixel_values(self, frames):
+        """the HF image processor alone, for a LIST of uint8 frames [H, W, 3] that may differ in size (history frames already at
+        resize_w x resize_h, the look-down frame at camera size): per frame smart_resize -> PIL bicubic -> rescale / normalize /
+        patchify, rows concatenated in list order -> (pixel_values bf16 [sum gh*gw, 1176], image_grid_thw int64 [n, 3])."""
+        pvs, grids = [], []
+        for f in frames:
+            H, W = int(f.shape[0]), int(f.shape[1])
+            hb, wb = smart_resize(H, W, self.ps * self.merge, self.min_pixels, self.max_pixels)
+            x = self.resize(f[None].contiguous(), wb, hb)
+            gh, gw = hb // self.ps, wb // self.ps
+            pv = torch.empty(gh * gw, 3 * self.tdup * self.ps * self.ps, dtype=torch.bfloat16, device=x.device)
+            ops.qwen_patchify_u8(x, pv, self.qwen_lut, self.ps, self.merge, self.tdup)
+            pvs.append(pv)
+            grids.append([1, gh, gw])
+        return torch.cat(pvs, 0), torch.tensor(grids, dtype=torch.int64)
+
     def s1_frames(self, frames: torch.Tensor, size: int = 224) -> torch.Tensor:
         """raw frames -> bf16 [n, size, size, 3] in 0..1: np.array(Image.fromarray(f).resize((size, size))) / 255.0."""
         x = self.resize(frames, size, size)

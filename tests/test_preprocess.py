@@ -101,3 +101,94 @@ def test_device_qwen_pixel_values_and_s1_frames_are_bit_exact(built_lib, gold):
     ref, gref = o_pp.qwen_pixel_values(f, 384, 384)
     assert grid2.tolist() == gref.tolist() == [[1, 28, 28]]
     assert torch.equal(pv2.cpu(), torch.from_numpy(ref).to(torch.bfloat16))
+
+
+class _OraclePre:
+    """CPU stand-in with the FramePreprocessor interface (numpy oracle instead of the device kernels): exercises the policy wiring."""
+    device, merge = torch.device("cpu"), 2
+
+    def resize(self, frames, w, h):
+        return torch.from_numpy(np.stack([o_pp.pil_resize(f.numpy(), w, h) for f in frames]))
+
+    def processor_pixel_values(self, frames):
+        pvs, grids = [], []
+        for f in frames:
+            H, W = f.shape[:2]
+            pv, g = o_pp.qwen_pixel_values([f.numpy()], W, H)      # resize_w/h = the frame's own size: only the processor's resize acts
+            pvs.append(torch.from_numpy(pv).to(torch.bfloat16))
+            grids.append(g[0].tolist())
+        return torch.cat(pvs, 0), torch.tensor(grids, dtype=torch.int64)
+
+
+class _Tok:
+    IMG = "<|image_pad|>"
+
+    def __call__(self, texts, return_tensors="pt"):
+        ids = []
+        for part in texts[0].replace(self.IMG, "\\x00").split("\\x00"):
+            ids += [ord(c) % 500 for c in part] + [1001]
+        return {"input_ids": torch.tensor([ids[:-1]])}
+
+    def decode(self, ids, skip_special_tokens=True):
+        return "".join(chr(int(i)) for i in ids)
+
+
+class _Proc:
+    image_token, tokenizer = _Tok.IMG, _Tok()
+
+    def apply_chat_template(self, conv, tokenize=False, add_generation_prompt=True):
+        return "".join("<|vision_start|>" + _Tok.IMG + "<|vision_end|>" if c["type"] == "image" else c["text"] for t in conv for c in t["content"])
+
+
+def test_policy_device_preprocess_wiring_matches_host_path():
+    """InternVLAN1Net with a frame pre-processor: history frames are resized once on arrival, the look-down frame goes in at camera
+    size, every image placeholder expands to grid.prod() / 4 image tokens (Qwen2VLProcessor.__call__), and pixel_values equal the
+    host path (PIL resize + HF processor arithmetic) bit for bit."""
+    from types import SimpleNamespace
+
+    from internnav_amd.policy import InternVLAN1Net
+
+    net = InternVLAN1Net(SimpleNamespace(device=torch.device("cpu")), _Proc(), num_history=3, resize_w=56, resize_h=56, frame_preprocessor=_OraclePre())
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (60, 80, 3), dtype=np.uint8) for _ in range(4)]
+    for f in frames[:3]:
+        net.step_no_infer(f, None, None)
+    inp = net.build_s2_inputs(frames[3], "go to the door")
+    n_hist = len(np.unique(np.linspace(0, 2, 3, dtype=np.int32)))
+    assert inp["image_grid_thw"].tolist() == [[1, 4, 4]] * (n_hist + 1)
+    assert int((inp["input_ids"] == 1001).sum()) == 4 * (n_hist + 1)                      # 16 patches / merge^2 per image
+    ref_pv, _ = o_pp.qwen_pixel_values(frames, 56, 56)
+    assert torch.equal(inp["pixel_values"], torch.from_numpy(ref_pv).to(torch.bfloat16))
+    # look-down frame: appended at camera size (60 x 80 -> smart_resize 56 x 84 = 4 x 6 patches)
+    net.llm_output = "↓"
+    look = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    inp2 = net.build_s2_inputs(look, "go to the door", look_down=True)
+    assert inp2["image_grid_thw"].tolist()[-1] == [1, 4, 6] and int((inp2["input_ids"] == 1001).sum()) == 4 * (n_hist + 1) + 6
+    ref_look, _ = o_pp.qwen_pixel_values([look], 80, 60)
+    assert torch.equal(inp2["pixel_values"][-24:], torch.from_numpy(ref_look).to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_device_processor_pixel_values_mixed_sizes_in_the_policy(built_lib):
+    """the wired path on the device: history frames resized on arrival + camera-sized look-down frame through InternVLAN1Net."""
+    from types import SimpleNamespace
+
+    from internnav_amd.policy import InternVLAN1Net
+    from internnav_amd.preprocess import FramePreprocessor
+
+    pre = FramePreprocessor(DEV, resize_w=56, resize_h=56)
+    net = InternVLAN1Net(SimpleNamespace(device=torch.device(DEV)), _Proc(), num_history=3, resize_w=56, resize_h=56, frame_preprocessor=pre)
+    rng = np.random.default_rng(11)
+    frames = [rng.integers(0, 256, (60, 80, 3), dtype=np.uint8) for _ in range(4)]
+    for f in frames[:3]:
+        net.step_no_infer(f, None, None)
+    inp = net.build_s2_inputs(frames[3], "go to the door")
+    ref_pv, ref_grid = o_pp.qwen_pixel_values(frames, 56, 56)
+    assert inp["image_grid_thw"].tolist() == ref_grid.tolist()
+    assert torch.equal(inp["pixel_values"].cpu(), torch.from_numpy(ref_pv).to(torch.bfloat16))
+    net.llm_output = "↓"
+    look = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    inp2 = net.build_s2_inputs(look, "go to the door", look_down=True)
+    ref_look, _ = o_pp.qwen_pixel_values([look], 80, 60)
+    assert inp2["image_grid_thw"].tolist()[-1] == [1, 4, 6]
+    assert torch.equal(inp2["pixel_values"][-24:].cpu(), torch.from_numpy(ref_look).to(torch.bfloat16))
