@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -291,6 +291,17 @@ typedef struct ina_resize_u8_args {
     int32_t outer, n_in, n_out, inner, ksize, _pad;
 } ina_resize_u8_args;
 int ina_resize_u8(const ina_resize_u8_args* args, void* stream);
+
+/*      resize_f32: the same for PIL mode "F" images (the depth frames, internvla_n1_agent.py:313,319): double coefficients, double
+ *      accumulation in tap order, one rounding to float (ImagingResampleHorizontal_32bpc / Vertical_32bpc). */
+typedef struct ina_resize_f32_args {
+    const void* in;         /* f32 [outer, n_in, inner] */
+    void* out;              /* f32 [outer, n_out, inner] */
+    const int32_t* bounds;  /* int32 [n_out, 2] */
+    const double* coefs;    /* f64 [n_out, ksize] */
+    int32_t outer, n_in, n_out, inner, ksize, _pad;
+} ina_resize_f32_args;
+int ina_resize_f32(const ina_resize_f32_args* args, void* stream);
 
 /*      qwen_patchify_u8: HF Qwen2VLImageProcessor rescale + normalize (as a 3 x 256 fp32 table computed with the processor's own
  *      arithmetic) + patchify: rows (grid_h/merge, grid_w/merge, merge, merge), columns (C, tdup copies, ps, ps); bf16 out.

@@ -167,6 +167,11 @@ class U8LutArgs(C.Structure):
     _fields_ = [("in_", c_void_p), ("out", c_void_p), ("lut", c_void_p), ("n", c_int64)]
 
 
+class ResizeF32Args(C.Structure):
+    _fields_ = [("in_", c_void_p), ("out", c_void_p), ("bounds", c_void_p), ("coefs", c_void_p),
+                ("outer", c_int32), ("n_in", c_int32), ("n_out", c_int32), ("inner", c_int32), ("ksize", c_int32), ("_pad", c_int32)]
+
+
 class SelectArgs(C.Structure):
     _fields_ = [
         ("critic", c_void_p), ("sample", c_void_p), ("neg", c_void_p), ("pos", c_void_p),
@@ -198,6 +203,7 @@ SYMBOLS = {
     "ina_resize_u8": (C.c_int, [C.POINTER(ResizeU8Args), c_void_p]),
     "ina_qwen_patchify_u8": (C.c_int, [C.POINTER(QwenPatchifyArgs), c_void_p]),
     "ina_u8_lut": (C.c_int, [C.POINTER(U8LutArgs), c_void_p]),
+    "ina_resize_f32": (C.c_int, [C.POINTER(ResizeF32Args), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_prof_enable": (C.c_int, [C.c_int]),

@@ -61,6 +61,7 @@ class InternVLAN1Agent:
                                       resize_h=ms.get("resize_h", 384), continuous_traj=ms.get("continuous_traj", True),
                                       frame_preprocessor=frame_preprocessor)
         self._factory = policy_factory
+        self.pre = frame_preprocessor
         self.model = model
         self.envs: List[_EnvState] = []
         self.episode_idx = 0
@@ -201,8 +202,27 @@ class InternVLAN1Agent:
         d[d > self.sys1_depth_threshold] = self.sys1_depth_threshold
         return r, d
 
+    def _prep_s1_device(self, jobs):
+        """the look-down pairs of all jobs in one device batch (frame pre-processor): PIL 8-bit / float bicubic resize to 224 x 224,
+        rgb / 255.0 and depth x10 clipped - the same values as _prep_s1, computed from the raw frames on the device."""
+        dev = self.pre.device
+        rgb = np.stack([np.asarray(f)[..., :3] for e, o in jobs for f in (e.s2_output.rgb_memory, o["rgb"])]).astype(np.uint8, copy=False)
+        dep = np.stack([np.asarray(d)[:, :, 0] for e, o in jobs for d in (e.s2_output.depth_memory, o["depth"])]).astype(np.float32, copy=False)
+        r = self.pre.unit_lut[self.pre.resize(torch.from_numpy(np.ascontiguousarray(rgb)).to(dev), 224, 224).long()]
+        d = self.pre.s1_depth(torch.from_numpy(np.ascontiguousarray(dep)).to(dev), 224, 10.0, self.sys1_depth_threshold)
+        n = len(jobs)
+        return r.view(n, 2, 224, 224, 3), d.view(n, 2, 224, 224, 1)
+
     def _run_s1(self, jobs):
         model = jobs[0][0].policy.model
+        if self.pre is not None and self.mode != "sync" and len({np.asarray(f).shape for e, o in jobs for f in (e.s2_output.rgb_memory, o["rgb"])}) == 1:
+            rgb_t, dep_t = self._prep_s1_device(jobs)
+            lats = [e.s2_output.output_latent for e, _ in jobs]
+            traj = model.generate_traj(traj_latents=torch.cat(lats, 0), images_dp=rgb_t.to(model.device), depths_dp=dep_t.to(model.device))
+            S = traj.shape[0] // len(jobs)
+            for k, (e, _) in enumerate(jobs):
+                e.s1_output = e.policy.actions_from_traj(traj[k * S:(k + 1) * S])
+            return
         rgbs, depths, lats = [], [], []
         for e, o in jobs:
             so = e.s2_output

@@ -134,7 +134,7 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
 }
 
 /* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify,
- * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut */
+ * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32 */
 int ina_struct_size(int k) {
     switch (k) {
         case 0: return (int)sizeof(ina_gemm_args);
@@ -155,6 +155,7 @@ int ina_struct_size(int k) {
         case 15: return (int)sizeof(ina_resize_u8_args);
         case 16: return (int)sizeof(ina_qwen_patchify_args);
         case 17: return (int)sizeof(ina_u8_lut_args);
+        case 18: return (int)sizeof(ina_resize_f32_args);
         default: return -1;
     }
 }
@@ -178,6 +179,7 @@ INA_ENTRY(ina_gemm_rownorm_bf16, ina_gemm_rownorm_args, ina_launch_gemm_rownorm)
 INA_ENTRY(ina_resize_u8, ina_resize_u8_args, ina_launch_resize_u8)
 INA_ENTRY(ina_qwen_patchify_u8, ina_qwen_patchify_args, ina_launch_qwen_patchify_u8)
 INA_ENTRY(ina_u8_lut, ina_u8_lut_args, ina_launch_u8_lut)
+INA_ENTRY(ina_resize_f32, ina_resize_f32_args, ina_launch_resize_f32)
 INA_ENTRY(ina_argmax_rows, ina_argmax_args, ina_launch_argmax)
 #undef INA_ENTRY
 

@@ -26,6 +26,7 @@ using GemmRownormArgs = ina_gemm_rownorm_args;
 using ResizeU8Args = ina_resize_u8_args;
 using QwenPatchifyArgs = ina_qwen_patchify_args;
 using U8LutArgs = ina_u8_lut_args;
+using ResizeF32Args = ina_resize_f32_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
@@ -47,4 +48,5 @@ int ina_launch_gemm_rownorm(const GemmRownormArgs& p, hipStream_t stream);  // N
 int ina_launch_resize_u8(const ResizeU8Args& p, hipStream_t stream);            // one axis of PIL's 8-bit bicubic resample
 int ina_launch_qwen_patchify_u8(const QwenPatchifyArgs& p, hipStream_t stream);  // HF Qwen2-VL rescale + normalize + patchify from bytes
 int ina_launch_u8_lut(const U8LutArgs& p, hipStream_t stream);
+int ina_launch_resize_f32(const ResizeF32Args& p, hipStream_t stream);          // one axis of PIL's float ("F" mode) bicubic resample
 int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream);  // q/k-LayerNorm + self-attention + gated cross-attention of a NextDiT block

@@ -37,6 +37,27 @@ __global__ __launch_bounds__(256) void resize_u8_kernel(ResizeU8Args p) {
     }
 }
 
+// PIL's 32-bit-float resample (mode "F": the depth frames): double accumulation in tap order with double coefficients, one rounding
+// to float at the end (ImagingResampleHorizontal_32bpc / Vertical_32bpc). Products and sums are kept as separate IEEE operations
+// (__dmul_rn / __dadd_rn): the host library is built without FMA contraction.
+__global__ __launch_bounds__(256) void resize_f32_kernel(ResizeF32Args p) {
+    const long total = (long)p.outer * p.n_out * p.inner;
+    const float* __restrict__ in = reinterpret_cast<const float*>(p.in);
+    float* __restrict__ out = reinterpret_cast<float*>(p.out);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ii = (int)(idx % p.inner);
+        const long t = idx / p.inner;
+        const int xx = (int)(t % p.n_out);
+        const long o = t / p.n_out;
+        const int xmin = p.bounds[2 * xx], xmax = p.bounds[2 * xx + 1];
+        const double* __restrict__ k = p.coefs + (size_t)xx * p.ksize;
+        const float* src = in + ((size_t)o * p.n_in + xmin) * p.inner + ii;
+        double ss = 0.0;
+        for (int x = 0; x < xmax; ++x) ss = __dadd_rn(ss, __dmul_rn((double)src[(size_t)x * p.inner], k[x]));
+        out[idx] = (float)ss;
+    }
+}
+
 __global__ __launch_bounds__(256) void qwen_patchify_u8_kernel(QwenPatchifyArgs p) {
     const int gh = p.H / p.ps, gw = p.W / p.ps, m = p.merge;
     const int pp = p.ps * p.ps, cols = 3 * p.tdup * pp;
@@ -72,6 +93,17 @@ int ina_launch_resize_u8(const ResizeU8Args& p, hipStream_t stream) {
     const long total = (long)p.outer * p.n_out * p.inner;
     InaProfScope prof(INA_PROF_ELEMENTWISE, 2.0 * total * p.ksize, (double)p.outer * p.inner * (p.n_in + p.n_out), stream);
     hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int ina_launch_resize_f32(const ResizeF32Args& p, hipStream_t stream) {
+    INA_REQUIRE(p.in && p.out && p.bounds && p.coefs, "resize_f32: null pointer");
+    INA_REQUIRE(p.outer > 0 && p.n_in > 0 && p.n_out > 0 && p.inner > 0 && p.ksize > 0, "resize_f32: bad geometry outer=%d n_in=%d n_out=%d inner=%d ksize=%d",
+                p.outer, p.n_in, p.n_out, p.inner, p.ksize);
+    const long total = (long)p.outer * p.n_out * p.inner;
+    InaProfScope prof(INA_PROF_ELEMENTWISE, 2.0 * total * p.ksize, 4.0 * p.outer * p.inner * (p.n_in + p.n_out), stream);
+    hipLaunchKernelGGL(resize_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -472,3 +472,22 @@ def u8_lut(x: torch.Tensor, out: torch.Tensor, lut: torch.Tensor) -> torch.Tenso
     a.in_, a.out, a.lut, a.n = x.data_ptr(), out.data_ptr(), lut.data_ptr(), x.numel()
     _lib.check(_lib.lib().ina_u8_lut(C.byref(a), _stream()), "u8_lut")
     return out
+
+
+def resize_f32(x: torch.Tensor, out: torch.Tensor, bounds: torch.Tensor, coefs: torch.Tensor, axis: int) -> torch.Tensor:
+    """one axis of PIL's float ("F" mode) bicubic resample: x f32 contiguous, coefs f64 [n_out, ksize], bounds int32 [n_out, 2]."""
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
+    assert bounds.dtype == torch.int32 and coefs.dtype == torch.float64 and bounds.is_contiguous() and coefs.is_contiguous()
+    n_out = bounds.shape[0]
+    outer = 1
+    for d in x.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in x.shape[axis + 1:]:
+        inner *= d
+    assert out.shape[axis] == n_out and out.numel() == outer * n_out * inner and coefs.shape[0] == n_out
+    a = _lib.ResizeF32Args()
+    a.in_, a.out, a.bounds, a.coefs = x.data_ptr(), out.data_ptr(), bounds.data_ptr(), coefs.data_ptr()
+    a.outer, a.n_in, a.n_out, a.inner, a.ksize = outer, x.shape[axis], n_out, inner, coefs.shape[1]
+    _lib.check(_lib.lib().ina_resize_f32(C.byref(a), _stream()), "resize_f32")
+    return out

@@ -38,8 +38,9 @@ def _bicubic(x: float, a: float = -0.5) -> float:
     return 0.0
 
 
-def pil_bicubic_tables(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
-    """(bounds int32 [out, 2], coefs int32 [out, ksize]) of Pillow's 8-bit bicubic resample from in_size to out_size samples."""
+def pil_bicubic_tables(in_size: int, out_size: int, fixed_point: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """(bounds int32 [out, 2], coefs [out, ksize]) of Pillow's bicubic resample from in_size to out_size samples: int32 22-bit fixed
+    point for 8-bit images (normalize_coeffs_8bpc), the float64 weights themselves for mode "F" images (fixed_point=False)."""
     scale = filterscale = in_size / out_size
     if filterscale < 1.0:
         filterscale = 1.0
@@ -60,6 +61,8 @@ def pil_bicubic_tables(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndar
         if ww != 0.0:
             kk[xx, :xmax] /= ww
         bounds[xx] = (xmin, xmax)
+    if not fixed_point:
+        return bounds, kk
     fixed = np.where(kk < 0, (-0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64), (0.5 + kk * (1 << PRECISION_BITS)).astype(np.int64))
     return bounds, fixed.astype(np.int32)
 
@@ -94,6 +97,7 @@ class FramePreprocessor:
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
         self.ps, self.merge, self.tdup = patch_size, merge_size, temporal_patch_size
         self._tables: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._tables_f: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self.qwen_lut = torch.from_numpy(qwen_normalize_table()).to(self.device)
         self.unit_lut = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32)).to(self.device)  # np.array(img) / 255.0
 
@@ -116,6 +120,30 @@ class FramePreprocessor:
             out = torch.empty(n, h, x.shape[2], Cc, dtype=torch.uint8, device=frames.device)
             x = ops.resize_u8(x, out, *self._table(H, h), axis=1)
         return x
+
+    def resize_f32(self, frames: torch.Tensor, w: int, h: int) -> torch.Tensor:
+        """PIL Image.resize((w, h)) of mode "F" images (float32 [n, H, W]): double accumulation, horizontal then vertical pass."""
+        assert frames.dtype == torch.float32 and frames.dim() == 3 and frames.is_contiguous()
+
+        def table(n_in, n_out):
+            if (n_in, n_out) not in self._tables_f:
+                b, k = pil_bicubic_tables(n_in, n_out, fixed_point=False)
+                self._tables_f[(n_in, n_out)] = (torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device))
+            return self._tables_f[(n_in, n_out)]
+
+        n, H, W = frames.shape
+        x = frames
+        if W != w:
+            x = ops.resize_f32(x, torch.empty(n, H, w, dtype=torch.float32, device=frames.device), *table(W, w), axis=2)
+        if H != h:
+            x = ops.resize_f32(x, torch.empty(n, h, x.shape[2], dtype=torch.float32, device=frames.device), *table(H, h), axis=1)
+        return x
+
+    def s1_depth(self, depth: torch.Tensor, size: int = 224, scale: float = 10.0, clip: float = 5.0) -> torch.Tensor:
+        """depth f32 [n, H, W] (metres / 10) -> f32 [n, size, size]: np.array(Image.fromarray(d).resize((size, size))) * 10.0, values
+        above the threshold set to it (internvla_n1_agent.py:313-316)."""
+        x = self.resize_f32(depth, size, size) * scale
+        return torch.where(x > clip, torch.full_like(x, clip), x)
 
     def qwen_pixel_values(self, frames: torch.Tensor):
         """raw frames -> (pixel_values bf16 [n * gh * gw, 1176], image_grid_thw int64 [n, 3]) exactly as

@@ -368,14 +368,23 @@ def gold_preprocess():
     s1 = np.stack([np.array(Image.fromarray(f).resize((32, 32))) / 255.0 for f in frames])
     extra = [(frames[0], 100, 37), (frames[2][:33, :17], 40, 33)]                                    # (image, w, h): up-scale, identity height
     extra_out = [np.array(Image.fromarray(np.ascontiguousarray(im)).resize((w, h))) for im, w, h in extra]
+    depth = (rng.random((2, 60, 80), dtype=np.float32) * 0.8).astype(np.float32)                      # metres / 10, some beyond the 5 m clip
+    s1d = []
+    for d in depth:
+        x = np.array(Image.fromarray(d).resize((32, 32))) * 10.0
+        x[x > 5.0] = 5.0
+        s1d.append(x)
+    s1d = np.stack(s1d)
     pv, grid = o_pp.qwen_pixel_values(frames, rw, rh)
     diffs = [np.abs(o_pp.pil_resize(f, rw, rh).astype(int) - r.astype(int)).max() for f, r in zip(frames, resized)]
     diffs += [np.abs(o_pp.pil_resize(np.ascontiguousarray(im), w, h).astype(int) - o.astype(int)).max() for (im, w, h), o in zip(extra, extra_out)]
     diffs += [float(np.abs(pv - hf["pixel_values"]).max()), float(np.abs(o_pp.s1_frames(frames, 32) - s1).max())]
+    diffs += [float(np.abs(o_pp.s1_depth(depth, 32) - s1d).max())]
+    assert np.array_equal(o_pp.s1_depth(depth, 32), s1d)
     assert (grid == hf["image_grid_thw"]).all()
     return dict(frames=torch.from_numpy(frames), resize_w=rw, resize_h=rh, resized=torch.from_numpy(resized),
                 pixel_values=torch.from_numpy(hf["pixel_values"]), image_grid_thw=torch.from_numpy(np.asarray(hf["image_grid_thw"])),
-                s1_size=32, s1=torch.from_numpy(s1),
+                s1_size=32, s1=torch.from_numpy(s1), depth=torch.from_numpy(depth), s1_depth=torch.from_numpy(s1d),
                 extra=[dict(image=torch.from_numpy(np.ascontiguousarray(im)), w=w, h=h, out=torch.from_numpy(o)) for (im, w, h), o in zip(extra, extra_out)],
                 pillow=__import__("PIL").__version__, transformers=__import__("transformers").__version__,
                 oracle_max_abs_diff=float(max(diffs)))

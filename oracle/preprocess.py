@@ -79,6 +79,50 @@ def pil_resize(img, w, h):
     return img
 
 
+def resample_axis_f32(img, out_size, axis):
+    """one pass of PIL's 32-bit float resample (mode "F", ImagingResampleHorizontal_32bpc / Vertical_32bpc): double weights (not
+    quantised), double accumulation in tap order, rounded to float once."""
+    x = np.moveaxis(img, axis, 0).astype(np.float64)
+    scale = filterscale = x.shape[0] / out_size
+    filterscale = max(filterscale, 1.0)
+    support = 2.0 * filterscale
+    out = np.empty((out_size,) + x.shape[1:], dtype=np.float32)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), x.shape[0]) - xmin
+        k = [bicubic_filter((j + xmin - center + 0.5) * (1.0 / filterscale)) for j in range(xmax)]   # Resample.c multiplies by ss = 1 / filterscale
+        ww = 0.0
+        for w in k:
+            ww += w
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        ss = np.zeros(x.shape[1:], dtype=np.float64)
+        for j in range(xmax):
+            ss = ss + x[xmin + j] * k[j]
+        out[xx] = ss.astype(np.float32)
+    return np.moveaxis(out, 0, axis)
+
+
+def pil_resize_f32(img, w, h):
+    """Image.fromarray(img).resize((w, h)) for float32 [H, W] (mode "F")."""
+    if img.shape[1] != w:
+        img = resample_axis_f32(img, w, 1)
+    if img.shape[0] != h:
+        img = resample_axis_f32(img, h, 0)
+    return img
+
+
+def s1_depth(depth, size=224, threshold=5.0):
+    """np.array(Image.fromarray(d).resize((size, size))) * 10.0 with values above the threshold set to it (internvla_n1_agent.py:313-316)."""
+    out = []
+    for d in depth:
+        x = pil_resize_f32(np.asarray(d, dtype=np.float32), size, size) * 10.0
+        x[x > threshold] = threshold
+        out.append(x)
+    return np.stack(out)
+
+
 def smart_resize(height, width, factor=28, min_pixels=56 * 56, max_pixels=14 * 14 * 4 * 1280):
     h_bar, w_bar = round(height / factor) * factor, round(width / factor) * factor
     if h_bar * w_bar > max_pixels:

@@ -29,6 +29,7 @@ def test_oracle_reproduces_pil_and_hf_processor_fixture(gold):
     pv, grid = o_pp.qwen_pixel_values(frames, rw, rh)
     assert np.array_equal(pv, gold["pixel_values"].numpy()) and np.array_equal(grid, gold["image_grid_thw"].numpy())
     assert np.array_equal(o_pp.s1_frames(frames, gold["s1_size"]), gold["s1"].numpy())
+    assert np.array_equal(o_pp.s1_depth(gold["depth"].numpy(), gold["s1_size"]), gold["s1_depth"].numpy())      # PIL mode "F" path
 
 
 def test_oracle_matches_live_pil_at_camera_size():
@@ -40,6 +41,8 @@ def test_oracle_matches_live_pil_at_camera_size():
     assert o_pp.smart_resize(384, 384) == (392, 392) and o_pp.smart_resize(480, 640) == (476, 644)
     assert np.array_equal(o_pp.pil_resize(a, 392, 392), np.array(Image.fromarray(a).resize((392, 392), resample=Image.BICUBIC)))
     assert np.array_equal(o_pp.pil_resize(f, 224, 224), np.array(Image.fromarray(f).resize((224, 224))))
+    d = (rng.random((480, 640), dtype=np.float32) * 0.7).astype(np.float32)
+    assert np.array_equal(o_pp.pil_resize_f32(d, 224, 224), np.array(Image.fromarray(d).resize((224, 224))))
 
 
 def test_product_tables_are_the_oracle_tables():
@@ -50,6 +53,8 @@ def test_product_tables_are_the_oracle_tables():
         b, k = pp.pil_bicubic_tables(n_in, n_out)
         ob, ok = o_pp.precompute_coeffs(n_in, n_out)
         assert np.array_equal(b, np.asarray(ob, dtype=np.int32)) and np.array_equal(k, np.asarray(ok, dtype=np.int32))
+    bf, kf = pp.pil_bicubic_tables(640, 224, fixed_point=False)
+    assert kf.dtype == np.float64 and np.array_equal(bf, pp.pil_bicubic_tables(640, 224)[0]) and np.allclose(kf.sum(1), 1.0, atol=1e-12)
     for hw in [(384, 384), (480, 640), (30, 30), (3000, 4000), (56, 57)]:
         assert pp.smart_resize(*hw) == o_pp.smart_resize(*hw)
     v = (np.arange(256, dtype=np.float64) * (1 / 255)).astype(np.float32)
@@ -93,6 +98,11 @@ def test_device_qwen_pixel_values_and_s1_frames_are_bit_exact(built_lib, gold):
     assert torch.equal(pv.cpu(), gold["pixel_values"].to(torch.bfloat16))          # the policy casts the processor output to bf16
     s1 = pre.s1_frames(gold["frames"].to(DEV), gold["s1_size"])
     assert torch.equal(s1.cpu(), gold["s1"].to(torch.bfloat16))
+    dd = pre.s1_depth(gold["depth"].to(DEV), gold["s1_size"])
+    assert torch.equal(dd.cpu(), gold["s1_depth"])                                   # float resample: bit-exact fp32
+    rng0 = np.random.default_rng(9)
+    big = (rng0.random((2, 480, 640), dtype=np.float32) * 0.7).astype(np.float32)
+    assert np.array_equal(pre.s1_depth(torch.from_numpy(big).to(DEV)).cpu().numpy(), o_pp.s1_depth(big))
     # full geometry of the deployment: 480x640 camera frame -> 384x384 -> 392x392 -> 784 patches x 1176
     rng = np.random.default_rng(5)
     f = rng.integers(0, 256, (1, 480, 640, 3), dtype=np.uint8)
@@ -192,3 +202,31 @@ def test_device_processor_pixel_values_mixed_sizes_in_the_policy(built_lib):
     ref_look, _ = o_pp.qwen_pixel_values([look], 80, 60)
     assert inp2["image_grid_thw"].tolist()[-1] == [1, 4, 6]
     assert torch.equal(inp2["pixel_values"][-24:].cpu(), torch.from_numpy(ref_look).to(torch.bfloat16))
+
+
+def test_agent_s1_device_preprocess_equals_host_path():
+    """InternVLAN1Agent._prep_s1_device (one batch for all jobs) == the per-frame host path _prep_s1 (PIL + numpy), bit for bit."""
+    pytest.importorskip("PIL.Image")
+    from types import SimpleNamespace
+
+    from internnav_amd.agent import InternVLAN1Agent
+
+    class Pre(_OraclePre):
+        unit_lut = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32))
+
+        def s1_depth(self, depth, size=224, scale=10.0, clip=5.0):
+            return torch.from_numpy(o_pp.s1_depth(depth.numpy(), size, clip))
+
+    ag = InternVLAN1Agent({"model_settings": {"infer_mode": "partial_async"}}, policy_factory=lambda: None, frame_preprocessor=Pre())
+    rng = np.random.default_rng(21)
+    jobs = []
+    for _ in range(2):
+        mk = lambda: (rng.integers(0, 256, (48, 64, 3), dtype=np.uint8), (rng.random((48, 64, 1), dtype=np.float32) * 0.8).astype(np.float32))
+        (r0, d0), (r1, d1) = mk(), mk()
+        jobs.append((SimpleNamespace(s2_output=SimpleNamespace(rgb_memory=r0, depth_memory=d0)), {"rgb": r1, "depth": d1}))
+    rgb_t, dep_t = ag._prep_s1_device(jobs)
+    for k, (e, o) in enumerate(jobs):
+        for j, (rgb, dep) in enumerate(((e.s2_output.rgb_memory, e.s2_output.depth_memory), (o["rgb"], o["depth"]))):
+            r, d = ag._prep_s1(rgb, dep)
+            assert torch.equal(rgb_t[k, j], torch.from_numpy(r).to(torch.float32))
+            assert torch.equal(dep_t[k, j, ..., 0], torch.from_numpy(d))
