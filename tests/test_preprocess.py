@@ -230,3 +230,69 @@ def test_agent_s1_device_preprocess_equals_host_path():
             r, d = ag._prep_s1(rgb, dep)
             assert torch.equal(rgb_t[k, j], torch.from_numpy(r).to(torch.float32))
             assert torch.equal(dep_t[k, j, ..., 0], torch.from_numpy(d))
+
+
+def test_agent_step_with_frame_preprocessor_end_to_end():
+    """the batched agent stepping with the device pre-processing interface (oracle-backed stand-in on CPU): System-2 prompt building,
+    grouping, discrete actions, pixel goal -> latent -> System-1 with the batched look-down pre-processing; same actions as without."""
+    pytest.importorskip("PIL.Image")
+    from types import SimpleNamespace
+
+    from internnav_amd.agent import InternVLAN1Agent
+
+    class Pre(_OraclePre):
+        unit_lut = torch.from_numpy((np.arange(256, dtype=np.float64) / 255.0).astype(np.float32))
+
+        def s1_depth(self, depth, size=224, scale=10.0, clip=5.0):
+            return torch.from_numpy(o_pp.s1_depth(depth.numpy(), size, clip))
+
+    class Model:
+        device = torch.device("cpu")
+
+        def __init__(self, answers):
+            self.answers, self.s1_inputs, self.pv = list(answers), [], []
+
+        def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, **kw):
+            assert pixel_values.shape[0] == int(image_grid_thw.prod(1).sum())      # (host path: fp32 from the processor, device path: bf16)
+            self.pv.append(pixel_values.to(torch.bfloat16).cpu())
+            B = input_ids.shape[0]
+            ans = [self.answers.pop(0) for _ in range(B)]
+            n = max(len(a) for a in ans)
+            toks = torch.tensor([[ord(c) for c in a] + [0] * (n - len(a)) for a in ans])
+            return SimpleNamespace(sequences=torch.cat([input_ids, toks], 1))
+
+        def generate_latents(self, seqs, pv, grid):
+            return torch.zeros(seqs.shape[0], 4, 8)
+
+        def generate_traj(self, traj_latents=None, images_dp=None, depths_dp=None):
+            self.s1_inputs.append((images_dp.clone(), depths_dp.clone()))
+            t = torch.zeros(traj_latents.shape[0] * 32, 32, 3)
+            t[:, :, 0] = 1.0
+            return t
+
+    rng = np.random.default_rng(33)
+    obs = [{"rgb": rng.integers(0, 256, (60, 80, 3), dtype=np.uint8), "depth": (rng.random((60, 80, 1), dtype=np.float32) * 0.6).astype(np.float32),
+            "instruction": ins} for ins in ("go to the door", "go to the wall")]
+    outs, s1_in, pvs = [], [], []
+    for pre in (None, Pre()):
+        model = Model(["↑←", "12 34"])
+        ag = InternVLAN1Agent({"model_settings": {"infer_mode": "partial_async", "resize_w": 56, "resize_h": 56}}, model=model, processor=_Proc(),
+                              frame_preprocessor=pre)
+        if pre is None:   # host path needs a processor call: give the fake one the HF behaviour through the oracle
+            def call(text, images, return_tensors="pt", _tok=_Proc.tokenizer):
+                fr = [np.array(im) for im in images]
+                pvs, grids = zip(*[o_pp.qwen_pixel_values([f], f.shape[1], f.shape[0]) for f in fr])
+                grid = np.concatenate(grids)
+                parts = text[0].split(_Tok.IMG)
+                exp = parts[0] + "".join(_Tok.IMG * int(g.prod() // 4) + r for g, r in zip(grid, parts[1:]))
+                return {"input_ids": _tok([exp])["input_ids"], "pixel_values": torch.from_numpy(np.concatenate(pvs)), "image_grid_thw": torch.from_numpy(grid)}
+            ag_proc = type("P", (_Proc,), {"__call__": staticmethod(call)})()
+            ag = InternVLAN1Agent({"model_settings": {"infer_mode": "partial_async", "resize_w": 56, "resize_h": 56}}, model=model, processor=ag_proc)
+        ag.reset()
+        outs.append([o["action"] for o in ag.step(obs)])
+        s1_in.append(model.s1_inputs)
+        pvs.append(torch.cat(model.pv))
+    assert outs[0] == outs[1] == [[1], [1]]
+    assert torch.equal(pvs[0], pvs[1])                                                       # System-2 pixel_values identical on both paths
+    (ri, di), (rd, dd) = s1_in[0][0], s1_in[1][0]
+    assert torch.equal(ri.float(), rd.float()) and torch.equal(di.float(), dd.float())      # System-1 inputs identical on both paths
