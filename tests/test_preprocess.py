@@ -296,3 +296,16 @@ def test_agent_step_with_frame_preprocessor_end_to_end():
     assert torch.equal(pvs[0], pvs[1])                                                       # System-2 pixel_values identical on both paths
     (ri, di), (rd, dd) = s1_in[0][0], s1_in[1][0]
     assert torch.equal(ri.float(), rd.float()) and torch.equal(di.float(), dd.float())      # System-1 inputs identical on both paths
+
+
+def test_smart_resize_matches_installed_transformers():
+    hf = pytest.importorskip("transformers.models.qwen2_vl.image_processing_pil_qwen2_vl")
+    from internnav_amd import preprocess as pp
+
+    rng = np.random.default_rng(0)
+    cases = [(480, 640), (384, 384), (30, 30), (3000, 4000), (56, 57), (28, 2000), (224, 224)] + [tuple(int(v) for v in rng.integers(20, 2500, 2)) for _ in range(200)]
+    for h, w in cases:
+        if max(h, w) / min(h, w) > 200:
+            continue
+        ref = tuple(hf.smart_resize(h, w, 28, 56 * 56, 14 * 14 * 4 * 1280))
+        assert pp.smart_resize(h, w) == ref == o_pp.smart_resize(h, w), (h, w)
