@@ -213,12 +213,16 @@ SYMBOLS = {
 _lib = None
 
 
+class EngineError(RuntimeError):
+    """the HIP library is missing / stale, or one of its entry points reported an error: never recoverable by retrying a policy call."""
+
+
 def lib() -> C.CDLL:
     """Load the shared library (once). Fails loudly when it is missing: there is no fallback path."""
     global _lib
     if _lib is None:
         if not LIB_PATH.exists():
-            raise RuntimeError(
+            raise EngineError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m internnav_amd.build` "
                 "(or __graft_entry__.build()). internnav_amd has no CPU/PyTorch fallback."
             )
@@ -233,4 +237,4 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().ina_last_error().decode("utf-8", "replace")
-        raise RuntimeError(f"internnav_amd.{what} failed (rc={rc}): {msg}")
+        raise EngineError(f"internnav_amd.{what} failed (rc={rc}): {msg}")

@@ -7,12 +7,15 @@ HTTP AgentServer requires). Differences, all behind that contract:
   * the S2 daemon thread + sleep polling (:133-208, 270-274) is replaced by a synchronous batched schedule: all envs whose plan
     expired run System-2 in ONE batched generate (grouped by prompt length), then all envs holding a latent run System-1 in ONE
     batched generate_traj. The reference's main thread blocks until S2 finishes anyway, so per-env results are unchanged;
-  * S2 failures never raise: the env falls back to STOP ([0]) like the reference's handler (:182-189).
+  * an S2 failure of an env (any exception out of its s2_step, e.g. an unparsable pixel goal) resets that env's policy and retries
+    ONCE with look_down=False, then falls back to STOP ([0]) - the reference's handler (:168-189). Configuration / engine errors
+    (`CapacityError`, `EngineError`) are NOT policy failures: they propagate to the caller instead of ending episodes silently.
 The per-env dual-system state machine (sync / partial_async cadence, look-down turn, action queue, dual_forward_step
 accounting) follows internvla_n1_agent.py:210-241 and :243-356 line by line.
 
-Registration: `register(Agent)` replaces the 'internvla_n1' entry of the reference's registry (Agent.register raises on duplicates,
-internnav/agent/base.py:33-34) - see INTEGRATION.md.
+Registration: `internnav_amd.register_all()` replaces the 'internvla_n1' entry of the reference's registry (Agent.register raises on
+duplicates, internnav/agent/base.py:33-34) and the 'InternVLAN1_Policy' / 'NavDP_Policy' branches of get_policy / get_config - see
+INTEGRATION.md. `Agent.init(cfg)` -> `InternVLAN1Agent(cfg)` then works from the config alone, as in the reference.
 """
 from __future__ import annotations
 
@@ -23,7 +26,11 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import torch
 
-from .policy import InternVLAN1Net, S1Output, S2Output
+from ._lib import EngineError
+from .policy import InternVLAN1ModelConfig, InternVLAN1Net, S1Output, S2Output
+from .runtime import CapacityError
+
+_FATAL = (CapacityError, EngineError, MemoryError, KeyboardInterrupt)
 
 
 class _EnvState:
@@ -43,9 +50,13 @@ class _EnvState:
 
 class InternVLAN1Agent:
     def __init__(self, config, model=None, processor=None, policy_factory=None, frame_preprocessor=None):
-        """config: AgentCfg-like (attribute or dict `model_settings` with mode / infer_mode, sys2_max_forward_step, num_history,
-        resize_w/h, continuous_traj, device ...). `model` + `processor` (or a `policy_factory() -> InternVLAN1Net`) supply the policy.
-        frame_preprocessor (internnav_amd.preprocess.FramePreprocessor): System-2 image pre-processing on the device."""
+        """config: AgentCfg (or a dict / object with `model_settings`). From the config ALONE - the way `Agent.init(cfg)` and the
+        AgentServer construct agents (internnav/agent/base.py:40-45) - the agent does what the reference's does (:30-43):
+        `policy = get_policy(policy_name)(config=get_config(policy_name)(model_cfg={'model': model_settings}))`, which loads the
+        checkpoint at model_settings['model_path'] on model_settings['device'] and the HF processor from the same path.
+        model_settings read: model_path, device, policy_name, infer_mode ('sync' | 'partial_async'), sys2_max_forward_step, num_history,
+        resize_w/h, width/height (camera), continuous_traj, env_num (engine capacity), device_preprocess (optional).
+        Tests / bench may pass a built `model` + `processor`, or a `policy_factory() -> InternVLAN1Net`, instead."""
         self.config = config
         ms = getattr(config, "model_settings", None) or (config.get("model_settings") if isinstance(config, dict) else {}) or {}
         self.mode = ms.get("infer_mode", "sync")
@@ -53,18 +64,37 @@ class InternVLAN1Agent:
         self.sys1_depth_threshold = 5.0
         self.sys1_forward_step = 4
         self._ms = ms
+        self._first = None
         if policy_factory is None:
-            assert model is not None and processor is not None, "pass a model + processor, or a policy_factory"
+            if model is not None:
+                assert processor is not None, "a pre-built model needs its processor"
+                first = InternVLAN1Net(model, processor, num_history=ms.get("num_history", 8), resize_w=ms.get("resize_w", 384),
+                                       resize_h=ms.get("resize_h", 384), continuous_traj=ms.get("continuous_traj", True),
+                                       frame_preprocessor=frame_preprocessor)
+            else:
+                from . import get_config, get_policy
+
+                name = ms.get("policy_name") or "InternVLAN1_Policy"
+                first = get_policy(name)(config=get_config(name)(model_cfg={"model": dict(ms)}))
+                first.eval()
+                model, frame_preprocessor = first.model, frame_preprocessor or first.pre
+            self._first = first
+            if self.mode == "sync" and getattr(getattr(model, "config", None), "system1", "").endswith("_async"):
+                # the sync branch feeds the raw camera frame / 10000 x depth to generate_traj (:334), which the checkpoints' async
+                # heads cannot take; the reference's own configs run these checkpoints with infer_mode='partial_async'
+                raise ValueError(f"infer_mode='sync' cannot drive a '{model.config.system1}' checkpoint: set model_settings['infer_mode']='partial_async'")
 
             def policy_factory():
-                return InternVLAN1Net(model, processor, num_history=ms.get("num_history", 8), resize_w=ms.get("resize_w", 384),
-                                      resize_h=ms.get("resize_h", 384), continuous_traj=ms.get("continuous_traj", True),
-                                      frame_preprocessor=frame_preprocessor)
+                if self._first is not None:
+                    p, self._first = self._first, None
+                    return p
+                return first.spawn()
         self._factory = policy_factory
         self.pre = frame_preprocessor
         self.model = model
         self.envs: List[_EnvState] = []
         self.episode_idx = 0
+        self.s2_failures = 0     # env-turns that ended in the STOP fallback (visible to the operator; the reference only prints)
 
     # ------------------------------------------------------------------------------------------------ plugin surface
     def reset(self, reset_index: Optional[List[int]] = None):
@@ -150,48 +180,69 @@ class InternVLAN1Agent:
             return so.output_action is None and so.output_pixel is None and so.output_latent is None
         raise ValueError(f"Invalid mode: {self.mode}")
 
-    def _run_s2(self, jobs):
-        """batched System-2: envs are grouped by prompt length (the engine batches equal-length sequences); failures -> STOP."""
-        built = []
+    def _run_s2(self, jobs, retry: bool = True):
+        """batched System-2 over the envs whose plan expired. Prompts are built per env (host), batched by (length, image grids) -
+        the engine batches equal-length sequences - in chunks of the engine's capacity. An env whose turn fails is reset and retried
+        once without look-down, then STOPs (reference :156-189); fatal errors propagate."""
+        built, failed = [], []
         for e, o in jobs:
             try:
-                inputs = e.policy.build_s2_inputs(o["rgb"], o["instruction"], e.look_down)
+                inputs = e.policy.build_s2_inputs(o["rgb"], o["instruction"], e.look_down if retry else False)
                 built.append((e, o, inputs))
-            except Exception as ex:  # noqa: BLE001 - the agent must never raise out of step() (reference :156-189)
-                self._s2_fail(e, o, ex)
+            except _FATAL:
+                raise
+            except Exception as ex:  # noqa: BLE001
+                failed.append((e, o, ex))
         groups: Dict[Any, list] = {}
         for item in built:
             ids = item[2]["input_ids"]
             groups.setdefault((ids.shape[1], tuple(map(tuple, item[2]["image_grid_thw"].tolist()))), []).append(item)
-        for (_, _), items in groups.items():
-            try:
-                model = items[0][0].policy.model
-                ids = torch.cat([it[2]["input_ids"] for it in items], 0)
-                pv = torch.cat([it[2]["pixel_values"] for it in items], 0)
-                grid = torch.cat([it[2]["image_grid_thw"] for it in items], 0)
-                seqs = model.generate(input_ids=ids, pixel_values=pv, image_grid_thw=grid, max_new_tokens=128, do_sample=False,
-                                      use_cache=True, past_key_values=None, return_dict_in_generate=True).sequences
+        for items_all in groups.values():
+            model = items_all[0][0].policy.model
+            cap = getattr(getattr(model, "qwen", None), "B_max", None) or len(items_all)
+            for c0 in range(0, len(items_all), cap):
+                items = items_all[c0:c0 + cap]
+                try:
+                    ids = torch.cat([it[2]["input_ids"] for it in items], 0)
+                    pv = torch.cat([it[2]["pixel_values"] for it in items], 0)
+                    grid = torch.cat([it[2]["image_grid_thw"] for it in items], 0)
+                    seqs = model.generate(input_ids=ids, pixel_values=pv, image_grid_thw=grid, max_new_tokens=128, do_sample=False,
+                                          use_cache=True, past_key_values=None, return_dict_in_generate=True).sequences
+                except _FATAL:
+                    raise
+                except Exception as ex:  # noqa: BLE001
+                    failed += [(e, o, ex) for e, o, _ in items]
+                    continue
                 lat_cache = {}
 
-                def latents():
+                def latents(seqs=seqs, pv=pv, grid=grid, lat_cache=lat_cache):
                     if "v" not in lat_cache:
                         lat_cache["v"] = model.generate_latents(seqs, pv, grid)
                     return lat_cache["v"]
 
                 for k, (e, o, inputs) in enumerate(items):
-                    so = e.policy.finish_s2(inputs, seqs[k:k + 1], lambda k=k: latents()[k:k + 1])
+                    try:
+                        so = e.policy.finish_s2(inputs, seqs[k:k + 1], lambda k=k: latents()[k:k + 1])
+                    except _FATAL:
+                        raise
+                    except Exception as ex:  # noqa: BLE001 - e.g. IndexError on a one-number pixel goal (internvla_n1_policy.py:187)
+                        failed.append((e, o, ex))
+                        continue
                     so.idx = e.episode_step
                     so.rgb_memory, so.depth_memory = o["rgb"], o["depth"]
                     so.is_infering = False
                     e.s2_output = so
-            except Exception as ex:  # noqa: BLE001
-                for e, o, _ in items:
-                    self._s2_fail(e, o, ex)
-
-    def _s2_fail(self, e: _EnvState, o, ex):
-        print(f"[internnav_amd.agent] S2 failed for an env ({type(ex).__name__}: {ex}); emitting STOP")
-        e.policy.reset()
-        e.s2_output = S2Output(idx=e.episode_step, output_action=[0], rgb_memory=o["rgb"], depth_memory=o["depth"])
+        if not failed:
+            return
+        for e, o, ex in failed:
+            print(f"s2 infer error: {type(ex).__name__}: {ex}")
+            e.policy.reset()
+        if retry:
+            self._run_s2([(e, o) for e, o, _ in failed], retry=False)     # second attempt: look_down=False (:172-180)
+        else:
+            for e, o, _ in failed:
+                self.s2_failures += 1
+                e.s2_output = S2Output(idx=e.episode_step, output_action=[0], rgb_memory=o["rgb"], depth_memory=o["depth"])
 
     def _prep_s1(self, rgb, depth):
         """224x224 RGB in 0..1 and depth x10 clipped at 5 m (internvla_n1_agent.py:309-321)."""
@@ -215,6 +266,11 @@ class InternVLAN1Agent:
 
     def _run_s1(self, jobs):
         model = jobs[0][0].policy.model
+        cap = getattr(getattr(model, "s1", None), "b_max", None)
+        if cap and len(jobs) > cap:      # more envs than the System-1 engine was sized for: run it in engine-sized chunks
+            for c0 in range(0, len(jobs), cap):
+                self._run_s1(jobs[c0:c0 + cap])
+            return
         if self.pre is not None and self.mode != "sync" and len({np.asarray(f).shape for e, o in jobs for f in (e.s2_output.rgb_memory, o["rgb"])}) == 1:
             rgb_t, dep_t = self._prep_s1_device(jobs)
             lats = [e.s2_output.output_latent for e, _ in jobs]
@@ -244,6 +300,7 @@ class InternVLAN1Agent:
 
 
 def register(agent_registry, name: str = "internvla_n1"):
-    """Install this agent under `name` in the reference's registry class (internnav.agent.base.Agent), replacing the PyTorch one."""
+    """Install this agent under `name` in the reference's registry class (internnav.agent.base.Agent), replacing the PyTorch one.
+    `internnav_amd.register_all()` does this and the model factories in one call."""
     agent_registry.agents[name] = InternVLAN1Agent
     return InternVLAN1Agent

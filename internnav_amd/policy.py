@@ -32,6 +32,7 @@ from . import synthetic
 from .navdp import NavDPPolicyDAT
 from .nextdit import NextDiTSystem1
 from .qwen_vl import QwenVLEngine
+from .runtime import CapacityError  # noqa: F401  (re-exported)
 
 
 # ------------------------------------------------------------------------------------------------------ vln_utils mirror
@@ -133,31 +134,86 @@ class S1Output:
 
 
 # ------------------------------------------------------------------------------------------------------ model facade
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280):
+    """transformers image_processing_qwen2_vl.smart_resize (the processor's target size; restated in preprocess.py for the device path)."""
+    import math
+
+    h_bar, w_bar = round(height / factor) * factor, round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar, w_bar = max(factor, math.floor(height / beta / factor) * factor), max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar, w_bar = math.ceil(height * beta / factor) * factor, math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def s2_capacity(num_history: int = 8, resize_w: int = 384, resize_h: int = 384, cam_w: int = 640, cam_h: int = 480,
+                text_tokens: int = 512, max_new_tokens: int = 128, n_query: int = 4):
+    """(max_seq_len, max_patches_per_seq) of the longest System-2 prompt the reference's callers can build: num_history history frames
+    + the current frame at the resized size, + one look-down frame fed UN-resized at camera size (internvla_n1_policy.py:113-116,140),
+    the chat text, the answer and the latent queries. Default harness settings: 9 x 196 + 391 image tokens + text = 2.8 K tokens."""
+    rh, rw = smart_resize(resize_h, resize_w)
+    ch, cw = smart_resize(cam_h, cam_w)
+    p_hist, p_cam = (rh // 14) * (rw // 14), (ch // 14) * (cw // 14)
+    patches = (num_history + 1) * p_hist + p_cam
+    seq = patches // 4 + 2 * (num_history + 2) + text_tokens + max_new_tokens + n_query
+    return (seq + 127) // 128 * 128, patches
+
+
+def qwen_cfg_from_hf(cfgj: dict) -> dict:
+    """engine configuration from a checkpoint's config.json (Qwen2.5-VL layout of transformers 4.51: text keys at the top level;
+    newer exports nest them under text_config) - defaults are the Qwen2.5-VL-7B values InternVLA-N1 ships with."""
+    t = dict(cfgj)
+    t.update(cfgj.get("text_config") or {})
+    v = cfgj.get("vision_config") or {}
+    d = synthetic.QWEN_N1_CFG
+    rope = t.get("rope_theta") or (t.get("rope_parameters") or {}).get("rope_theta") or d["rope_theta"]
+    eos = t.get("eos_token_id", d["eos_token_id"])
+    return dict(
+        v_hidden=v.get("hidden_size", d["v_hidden"]), v_heads=v.get("num_heads", d["v_heads"]), v_inter=v.get("intermediate_size", d["v_inter"]),
+        v_depth=v.get("depth", d["v_depth"]), v_fullatt=tuple(v.get("fullatt_block_indexes", d["v_fullatt"])), v_window=v.get("window_size", d["v_window"]),
+        v_patch=v.get("patch_size", d["v_patch"]), v_out=v.get("out_hidden_size", d["v_out"]),
+        t_hidden=t.get("hidden_size", d["t_hidden"]), t_inter=t.get("intermediate_size", d["t_inter"]), t_heads=t.get("num_attention_heads", d["t_heads"]),
+        t_kv_heads=t.get("num_key_value_heads", d["t_kv_heads"]), t_layers=t.get("num_hidden_layers", d["t_layers"]), vocab=t.get("vocab_size", d["vocab"]),
+        rope_theta=float(rope), n_query=cfgj.get("n_query", d["n_query"]),
+        image_token_id=cfgj.get("image_token_id", d["image_token_id"]), traj_token_id=cfgj.get("traj_token_id", d["traj_token_id"]),
+        vision_start_id=cfgj.get("vision_start_token_id", d["vision_start_id"]), vision_end_id=cfgj.get("vision_end_token_id", d["vision_end_id"]),
+        eos_token_id=int(eos[0] if isinstance(eos, (list, tuple)) else eos))
+
+
 class InternVLAN1ForCausalLM:
     """HF-style model object backed by the HIP engines (no nn.Module, no CPU fallback)."""
 
     def __init__(self, weights, qwen_cfg: dict, system1: str = "nextdit_async", s1_cfg: Optional[dict] = None,
-                 device="cuda:0", max_envs: int = 16, max_seq_len: int = 2048, max_patches: Optional[int] = None,
-                 max_s2_seqs: Optional[int] = None):
+                 device="cuda:0", max_envs: int = 16, max_seq_len: Optional[int] = None, max_patches: Optional[int] = None,
+                 max_s2_seqs: Optional[int] = None, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
+                 cam_w: int = 640, cam_h: int = 480):
+        """Engine capacity defaults to the longest prompt the reference's harness can build for (num_history, resize, camera size):
+        see `s2_capacity`; exceeding it raises `CapacityError` (never a silent STOP)."""
         self.device = torch.device(device)
+        if system1 not in ("nextdit_async", "navdp_async"):
+            # the engines implement the checkpoints' async branches (internvla_n1.py:359-432 'nextdit'+'async', navdp.py:197-253); the
+            # no-memory 'nextdit' / non-async 'navdp' variants take differently shaped inputs and are not built
+            raise NotImplementedError(f"system1={system1!r}: only 'nextdit_async' (DualVLN) and 'navdp_async' are implemented")
         self.config = SimpleNamespace(system1=system1, n_query=qwen_cfg["n_query"], hidden_size=qwen_cfg["t_hidden"],
                                       image_token_id=qwen_cfg["image_token_id"])
         n_s2 = max_s2_seqs or max_envs   # System-2 runs on micro-batches of the envs whose plan expired (agent / bench schedule)
-        self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=n_s2, max_seq_len=max_seq_len,
-                                 max_patches=max_patches or n_s2 * 10 * 784)
-        if "nextdit" in system1:
+        cap_seq, cap_patches = s2_capacity(num_history, resize_w, resize_h, cam_w, cam_h, n_query=qwen_cfg["n_query"])
+        self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=n_s2, max_seq_len=max_seq_len or cap_seq,
+                                 max_patches=max_patches or n_s2 * cap_patches)
+        if system1 == "nextdit_async":
             self.s1 = NextDiTSystem1(_Prefixed(weights, "model."), s1_cfg or synthetic.N1_NEXTDIT_CFG, device, max_envs)
-        elif "navdp" in system1:
-            self.s1 = NavDPPolicyDAT(_Prefixed(weights, "model.navdp."), s1_cfg or synthetic.N1_NAVDP_CFG, device, max_envs)
         else:
-            raise NotImplementedError(system1)
+            self.s1 = NavDPPolicyDAT(_Prefixed(weights, "model.navdp."), s1_cfg or synthetic.N1_NAVDP_CFG, device, max_envs)
         self._noise_gen = torch.Generator(device=self.device).manual_seed(0)
 
     # ---- construction
     @classmethod
     def from_pretrained(cls, path, torch_dtype=torch.bfloat16, attn_implementation: str = "flash_attention_2", device_map=None, **kw):
         """reference call: InternVLAN1ForCausalLM.from_pretrained(path, torch_dtype=bf16, attn_implementation=..., device_map={"": dev}).
-        Loads every *.safetensors shard under `path` (HF checkpoint layout); config.json supplies system1 / n_query."""
+        Loads every *.safetensors shard under `path` (HF checkpoint layout, the reference's parameter names); config.json supplies the
+        Qwen2.5-VL dimensions / token ids, system1 and n_query (InternVLAN1ModelConfig fields, internvla_n1.py:22-29)."""
         import json
         from pathlib import Path
 
@@ -169,13 +225,11 @@ class InternVLAN1ForCausalLM:
             raise FileNotFoundError(f"no *.safetensors under {p}: InternVLA-N1 checkpoints are HF safetensors shards")
         cfgj = json.loads((p / "config.json").read_text()) if (p / "config.json").exists() else {}
         device = (device_map or {"": "cuda:0"})[""]
-        weights = {}
-        for f in files:
-            with safe_open(str(f), framework="pt", device="cpu") as sf:
-                for k in sf.keys():
-                    weights[k] = sf.get_tensor(k)
-        qcfg = dict(synthetic.QWEN_N1_CFG, n_query=cfgj.get("n_query", 4))
-        return cls(weights, qcfg, system1=cfgj.get("system1", "nextdit_async"), device=device, **kw)
+        weights = _ShardedCheckpoint(files)
+        missing = [k for k in synthetic.n1_full_spec(qwen_cfg_from_hf(cfgj), cfgj.get("system1", "nextdit_async")) if k not in weights]
+        if missing:
+            raise KeyError(f"checkpoint {p} lacks {len(missing)} parameters the engines need, e.g. {missing[:4]}")
+        return cls(weights, qwen_cfg_from_hf(cfgj), system1=cfgj.get("system1", "nextdit_async"), device=device, **kw)
 
     def eval(self):
         return self
@@ -272,7 +326,44 @@ class _Prefixed:
             return False
 
 
+class _ShardedCheckpoint:
+    """key -> tensor over a list of safetensors shards, read lazily (one tensor on the host at a time: the engines repack and upload
+    each parameter as they read it, so a 16 GB checkpoint never sits in host memory twice)."""
+
+    def __init__(self, files):
+        from safetensors import safe_open
+
+        self._where = {}
+        for f in files:
+            with safe_open(str(f), framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    self._where[k] = str(f)
+
+    def __contains__(self, k):
+        return k in self._where
+
+    def keys(self):
+        return self._where.keys()
+
+    def __getitem__(self, k):
+        from safetensors import safe_open
+
+        with safe_open(self._where[k], framework="pt", device="cpu") as sf:
+            return sf.get_tensor(k)
+
+
 # ------------------------------------------------------------------------------------------------------ policy wrapper
+class InternVLAN1ModelConfig:
+    """`InternVLAN1ModelConfig` as the agent layer uses it (internvla_n1_agent.py:40-43: `policy_config(model_cfg={'model': ModelCfg.model_dump()})`):
+    a holder of `model_cfg`; the HF PretrainedConfig machinery of the reference's class (internvla_n1.py:22-29) is not needed here."""
+    model_type = "internvla_n1"
+
+    def __init__(self, model_cfg: Optional[dict] = None, **kwargs):
+        self.model_cfg = model_cfg or {"model": {}}
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
 class InternVLAN1Net:
     """`InternVLAN1Net` of the reference (internvla_n1_policy.py:26-215) for ONE environment's episode state; the batched agent
     (internnav_amd/agent.py) holds one instance per env that share a single model and batches their model calls."""
@@ -282,15 +373,59 @@ class InternVLAN1Net:
     CONJUNCTION = "you can see "
     ACTIONS2IDX = OrderedDict({"STOP": [0], "↑": [1], "←": [2], "→": [3], "↓": [5]})
 
-    def __init__(self, model: InternVLAN1ForCausalLM, processor, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
-                 continuous_traj: bool = True, frame_preprocessor=None):
-        """frame_preprocessor: an internnav_amd.preprocess.FramePreprocessor - the PIL resizes and the HF image processor then run on
-        the device from raw uint8 frames (bit-exact with the host path); the injected processor is only used for the chat template and
+    _shared: Dict[Any, Any] = {}   # (model_path, device) -> (model, processor): one set of engines per GPU process, shared by all envs
+
+    def __init__(self, config=None, processor=None, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
+                 continuous_traj: bool = True, frame_preprocessor=None, model: Optional[InternVLAN1ForCausalLM] = None):
+        """Two ways in, both ending in (model, processor, episode state):
+          * the reference's: `InternVLAN1Net(config=InternVLAN1ModelConfig(model_cfg={'model': model_settings}))`
+            (internvla_n1_agent.py:39-43, internvla_n1_policy.py:29-48) - loads the checkpoint at model_settings['model_path'] on
+            model_settings['device'] with `InternVLAN1ForCausalLM.from_pretrained`, and the HF tokenizer / processor from the same
+            path (a1 stays on the host); engines are sized from num_history / resize / camera size / env_num;
+          * `InternVLAN1Net(model, processor, ...)` with an already-built model (tests, bench, the batched agent's per-env states).
+        frame_preprocessor: an internnav_amd.preprocess.FramePreprocessor - the PIL resizes and the HF image processor then run on
+        the device from raw uint8 frames (bit-exact with the host path); the processor is only used for the chat template and
         its tokenizer."""
+        if model is None and config is not None and not hasattr(config, "model_cfg"):
+            model, config = config, None                      # legacy positional form: InternVLAN1Net(model, processor, ...)
+        if model is None:
+            ms = dict(config.model_cfg["model"])
+            num_history, resize_w, resize_h = ms.get("num_history", num_history), ms.get("resize_w", resize_w), ms.get("resize_h", resize_h)
+            continuous_traj = ms.get("continuous_traj", continuous_traj)
+            model, processor = self._load(ms)
+            if frame_preprocessor is None and ms.get("device_preprocess", False):
+                from .preprocess import FramePreprocessor
+
+                frame_preprocessor = FramePreprocessor(model.device, resize_w=resize_w, resize_h=resize_h)
+        self.model_config = SimpleNamespace(num_history=num_history, resize_w=resize_w, resize_h=resize_h, continuous_traj=continuous_traj)
         self.model, self.processor, self.pre = model, processor, frame_preprocessor
+        self.tokenizer = getattr(processor, "tokenizer", None)
         self.num_history, self.resize_w, self.resize_h, self.continuous_traj = num_history, resize_w, resize_h, continuous_traj
         self.device = model.device
         self.reset()
+
+    @classmethod
+    def _load(cls, ms: dict):
+        """model + processor for a model_settings dict, loaded once per (checkpoint, device) and shared afterwards."""
+        key = (str(ms["model_path"]), str(ms.get("device", "cuda:0")))
+        if key not in cls._shared:
+            from transformers import AutoProcessor, AutoTokenizer   # third-party host-side pre-processing, as in the reference (:40-43)
+
+            n_env = int(ms.get("env_num", 1) or 1)
+            model = InternVLAN1ForCausalLM.from_pretrained(
+                ms["model_path"], torch_dtype=torch.bfloat16, attn_implementation="flash_attention_2", device_map={"": ms.get("device", "cuda:0")},
+                max_envs=max(n_env, int(ms.get("max_envs", 1))), max_s2_seqs=ms.get("max_s2_seqs"), num_history=ms.get("num_history", 8),
+                resize_w=ms.get("resize_w", 384), resize_h=ms.get("resize_h", 384), cam_w=ms.get("width", 640), cam_h=ms.get("height", 480))
+            processor = AutoProcessor.from_pretrained(ms["model_path"])
+            processor.tokenizer = AutoTokenizer.from_pretrained(ms["model_path"], use_fast=True)
+            processor.tokenizer.padding_side = "left"
+            cls._shared[key] = (model.eval(), processor)
+        return cls._shared[key]
+
+    def spawn(self) -> "InternVLAN1Net":
+        """a fresh episode state on the same model / processor (the batched agent keeps one per environment)."""
+        return InternVLAN1Net(processor=self.processor, num_history=self.num_history, resize_w=self.resize_w, resize_h=self.resize_h,
+                              continuous_traj=self.continuous_traj, frame_preprocessor=self.pre, model=self.model)
 
     def eval(self):
         return self
@@ -371,7 +506,7 @@ class InternVLAN1Net:
         out = S2Output()
         if re.search(r"\d", self.llm_output):
             coord = [int(c) for c in re.findall(r"\d+", self.llm_output)]
-            out.output_pixel = np.array([int(coord[1]), int(coord[0])]) if len(coord) >= 2 else np.array([0, int(coord[0])])
+            out.output_pixel = np.array([int(coord[1]), int(coord[0])])   # a one-number answer raises IndexError like the reference (:187) -> the agent's retry path
             out.output_latent = latents_fn()
         else:
             out.output_action = self.parse_actions(self.llm_output)

@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .runtime import CapacityError
 
 
 # ---------------------------------------------------------------------------------------------------- host index logic (integers only)
@@ -119,6 +120,7 @@ class QwenVLEngine:
         bf, f32 = torch.bfloat16, torch.float32
         self.cfg, self.device = cfg, dev
         self.B_max, self.S_max, self.Np_max = max_seqs, max_seq_len, max_patches
+        self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
         Ip = (I + 63) // 64 * 64   # SwiGLU width padded with zero rows/cols: GLU tiles need N % 32 == 0, the LDS-DMA GEMM K % 64 == 0
         self.vD, self.vI, self.vH, self.vhd = D, Ip, cfg["v_heads"], D // cfg["v_heads"]
@@ -206,7 +208,8 @@ class QwenVLEngine:
         cu_full = np.concatenate([[0], np.cumsum([t * h * w for t, h, w in grids])]).astype(np.int32)
         cos, sin = vision_rope_tables(grids, hd)
         Np = int(cu_full[-1])
-        assert Np <= self.Np_max, f"{Np} patches exceed the engine's max_patches={self.Np_max}"
+        if Np > self.Np_max:
+            raise CapacityError(f"{Np} image patches exceed the engine's max_patches={self.Np_max}")
         return dict(Np=Np, perm=torch.from_numpy(perm).to(dev), cos=cos[perm].contiguous().to(dev), sin=sin[perm].contiguous().to(dev),
                     cu_win=torch.from_numpy(cu_win).to(dev), cu_full=torch.from_numpy(cu_full).to(dev),
                     max_win=int(np.diff(cu_win).max()), max_full=int(np.diff(cu_full).max()), inv=np.argsort(win_idx).astype(np.int32))
@@ -219,7 +222,7 @@ class QwenVLEngine:
         ops.gather_rows(pixel_values, xp, src=vp["perm"])
         ops.linear(xp, self.v_patch, out=x)
         q3 = qkv.view(Np, 3, Hh, hd)
-        for blk in self.v_blocks:
+        for bi, blk in enumerate(self.v_blocks):
             ops.norm(x, blk["n1"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, blk["qkv_w"], bias=blk["qkv_b"], out=qkv)
             ops.rope(qkv, vp["cos"], vp["sin"], heads=2 * Hh, D=hd, col0=0, rows=Np)
@@ -229,6 +232,8 @@ class QwenVLEngine:
             ops.norm(x, blk["n2"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, blk["gu_w"], bias=blk["gu_b"], act="silu", glu=True, out=ff)
             ops.linear(ff, blk["down_w"], bias=blk["down_b"], residual=x, out=x)
+            if self.tap is not None:
+                self.tap("vit", bi, x)
         ops.norm(x, self.m_ln, None, eps=1e-6, rms=True, out=h)
         ops.linear(h.view(Np // 4, 4 * D), self.m0[0], bias=self.m0[1], act="gelu", out=self.mh[: Np // 4])
         ops.linear(self.mh[: Np // 4], self.m2[0], bias=self.m2[1], out=self.emb[: Np // 4])
@@ -246,7 +251,8 @@ class QwenVLEngine:
         dev = self.device
         pos0 = np.broadcast_to(np.asarray(cache_pos0, dtype=np.int64).reshape(-1, 1), (B, 1))
         rows = (np.arange(B)[:, None] * self.S_max + pos0 + np.arange(S)[None]).reshape(-1).astype(np.int32)
-        assert int(pos0.max()) + S <= self.S_max, "KV cache capacity (max_seq_len) exceeded"
+        if int(pos0.max()) + S > self.S_max:
+            raise CapacityError(f"KV cache capacity exceeded: {int(pos0.max()) + S} tokens > max_seq_len={self.S_max}")
         ph = dict(B=B, S=S, pos=torch.from_numpy(np.ascontiguousarray(np.broadcast_to(pos3, (3, B, S)).reshape(3, B * S)).astype(np.int32)).to(dev),
                   rows=torch.from_numpy(rows).to(dev), Lk=int(pos0.max()) + S, k_len=None)
         if k_len is not None:
@@ -273,6 +279,8 @@ class QwenVLEngine:
             ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
             ops.linear(ff, L["down_w"], residual=x, out=x)
+            if self.tap is not None:
+                self.tap("llm", li, x)
 
     def _last_logits(self, B: int, S: int, row_in_seq: int):
         """final RMSNorm + lm_head on ONE row per sequence, greedy argmax on the device."""
@@ -287,7 +295,8 @@ class QwenVLEngine:
         cfg, dev = self.cfg, self.device
         ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
         B, S = ids.shape
-        assert B <= self.B_max and S <= self.S_max
+        if B > self.B_max or S > self.S_max:
+            raise CapacityError(f"System-2 batch of {B} x {S} tokens exceeds the engine's max_seqs={self.B_max} / max_seq_len={self.S_max}")
         grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
         flat = ids.reshape(-1)
         P = dict(B=B, S=S, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None)

@@ -18,6 +18,11 @@ from . import _lib
 PROF_KINDS = ("gemm", "attention", "norm", "elementwise", "gemm_skinny")
 
 
+class CapacityError(RuntimeError):
+    """a request exceeds what an engine was sized for (max_envs / max_seq_len / max_patches): a configuration error that must reach
+    the operator - the agent never converts it into a STOP action (capacity overflows used to end episodes silently)."""
+
+
 def require_gfx950() -> str:
     """Fail loudly unless the HIP library is built AND the current device is an MI355X-class gfx950 GPU (no fallback path)."""
     if not torch.cuda.is_available():

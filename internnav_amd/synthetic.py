@@ -87,6 +87,60 @@ class LazyDeviceWeights:
         return r.to(torch.bfloat16)
 
 
+_HASH_KIND = {"w": (None, 0.0), "w_small": (None, 0.0), "b": (0.1, 0.0), "ln_w": (0.1, 1.0), "ln_b": (0.1, 0.0), "emb": (0.3, 0.0),
+              "gamma": (0.1, 0.5), "gate": (0.5, 0.0), "latent": (1.0, 0.0)}
+
+
+def hash_uniform(n: int, seed: int, device="cpu", chunk: int = 1 << 24) -> torch.Tensor:
+    """n fp32 values in [-0.5, 0.5) from a counter hash of (seed, index): integer arithmetic only (32-bit mixes carried in int64, every
+    product < 2^63), so torch evaluates it to the SAME bits on the CPU and on the GPU - unlike torch.randn, whose CPU and device
+    generators are different streams. Used where a fixture generated in the build container (CPU) must meet weights created on the GPU."""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    M = 0xFFFFFFFF
+    for s0 in range(0, n, chunk):
+        m = min(chunk, n - s0)
+        x = torch.arange(s0, s0 + m, dtype=torch.int64, device=device)
+        x = (x * 2 + 1 + (seed & M)) & M
+        x = ((x ^ (x >> 16)) * 0x45D9F3B) & M
+        x = ((x ^ (x >> 15)) * 0x2C1B3C6D) & M
+        x = ((x ^ (x >> 16)) * 0x297A2D39) & M
+        x = x ^ (x >> 15)
+        out[s0:s0 + m] = (x >> 8).to(torch.float32).mul_(2.0 ** -24).sub_(0.5)
+    return out
+
+
+class HashWeights:
+    """Mapping key -> bf16 tensor drawn lazily from `hash_uniform` (uniform with the same standard deviation per kind as `_draw`):
+    bit-identical on cpu and cuda, seconds for the 7.6 B-parameter System-2 on the GPU. The full-configuration parity fixture
+    (oracle/make_golden_full.py, CPU) and its GPU test (tests/test_qwen_full_gpu.py) both build their weights here."""
+
+    def __init__(self, spec: Spec, seed: int = 0, device="cpu"):
+        self.spec, self.seed, self.device = spec, seed, torch.device(device)
+
+    def __contains__(self, key):
+        return key in self.spec
+
+    def keys(self):
+        return self.spec.keys()
+
+    def __getitem__(self, key: str) -> torch.Tensor:
+        shape, kind = self.spec[key]
+        n = 1
+        for d in shape:
+            n *= d
+        std, mean = _HASH_KIND[kind]
+        if std is None:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            std = (0.5 if kind == "w_small" else 1.0) * fan_in ** -0.5
+        u = hash_uniform(n, (zlib.crc32(key.encode()) ^ (self.seed * 0x9E3779B1)) & 0x7FFFFFFF, self.device)
+        u.mul_(float(torch.tensor(12.0 ** 0.5 * std, dtype=torch.float32)))
+        if mean:
+            u.add_(mean)
+        return u.to(torch.bfloat16).view(shape)
+
+
 def materialize(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
     return {k: _draw(k, shape, kind, seed) for k, (shape, kind) in spec.items()}
 

@@ -68,8 +68,9 @@ def vision_window_index(grid_thw, merge: int = 2, window_size: int = 112, patch:
     return torch.cat(index), cu
 
 
-def vision_tower(pixel_values, grid_thw, sd, cfg, p="visual."):
-    """Qwen2_5_VisionTransformerPretrainedModel.forward -> merged image embeds [sum(h*w)/4, out_hidden] in token order."""
+def vision_tower(pixel_values, grid_thw, sd, cfg, p="visual.", tap=None):
+    """Qwen2_5_VisionTransformerPretrainedModel.forward -> merged image embeds [sum(h*w)/4, out_hidden] in token order.
+    tap(i, x): called with the residual stream [N, D] (window order) after block i (drift reports of the full-depth fixture)."""
     D, H, merge = cfg["v_hidden"], cfg["v_heads"], 2
     hd = D // H
     grid = [tuple(int(v) for v in g) for g in grid_thw]
@@ -100,6 +101,8 @@ def vision_tower(pixel_values, grid_thw, sd, cfg, p="visual."):
         g = F.silu(F.linear(y, sd[b + "mlp.gate_proj.weight"], sd[b + "mlp.gate_proj.bias"]))
         u = F.linear(y, sd[b + "mlp.up_proj.weight"], sd[b + "mlp.up_proj.bias"])
         x = x + F.linear(g * u, sd[b + "mlp.down_proj.weight"], sd[b + "mlp.down_proj.bias"])
+        if tap is not None:
+            tap(i, x)
     m = p + "merger."
     y = rms_norm(x, sd[m + "ln_q.weight"], 1e-6).reshape(N // 4, 4 * D)
     y = F.linear(F.gelu(F.linear(y, sd[m + "mlp.0.weight"], sd[m + "mlp.0.bias"])), sd[m + "mlp.2.weight"], sd[m + "mlp.2.bias"])
@@ -152,14 +155,18 @@ def mrope_cos_sin(position_ids, hd: int = 128, theta: float = 1e6, section=(16, 
 
 
 # ----------------------------------------------------------------------------------------------------- text model
-def decoder_stack(x, position_ids, sd, cfg, p="model."):
-    """Qwen2_5_VLTextModel on inputs_embeds x [B, S, H] with a causal mask -> final-norm hidden states [B, S, H]."""
+def decoder_stack(x, position_ids, sd, cfg, p="model.", tap=None, cache=None):
+    """Qwen2_5_VLTextModel on inputs_embeds x [B, S, H] with a causal mask -> final-norm hidden states [B, S, H].
+    tap(i, x): called with the residual stream after layer i. cache: a list (one entry per layer, initially None) of (k, v) of the
+    tokens already processed - the S new tokens attend to them and are appended (HF `use_cache=True`; same result as re-running
+    the whole sequence in exact arithmetic, which tests/test_oracle_golden.py checks on the reduced configuration)."""
     B, S, Hd = x.shape
     nh, nkv = cfg["t_heads"], cfg["t_kv_heads"]
     hd = Hd // nh
     cos, sin = mrope_cos_sin(position_ids, hd, cfg["rope_theta"])
     cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
-    mask = torch.triu(torch.full((S, S), float("-inf")), diagonal=1)
+    past = cache[0][0].shape[2] if cache is not None and cache[0] is not None else 0
+    mask = torch.triu(torch.full((S, past + S), float("-inf")), diagonal=past + 1)
     for i in range(cfg["t_layers"]):
         b = f"{p}layers.{i}."
         y = rms_norm(x, sd[b + "input_layernorm.weight"], 1e-6)
@@ -168,6 +175,10 @@ def decoder_stack(x, position_ids, sd, cfg, p="model."):
         v = F.linear(y, sd[b + "self_attn.v_proj.weight"], sd[b + "self_attn.v_proj.bias"]).view(B, S, nkv, hd).transpose(1, 2)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
+        if cache is not None:
+            if cache[i] is not None:
+                k, v = torch.cat([cache[i][0], k], dim=2), torch.cat([cache[i][1], v], dim=2)
+            cache[i] = (k, v)
         k = k.repeat_interleave(nh // nkv, dim=1)
         v = v.repeat_interleave(nh // nkv, dim=1)
         o = sdpa(q, k, v, mask).transpose(1, 2).reshape(B, S, Hd)
@@ -175,6 +186,8 @@ def decoder_stack(x, position_ids, sd, cfg, p="model."):
         y = rms_norm(x, sd[b + "post_attention_layernorm.weight"], 1e-6)
         x = x + F.linear(F.silu(F.linear(y, sd[b + "mlp.gate_proj.weight"])) * F.linear(y, sd[b + "mlp.up_proj.weight"]),
                          sd[b + "mlp.down_proj.weight"])
+        if tap is not None:
+            tap(i, x)
     return rms_norm(x, sd[p + "norm.weight"], 1e-6)
 
 
