@@ -41,32 +41,55 @@ InaProfScope::~InaProfScope() {
 }
 
 // ---- workspace slots -----------------------------------------------------------------------------------------------
+// The scratch pointer is baked into every graph captured under a slot, so a buffer that a graph has seen is NEVER freed: when a
+// later (eager) launch needs more, a new buffer is allocated for new launches and the old one is retired but kept alive until the
+// process ends (graphs captured earlier keep replaying into it). The current slot is per host thread, like the error string.
 namespace {
-int g_ws_slot = 0;
+thread_local int g_ws_slot = 0;
 float* g_ws_ptr[INA_WS_KINDS][INA_WS_SLOTS] = {};
 size_t g_ws_cap[INA_WS_KINDS][INA_WS_SLOTS] = {};
+bool g_ws_captured[INA_WS_KINDS][INA_WS_SLOTS] = {};
+std::vector<float*> g_ws_retired;
+std::mutex g_ws_mu;
 }  // namespace
 
 int ina_workspace(int kind, size_t bytes, hipStream_t stream, float** out) {
-    float*& ptr = g_ws_ptr[kind][g_ws_slot];
-    size_t& cap = g_ws_cap[kind][g_ws_slot];
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    const int slot = g_ws_slot;
+    float*& ptr = g_ws_ptr[kind][slot];
+    size_t& cap = g_ws_cap[kind][slot];
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &st);
     if (bytes > cap) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &st);
         INA_REQUIRE(st == hipStreamCaptureStatusNone,
                     "workspace (kind %d, slot %d) of %zu bytes needed during graph capture: run the shape once eagerly under this slot first", kind,
-                    g_ws_slot, bytes);
-        INA_HIP_CHECK(hipDeviceSynchronize());
-        if (ptr) INA_HIP_CHECK(hipFree(ptr));
+                    slot, bytes);
+        if (ptr) {
+            if (g_ws_captured[kind][slot]) {
+                g_ws_retired.push_back(ptr);              // a captured graph still points here: keep the memory alive
+            } else {
+                INA_HIP_CHECK(hipDeviceSynchronize());
+                INA_HIP_CHECK(hipFree(ptr));
+            }
+            ptr = nullptr;
+            cap = 0;
+        }
         const size_t want = bytes < (size_t)(32u << 20) ? (size_t)(32u << 20) : bytes * 2;
         INA_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ptr), want));
         cap = want;
+        g_ws_captured[kind][slot] = false;
     }
+    if (st != hipStreamCaptureStatusNone) g_ws_captured[kind][slot] = true;
     *out = ptr;
     return 0;
 }
 
 extern "C" {
+
+int ina_workspace_retired(void) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    return (int)g_ws_retired.size();
+}
 
 int ina_set_workspace_slot(int slot) {
     INA_REQUIRE(slot >= 0 && slot < INA_WS_SLOTS, "workspace slot %d out of range [0, %d)", slot, INA_WS_SLOTS);

@@ -409,18 +409,24 @@ class InternVLAN1Net:
         """model + processor for a model_settings dict, loaded once per (checkpoint, device) and shared afterwards."""
         key = (str(ms["model_path"]), str(ms.get("device", "cuda:0")))
         if key not in cls._shared:
-            from transformers import AutoProcessor, AutoTokenizer   # third-party host-side pre-processing, as in the reference (:40-43)
-
             n_env = int(ms.get("env_num", 1) or 1)
             model = InternVLAN1ForCausalLM.from_pretrained(
                 ms["model_path"], torch_dtype=torch.bfloat16, attn_implementation="flash_attention_2", device_map={"": ms.get("device", "cuda:0")},
                 max_envs=max(n_env, int(ms.get("max_envs", 1))), max_s2_seqs=ms.get("max_s2_seqs"), num_history=ms.get("num_history", 8),
                 resize_w=ms.get("resize_w", 384), resize_h=ms.get("resize_h", 384), cam_w=ms.get("width", 640), cam_h=ms.get("height", 480))
-            processor = AutoProcessor.from_pretrained(ms["model_path"])
-            processor.tokenizer = AutoTokenizer.from_pretrained(ms["model_path"], use_fast=True)
-            processor.tokenizer.padding_side = "left"
-            cls._shared[key] = (model.eval(), processor)
+            cls._shared[key] = (model.eval(), cls.load_processor(ms["model_path"]))
         return cls._shared[key]
+
+    @staticmethod
+    def load_processor(model_path):
+        """the HF processor + tokenizer of the checkpoint, exactly as the reference loads them (internvla_n1_policy.py:40-43):
+        third-party host-side pre-processing."""
+        from transformers import AutoProcessor, AutoTokenizer
+
+        processor = AutoProcessor.from_pretrained(model_path)
+        processor.tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=True)
+        processor.tokenizer.padding_side = "left"
+        return processor
 
     def spawn(self) -> "InternVLAN1Net":
         """a fresh episode state on the same model / processor (the batched agent keeps one per environment)."""
@@ -510,6 +516,10 @@ class InternVLAN1Net:
             out.output_latent = latents_fn()
         else:
             out.output_action = self.parse_actions(self.llm_output)
+            if not out.output_action:
+                # neither a pixel goal nor a single action token: the reference's agent would index an empty list in its main thread
+                # (internvla_n1_agent.py:282, an uncaught IndexError); here it is an S2 failure like any other -> retry once, then STOP
+                raise ValueError(f"System-2 answer holds neither a pixel goal nor an action: {self.llm_output!r}")
         return out
 
     def s2_step(self, rgb, depth, pose, instruction, intrinsic, look_down: bool = False) -> S2Output:

@@ -466,3 +466,33 @@ def n1_navdp_inputs(B: int, seed: int = 0, cfg=N1_NAVDP_CFG):
     x_init = torch.randn(B, S, T, 3, generator=g)
     step_noise = torch.randn(K, B, S, T, 3, generator=g)
     return dict(vlm_tokens=vlm, images=images, depths=depths, x_init=x_init, step_noise=step_noise)
+
+
+def write_checkpoint(path, qwen_cfg=None, system1: str = "nextdit_async", seed: int = 0, shards: int = 2):
+    """A synthetic InternVLA-N1 checkpoint ON DISK in the layout of a real one (HF safetensors shards with the reference's parameter
+    names + config.json in the Qwen2.5-VL / InternVLAN1ModelConfig layout): what `InternVLAN1ForCausalLM.from_pretrained` and the
+    agent's config-only construction are tested against (no real checkpoint is available offline). bf16 tensors, like the release."""
+    import json
+    from pathlib import Path
+
+    from safetensors.torch import save_file
+
+    cfg = qwen_cfg or QWEN_TEST_CFG
+    p = Path(path)
+    p.mkdir(parents=True, exist_ok=True)
+    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in materialize(n1_full_spec(cfg, system1), seed).items()}
+    keys = sorted(sd)
+    per = (len(keys) + shards - 1) // shards
+    for i in range(shards):
+        save_file({k: sd[k] for k in keys[i * per:(i + 1) * per]}, str(p / f"model-{i + 1:05d}-of-{shards:05d}.safetensors"))
+    hf = {"architectures": ["InternVLAN1ForCausalLM"], "model_type": "internvla_n1", "system1": system1, "n_query": cfg["n_query"],
+          "hidden_size": cfg["t_hidden"], "intermediate_size": cfg["t_inter"], "num_hidden_layers": cfg["t_layers"],
+          "num_attention_heads": cfg["t_heads"], "num_key_value_heads": cfg["t_kv_heads"], "vocab_size": cfg["vocab"],
+          "rope_theta": cfg["rope_theta"], "rms_norm_eps": 1e-6, "eos_token_id": cfg["eos_token_id"], "image_token_id": cfg["image_token_id"],
+          "traj_token_id": cfg["traj_token_id"], "vision_start_token_id": cfg["vision_start_id"], "vision_end_token_id": cfg["vision_end_id"],
+          "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}, "torch_dtype": "bfloat16",
+          "vision_config": {"depth": cfg["v_depth"], "hidden_size": cfg["v_hidden"], "intermediate_size": cfg["v_inter"], "num_heads": cfg["v_heads"],
+                            "out_hidden_size": cfg["v_out"], "fullatt_block_indexes": list(cfg["v_fullatt"]), "window_size": cfg["v_window"],
+                            "patch_size": cfg["v_patch"], "spatial_merge_size": 2}}
+    (p / "config.json").write_text(json.dumps(hf, indent=1))
+    return sd

@@ -40,7 +40,7 @@ def test_dinov2_encoder_vs_reference_fixture(built_lib):
     enc.forward(img.permute(0, 2, 3, 1).contiguous().to(DEV), ws, out)
     mean, mx, ref = _stats(out.view(2, 256, 384), gold["tokens"])
     print(f"dinov2: mean|err| {mean:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
-    assert mean < 1.5e-2 and mx < 0.25
+    assert mean < 5e-3 and mx < 5e-2     # measured 2.4e-3 / 2.2e-2 on O(1) tokens after 12 blocks (was 6-10x slack)
 
 
 def test_navdpnet_vs_reference_fixture(built_lib):
@@ -101,7 +101,7 @@ def test_n1_navdp_head_vs_reference_fixture(built_lib):
                                              inp["x_init"].to(DEV), inp["step_noise"].to(DEV))
     m, mx, ref = _stats(out, gold["trajectories"])
     print(f"n1 navdp trajectories: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
-    assert m < 3e-3 and mx < 1e-1
+    assert m < 1e-3 and mx < 5e-2        # north_star tolerance on waypoint increments in [-1, 1] (measured 9.4e-4)
 
 
 def test_navdpnet_batch_invariance(built_lib):
@@ -111,12 +111,20 @@ def test_navdpnet_batch_invariance(built_lib):
     sd = W.navdpnet_state_dict(seed=5)
     inp = {k: v.to(DEV) for k, v in W.navdpnet_inputs(3, seed=5).items()}
     net = NavDPNet(sd, W.NAVDPNET_CFG, DEV, max_envs=3)
+    S, T = net.S, net.T
     neg3, pos3 = net.predict_pointgoal_batch_action_vel(inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
     neg3, pos3 = neg3.clone(), pos3.clone()
+    fin3 = net.sample[: 3 * S * T].view(3, S, T, 3).clone()
+    cr3 = net.critic[: 3 * S].view(3, S).clone()
     b = 1
     neg1, pos1 = net.predict_pointgoal_batch_action_vel(inp["goal"][b:b + 1].contiguous(), inp["images"][b:b + 1].contiguous(),
                                                         inp["depths"][b:b + 1].contiguous(), inp["x_init"][b:b + 1].contiguous(),
                                                         inp["step_noise"][:, b:b + 1].contiguous())
-    # tile-kernel selection depends on the row count, so the two runs may differ in fp32 accumulation order: compare the
-    # continuous quantity (denoised samples) with a tolerance; the ranked outputs are equal whenever the ranking is.
-    assert (neg3[b] - neg1[0]).abs().max().item() < 5e-2 or (pos3[b] - pos1[0]).abs().max().item() < 5e-2
+    fin1, cr1 = net.sample[: S * T].view(S, T, 3), net.critic[:S]
+    # tile-kernel selection depends on the row count, so the two runs differ in fp32 accumulation order: the continuous quantities
+    # (denoised samples, critic values) must agree to rounding level; the ranked outputs are compared whenever the ranking agrees.
+    assert (fin3[b] - fin1).abs().max().item() < 2e-2 and (cr3[b] - cr1).abs().max().item() < 2e-2
+    if torch.equal(cr3[b].argsort()[:8], cr1.argsort()[:8]):
+        assert (neg3[b] - neg1[0]).abs().max().item() < 5e-2
+    if torch.equal((-cr3[b]).argsort()[:8], (-cr1).argsort()[:8]):
+        assert (pos3[b] - pos1[0]).abs().max().item() < 5e-2
