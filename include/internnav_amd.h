@@ -37,7 +37,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -46,10 +46,17 @@ int ina_struct_size(int k);
  * ina_prof_enable(0|1) also clears the tally; ina_prof_read synchronises on the recorded events. Eager launches only. */
 /* Library-owned scratch (split-K partials of the skinny GEMM, flash-decoding partials) lives in numbered slots [0, 8). Launches
  * use the slot current at issue time (default 0) and a captured graph keeps it: graphs that may replay concurrently on different
- * streams must be captured under different slots. */
+ * streams must be captured under different slots.
+ * The current slot is per host thread. A buffer that a captured graph has seen is never freed: if a later launch under the same
+ * slot needs more, a new buffer serves new launches and the old one is retired but stays allocated (ina_workspace_retired() counts
+ * them), so graphs captured earlier keep replaying into valid memory. */
 int ina_set_workspace_slot(int slot);
+int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
+/* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
+int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
  *      (reference: torch.nn.Linear call sites, e.g. dinov2_layers/attention.py:46-48, mlp.py:27-29,
@@ -342,6 +349,30 @@ typedef struct ina_gemm_rownorm_args {
     float eps;
 } ina_gemm_rownorm_args;
 int ina_gemm_rownorm_bf16(const ina_gemm_rownorm_args* args, void* stream);
+
+/* ---- dit_ffn: the SwiGLU feed-forward of one NextDiT block (dim 384) in one launch, F never leaves the chip:
+ *          F = silu(A . W1^T) * (A . W3^T) ;  P = F . W2^T ;  X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma ;
+ *          H = rmsnorm(X) * gamma2 * (1 + mod_scale2[r/mod_div])
+ *      replaces feed_forward.linear_1/3 + SiLU gate + linear_2 + ffn_norm2 + gate + residual + the next block's norm1 of diffusers'
+ *      LuminaNextDiTBlock.forward / LuminaFeedForward (diffusers==0.33.1) as wired by nextdit_traj.py:121-188.
+ *      W13 = linear_1 / linear_3 rows interleaved in 16-row blocks [gate16 | up16] (the GLU layout of ina_gemm_bf16). H may alias A. */
+typedef struct ina_dit_ffn_args {
+    const void* A;          /* bf16 [M,D] pre-normed input, row stride lda */
+    const void* W13;        /* bf16 [2F,D], row stride ldw13 */
+    const void* W2;         /* bf16 [D,F], row stride ldw2 */
+    const float* gamma;     /* f32 [D] RMSNorm weight on the projection (ffn_norm2) */
+    const float* gate;      /* f32 [M/mod_div, mod_ld] (tanh applied) or NULL */
+    float* X;               /* f32 [M,D] residual stream, updated in place, row stride ldx */
+    void* H;                /* bf16 [M,D] next pre-norm output or NULL, row stride ldh */
+    const float* gamma2;    /* f32 [D] or NULL */
+    const float* mod_scale2;/* f32 [M/mod_div, mod_ld] or NULL */
+    int32_t M, D, F;
+    int32_t lda, ldw13, ldw2, ldx, ldh;
+    int32_t mod_div, mod_ld;
+    float eps;
+    int32_t _pad;
+} ina_dit_ffn_args;
+int ina_dit_ffn(const ina_dit_ffn_args* args, void* stream);
 
 /* ---- dit_attention: the attention stage of one NextDiT block in one launch:
  *          O = SDPA(LN(q1), LN(k1), v1) + tanh(head_gate[h]) * SDPA(LN(q2), K2, V2)

@@ -153,6 +153,16 @@ class GemmRownormArgs(C.Structure):
     ]
 
 
+class DitFfnArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W13", c_void_p), ("W2", c_void_p), ("gamma", c_void_p), ("gate", c_void_p), ("X", c_void_p), ("H", c_void_p),
+        ("gamma2", c_void_p), ("mod_scale2", c_void_p),
+        ("M", c_int32), ("D", c_int32), ("F", c_int32),
+        ("lda", c_int32), ("ldw13", c_int32), ("ldw2", c_int32), ("ldx", c_int32), ("ldh", c_int32),
+        ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("_pad", c_int32),
+    ]
+
+
 class ResizeU8Args(C.Structure):
     _fields_ = [("in_", c_void_p), ("out", c_void_p), ("bounds", c_void_p), ("coefs", c_void_p),
                 ("outer", c_int32), ("n_in", c_int32), ("n_out", c_int32), ("inner", c_int32), ("ksize", c_int32), ("_pad", c_int32)]
@@ -204,10 +214,13 @@ SYMBOLS = {
     "ina_qwen_patchify_u8": (C.c_int, [C.POINTER(QwenPatchifyArgs), c_void_p]),
     "ina_u8_lut": (C.c_int, [C.POINTER(U8LutArgs), c_void_p]),
     "ina_resize_f32": (C.c_int, [C.POINTER(ResizeF32Args), c_void_p]),
+    "ina_dit_ffn": (C.c_int, [C.POINTER(DitFfnArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
+    "ina_workspace_retired": (C.c_int, []),
     "ina_prof_enable": (C.c_int, [C.c_int]),
     "ina_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ina_prof_read_sub": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -19,7 +19,8 @@ void ina_set_error(const char* fmt, ...) {
 #include <mutex>
 #include <vector>
 namespace {
-struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { int kind, sub; hipEvent_t a, b; double flops, bytes; };
+thread_local int g_prof_sub = 0;
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
@@ -27,13 +28,16 @@ std::mutex g_prof_mu;
 
 InaProfScope::InaProfScope(int kind, double flops, double bytes, hipStream_t s) : idx(-1), stream(s) {
     if (!g_prof_on) return;
-    ProfRec r{kind, nullptr, nullptr, flops, bytes};
+    ProfRec r{kind, g_prof_sub, nullptr, nullptr, flops, bytes};
+    g_prof_sub = 0;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
     idx = (int)g_prof.size() - 1;
 }
+void ina_prof_set_sub(int sub) { g_prof_sub = sub; }
+
 InaProfScope::~InaProfScope() {
     if (idx < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -105,13 +109,13 @@ int ina_prof_enable(int on) {
     return 0;
 }
 
-int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes) {
+static int prof_read_impl(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes) {
     INA_REQUIRE(kind >= 0 && kind < INA_PROF_KINDS, "prof_read: bad kind %d", kind);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     double ms = 0, fl = 0, by = 0;
     int64_t n = 0;
     for (auto& r : g_prof) {
-        if (r.kind != kind) continue;
+        if (r.kind != kind || (sub >= 0 && r.sub != sub)) continue;
         INA_HIP_CHECK(hipEventSynchronize(r.b));
         float t = 0.f;
         INA_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
@@ -122,6 +126,14 @@ int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, 
     if (flops) *flops = fl;
     if (bytes) *bytes = by;
     return 0;
+}
+
+int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes) {
+    return prof_read_impl(kind, -1, ms_total, launches, flops, bytes);
+}
+
+int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes) {
+    return prof_read_impl(kind, sub, ms_total, launches, flops, bytes);
 }
 
 int ina_abi_version(void) { return INA_ABI_VERSION; }
@@ -157,7 +169,7 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
 }
 
 /* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify,
- * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32 */
+ * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn */
 int ina_struct_size(int k) {
     switch (k) {
         case 0: return (int)sizeof(ina_gemm_args);
@@ -179,6 +191,7 @@ int ina_struct_size(int k) {
         case 16: return (int)sizeof(ina_qwen_patchify_args);
         case 17: return (int)sizeof(ina_u8_lut_args);
         case 18: return (int)sizeof(ina_resize_f32_args);
+        case 19: return (int)sizeof(ina_dit_ffn_args);
         default: return -1;
     }
 }
@@ -204,6 +217,7 @@ INA_ENTRY(ina_qwen_patchify_u8, ina_qwen_patchify_args, ina_launch_qwen_patchify
 INA_ENTRY(ina_u8_lut, ina_u8_lut_args, ina_launch_u8_lut)
 INA_ENTRY(ina_resize_f32, ina_resize_f32_args, ina_launch_resize_f32)
 INA_ENTRY(ina_argmax_rows, ina_argmax_args, ina_launch_argmax)
+INA_ENTRY(ina_dit_ffn, ina_dit_ffn_args, ina_launch_dit_ffn)
 #undef INA_ENTRY
 
 }  // extern "C"

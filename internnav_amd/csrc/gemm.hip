@@ -210,6 +210,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
             if (c21 < best) cfg = 21;
         }
     }
+    ina_prof_set_sub(cfg);
     switch (cfg) {
         case 1: return launch_cfg<128, 128, 64, 2, 2>(p, stream);
         case 2: return launch_cfg<64, 128, 64, 2, 2>(p, stream);   // wave tile 32x64

@@ -346,6 +346,7 @@ int launch_pp(const GemmArgs& p, hipStream_t stream) {
 // measured and is within noise: 1351 vs 1391 TF/s at 8192^3, 1196 vs 1234 on the gate/up GEMM)
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
     INA_REQUIRE(p.K % 64 == 0, "gemm(glds): K=%d must be a multiple of 64", p.K);
+    ina_prof_set_sub(cfg);
     switch (cfg) {
         case 11: return launch_glds<128, 128, 2, 2, 2>(p, stream);
         case 12: return launch_glds<256, 128, 4, 2, 2>(p, stream);

@@ -212,6 +212,7 @@ int ina_launch_gemm_rownorm(const GemmRownormArgs& p_in, hipStream_t stream) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rownorm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RN_LDS));
         attr_done = true;
     }
+    ina_prof_set_sub(41);
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * RN_BN * p.K, 2.0 * p.M * p.K + 2.0 * RN_BN * p.K + p.M * RN_BN * (8.0 + (p.H ? 2.0 : 0.0)), stream);
     hipLaunchKernelGGL(gemm_rownorm_kernel, dim3((p.M + RN_BM - 1) / RN_BM), dim3(RN_NW * 64), RN_LDS, stream, p);
     INA_HIP_CHECK(hipGetLastError());

@@ -42,7 +42,8 @@ def _interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 class NextDiTSystem1:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, fuse_rownorm: bool = False):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, fuse_rownorm: bool = False,
+                 fuse_ffn: bool = False):
         dev = torch.device(device)
         bf, f32 = torch.bfloat16, torch.float32
         sd = state_dict
@@ -50,6 +51,12 @@ class NextDiTSystem1:
         # attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue (needs dim 384). Off by
         # default: 5 % faster than the GEMM + chained-norm pair in isolation, 1 % slower end to end next to the concurrent decode phase.
         self.fuse_rownorm = bool(fuse_rownorm) and cfg["dit_dim"] == 384
+        # feed_forward.linear_1/3 -> SiLU gate -> linear_2 -> ffn_norm2 + gate + residual -> next norm1 as ONE launch (dit_ffn.hip): the
+        # [rows, 1024] intermediate never reaches HBM (3 launches and 670 MB of traffic per block at 64 envs otherwise). Parity-tested;
+        # off by default: measured 366 us vs 308 us for the three launches at 65 536 rows (profiles/r02b_bench_ffn.log) - with 64-row
+        # tiles every workgroup re-streams the 2.4 MB of FFN weights through a 3-stage LDS-DMA ring, and 48 KiB in flight per CU
+        # bounds that stream at ~6.5 TB/s chip-wide (the unfused 128 x 128 tiles move the same operand bytes with 4 workgroups per CU)
+        self.fuse_ffn = bool(fuse_ffn) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] % 128 == 0
         D, L, S, T = cfg["dit_dim"], cfg["latent_dim"], cfg["sample_num"], cfg["predict_size"]
         self.D, self.L, self.S, self.T, self.nq = D, L, S, T, cfg["n_query"]
         self.Fr = cfg["memory_frames"]
@@ -227,10 +234,14 @@ class NextDiTSystem1:
             # x += tanh(gate) * norm2(attn) and, chained in the same launch on the fresh row, h = ffn_norm1(x) * (1 + scale_mlp)
             ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x,
                      out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
-        ops.linear(h, Lr["w13"], act="silu", glu=True, out=ff)
-        # linear_2, then x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
+        # linear_1/3 + SiLU gate, linear_2, then x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
         last = l + 1 >= self.nl
         nxt = None if last else self.mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
+        if self.fuse_ffn:
+            ops.dit_ffn(h, Lr["w13"], Lr["w2"], Lr["fn2"], x, gate=gate_mlp, h=None if last else h,
+                        gamma2=None if last else self.layers[l + 1]["n1"], mod_scale2=nxt, mod_div=S * T, eps=1e-5)
+            return
+        ops.linear(h, Lr["w13"], act="silu", glu=True, out=ff)
         if self.fuse_rownorm:
             ops.gemm_rownorm(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, h=None if last else h,
                              gamma2=None if last else self.layers[l + 1]["n1"], mod_scale2=nxt, mod_div=S * T, eps=1e-5)

@@ -431,6 +431,36 @@ def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: to
     return x
 
 
+def dit_ffn(h_in: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, gamma: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
+            h: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None,
+            mod_div: int = 1, eps: float = 1e-5) -> torch.Tensor:
+    """SwiGLU feed-forward of a NextDiT block in one launch (the F = silu(h W1^T) * (h W3^T) intermediate never leaves the chip):
+    x += tanh(gate[r // mod_div]) * rmsnorm((silu(h_in @ w1.T) * (h_in @ w3.T)) @ w2.T) * gamma;  h = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div]).
+
+    h_in bf16 [M, 384]; w13 bf16 [2F, 384] = linear_1 / linear_3 interleaved in 16-row blocks; w2 bf16 [384, F]; x f32 [M, 384] (in place);
+    h bf16 [M, 384] or None (may be h_in itself)."""
+    assert h_in.dtype == torch.bfloat16 and w13.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
+    assert h_in.dim() == 2 and h_in.stride(1) == 1 and w13.stride(1) == 1 and w2.stride(1) == 1
+    M, D = h_in.shape
+    F = w2.shape[1]
+    assert w13.shape == (2 * F, D) and w2.shape[0] == D and x.dtype == torch.float32 and x.shape == (M, D) and x.stride(1) == 1
+    a = _lib.DitFfnArgs()
+    a.A, a.W13, a.W2, a.gamma, a.X = h_in.data_ptr(), w13.data_ptr(), w2.data_ptr(), _f32(gamma).data_ptr(), x.data_ptr()
+    a.M, a.D, a.F, a.lda, a.ldw13, a.ldw2, a.ldx = M, D, F, h_in.stride(0), w13.stride(0), w2.stride(0), x.stride(0)
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.stride(-1) == 1
+        a.gate, a.mod_ld = gate.data_ptr(), gate.stride(0)
+    if h is not None:
+        assert h.dtype == torch.bfloat16 and h.shape == (M, D) and h.stride(1) == 1
+        a.H, a.ldh, a.gamma2 = h.data_ptr(), h.stride(0), _ptr(_f32(gamma2))
+        if mod_scale2 is not None:
+            assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and a.mod_ld in (0, mod_scale2.stride(0))
+            a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
+    a.mod_div, a.eps = mod_div, eps
+    _lib.check(_lib.lib().ina_dit_ffn(C.byref(a), _stream()), "dit_ffn")
+    return x
+
+
 def resize_u8(x: torch.Tensor, out: torch.Tensor, bounds: torch.Tensor, coefs: torch.Tensor, axis: int) -> torch.Tensor:
     """one axis of PIL's 8-bit bicubic resample: x u8 contiguous, out the same shape with `axis` resized to bounds.shape[0];
     bounds int32 [n_out, 2], coefs int32 [n_out, ksize] (internnav_amd.preprocess builds PIL's tables)."""

@@ -63,6 +63,22 @@ def prof_enable(on: bool) -> None:
     _lib.check(_lib.lib().ina_prof_enable(1 if on else 0), "prof_enable")
 
 
+GEMM_SUBS = {18: "gemm_bf16_pp_kernel<256,256,4>", 21: "gemm_bf16_pp_kernel<192,256,4>", 22: "gemm_bf16_glds_kernel<128,128,2,2,1>",
+             11: "gemm_bf16_glds_kernel<128,128,2,2,2>", 14: "gemm_bf16_glds_kernel<256,128,4,2,3>", 1: "gemm_bf16_nt_kernel<128,128,64,2,2>",
+             2: "gemm_bf16_nt_kernel<64,128,64,2,2>", 3: "gemm_bf16_nt_kernel<64,128,64,1,4>", 40: "dit_ffn_kernel", 41: "gemm_rownorm_kernel"}
+
+
+def prof_read_gemm_kernels() -> Dict[str, dict]:
+    """the tiled-GEMM class split by kernel (tile config): summed event time, launches, algorithmic FLOPs of each named kernel."""
+    out = {}
+    for sub, name in GEMM_SUBS.items():
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().ina_prof_read_sub(0, sub, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "prof_read_sub")
+        if n.value:
+            out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out
+
+
 def prof_read() -> Dict[str, dict]:
     """Totals per kernel class since prof_enable(True): summed event-pair time (ms), launches, algorithmic FLOPs and bytes."""
     out = {}

@@ -27,16 +27,17 @@ def test_pool_act(built_lib):
     assert torch.allclose(o2.float(), torch.nn.functional.silu(t + pos), atol=2e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("fuse_rownorm", [False, True])
-def test_nextdit_generate_traj_vs_reference_fixture(built_lib, fuse_rownorm):
-    """fuse_rownorm: attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + pre-norm epilogue (gemm_rownorm)."""
+@pytest.mark.parametrize("fuse_rownorm,fuse_ffn", [(False, False), (True, False), (False, True), (True, True)])
+def test_nextdit_generate_traj_vs_reference_fixture(built_lib, fuse_rownorm, fuse_ffn):
+    """fuse_rownorm: attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + pre-norm epilogue (gemm_rownorm);
+    fuse_ffn: the whole SwiGLU feed-forward + its gated norm / residual / next pre-norm as one launch (dit_ffn; correct but slower, off by default)."""
     from internnav_amd.nextdit import NextDiTSystem1
 
     gold = torch.load(Path(__file__).resolve().parent / "golden" / "n1_nextdit.pt", weights_only=True)
     B = gold["B"]
     sd = W.n1_nextdit_state_dict(seed=gold["seed"])
     inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
-    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B, fuse_rownorm=fuse_rownorm)
+    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B, fuse_rownorm=fuse_rownorm, fuse_ffn=fuse_ffn)
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), inp["images"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV))
     d = (out.float().cpu() - gold["latents"]).abs()
     ref = gold["latents"].abs().max().item()

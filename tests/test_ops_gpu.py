@@ -552,3 +552,38 @@ def test_gemm_rownorm_fused_block_epilogue(ops, M, K, with_h):
     xu, hu = x0.clone(), torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
     ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
     _close(x, xu, rtol=1.0 / 128, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,with_h,alias", [(64, True, False), (200, True, True), (1024 + 37, False, False), (4096, True, True)])
+def test_dit_ffn_fused_swiglu_block(ops, M, with_h, alias):
+    """fused SwiGLU FFN (GLU GEMM -> F chunk in LDS -> linear_2 -> gated rmsnorm + residual + next pre-norm) vs the fp32 formula and vs
+    the three launches it replaces; M not a multiple of the 64-row tile; H aliasing the input (the NextDiT engine's usage)."""
+    D, F, div = 384, 1024, 96
+    g = torch.Generator().manual_seed(M + 7)
+    h_in = _rand((M, D), g)
+    w1, w3 = _rand((F, D), g, scale=D ** -0.5), _rand((F, D), g, scale=D ** -0.5)
+    w2 = _rand((D, F), g, scale=F ** -0.5)
+    w13 = torch.stack([w1.view(F // 16, 16, D), w3.view(F // 16, 16, D)], dim=1).reshape(2 * F, D).contiguous()
+    x0 = torch.randn(M, D, generator=g).to(_dev())
+    g1, g2 = [(1.0 + 0.1 * torch.randn(D, generator=g)).to(_dev()) for _ in range(2)]
+    nb = (M + div - 1) // div
+    mod = (0.5 * torch.randn(nb, 2 * D, generator=g)).to(_dev())
+    gate, ms2 = mod[:, :D], mod[:, D:]
+    x = x0.clone()
+    h_src = h_in.clone()
+    h = (h_src if alias else torch.empty(M, D, dtype=torch.bfloat16, device=_dev())) if with_h else None
+    ops.dit_ffn(h_src, w13, w2, g1, x, gate=gate, h=h, gamma2=g2, mod_scale2=ms2, mod_div=div)
+    rms = lambda t: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5)
+    rowb = torch.arange(M, device=_dev()) // div
+    hf = h_in.float()
+    ff = (torch.nn.functional.silu(hf @ w1.float().t()) * (hf @ w3.float().t())).to(torch.bfloat16).float()   # F is bf16 between the GEMMs, as unfused
+    x_ref = x0 + torch.tanh(gate[rowb]) * rms(ff @ w2.float().t()) * g1
+    _close(x, x_ref, rtol=2e-3, atol=5e-3)
+    if with_h:
+        _close(h, rms(x_ref) * g2 * (1.0 + ms2[rowb]), rtol=1.0 / 128, atol=1e-2)
+    # the three launches it replaces
+    fu = ops.linear(h_in, w13, act="silu", glu=True)
+    pj = ops.linear(fu, w2)
+    xu, hu = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device=_dev())
+    ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
+    _close(x, xu, rtol=1.0 / 128, atol=2e-2)
