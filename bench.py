@@ -100,10 +100,14 @@ class NavDPS1:
         self.inp["x_init"].normal_(generator=self.g)
         self.inp["step_noise"].normal_(generator=self.g)
         neg, pos = self.graph() if self.graph else self._call(**self.inp)
+        self.last_out = pos
         return pos
 
     def instrumented(self):
         self._call(**self.inp)
+
+    def step_output_for_check(self):
+        return self.last_out
 
     def cpu_baseline(self):
         from internnav_amd import synthetic
@@ -374,6 +378,9 @@ class N1Dual:
         traj = self.s1_graph() if self.s1_graph else self._s1_call()
         return self._finish(traj)
 
+    def step_output_for_check(self):
+        return self.actions
+
     def instrumented(self):
         m = max(self.mb)
         self._s2_call(m)
@@ -472,8 +479,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
+        from internnav_amd.dist import pin_host_threads
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # own slice of the host cores per rank
     wl = (N1Dual if a.workload == "n1_dual" else NavDPS1)(a, dev, rank)
     if not a.no_graph:
         wl.capture()
@@ -503,6 +513,15 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
+        # the exchanged actions are really everybody's: this rank's slice equals its own last output, every slice is a valid action table
+        mine = wl.step_output_for_check()
+        assert torch.equal(gathered[rank * wl.B:(rank + 1) * wl.B], mine), "all_gather: own slice differs from the local actions"
+        if a.workload == "n1_dual":
+            assert int(gathered.min()) >= 0 and int(gathered.max()) <= 3, "all_gather: action ids outside {0..3}"
+        chk = torch.stack([gathered[r * wl.B:(r + 1) * wl.B].double().sum() for r in range(world)])
+        ref = chk.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(chk, ref), "all_gather: ranks hold different gathered tensors"
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -514,9 +533,9 @@ def main():
         extra = wl.instrumented()
         torch.cuda.synchronize()
         prof = runtime.prof_read()
-        runtime.prof_enable(False)
-        gm = prof["gemm"]
         per_kernel = runtime.prof_read_gemm_kernels()
+        runtime.prof_enable(False)               # (also clears the tally)
+        gm = prof["gemm"]
         blend = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         # the dominant kernel = the named kernel with the largest share of the step's GEMM time
         dom_name, dom = max(per_kernel.items(), key=lambda kv: kv[1]["ms"]) if per_kernel else ("none", dict(ms=0.0, launches=0, flops=0.0))

@@ -181,9 +181,9 @@ class InternVLAN1Agent:
         raise ValueError(f"Invalid mode: {self.mode}")
 
     def _run_s2(self, jobs, retry: bool = True):
-        """batched System-2 over the envs whose plan expired. Prompts are built per env (host), batched by (length, image grids) -
-        the engine batches equal-length sequences - in chunks of the engine's capacity. An env whose turn fails is reset and retried
-        once without look-down, then STOPs (reference :156-189); fatal errors propagate."""
+        """batched System-2 over the envs whose plan expired. Prompts are built per env (host) and run as ragged batches in chunks of
+        the engine's capacity. An env whose turn fails is reset and retried once without look-down, then STOPs (reference :156-189);
+        fatal errors propagate."""
         built, failed = [], []
         for e, o in jobs:
             try:
@@ -193,21 +193,36 @@ class InternVLAN1Agent:
                 raise
             except Exception as ex:  # noqa: BLE001
                 failed.append((e, o, ex))
-        groups: Dict[Any, list] = {}
-        for item in built:
-            ids = item[2]["input_ids"]
-            groups.setdefault((ids.shape[1], tuple(map(tuple, item[2]["image_grid_thw"].tolist()))), []).append(item)
+        # ONE ragged batch per engine-capacity chunk: prompts of different lengths (instruction length, number of history frames, a
+        # camera-size look-down frame) are right-padded to the longest of the chunk - causal attention makes the padding invisible to
+        # the real tokens (QwenVLEngine.prefill seq_lens). Sorted by length so a chunk pads as little as possible.
+        built.sort(key=lambda it: it[2]["input_ids"].shape[1])
+        groups = {0: built} if built else {}
         for items_all in groups.values():
             model = items_all[0][0].policy.model
             cap = getattr(getattr(model, "qwen", None), "B_max", None) or len(items_all)
             for c0 in range(0, len(items_all), cap):
                 items = items_all[c0:c0 + cap]
                 try:
-                    ids = torch.cat([it[2]["input_ids"] for it in items], 0)
+                    lens = [int(it[2]["input_ids"].shape[1]) for it in items]
+                    ids = torch.zeros(len(items), max(lens), dtype=torch.long)
+                    mask = torch.zeros(len(items), max(lens), dtype=torch.long)
+                    for r, (it, L) in enumerate(zip(items, lens)):
+                        ids[r, :L], mask[r, :L] = it[2]["input_ids"][0], 1
+                    ragged = {"attention_mask": mask} if min(lens) != max(lens) else {}
                     pv = torch.cat([it[2]["pixel_values"] for it in items], 0)
                     grid = torch.cat([it[2]["image_grid_thw"] for it in items], 0)
+                    extra = {}
+                    if all("cached_image_embeds" in it[2] for it in items):        # per-frame ViT cache of the policies (device pre-processing)
+                        extra["cached_image_embeds"] = [c for it in items for c in it[2]["cached_image_embeds"]]
                     seqs = model.generate(input_ids=ids, pixel_values=pv, image_grid_thw=grid, max_new_tokens=128, do_sample=False,
-                                          use_cache=True, past_key_values=None, return_dict_in_generate=True).sequences
+                                          use_cache=True, past_key_values=None, return_dict_in_generate=True, **ragged, **extra).sequences
+                    if extra:
+                        fresh, o = model.last_image_embeds(), 0
+                        for e, _, inputs in items:
+                            n = len(inputs["cached_image_embeds"])
+                            e.policy.update_frame_cache(inputs, {k - o: v for k, v in fresh.items() if o <= k < o + n})
+                            o += n
                 except _FATAL:
                     raise
                 except Exception as ex:  # noqa: BLE001
@@ -215,9 +230,9 @@ class InternVLAN1Agent:
                     continue
                 lat_cache = {}
 
-                def latents(seqs=seqs, pv=pv, grid=grid, lat_cache=lat_cache):
+                def latents(seqs=seqs, pv=pv, grid=grid, lat_cache=lat_cache, extra=extra):
                     if "v" not in lat_cache:
-                        lat_cache["v"] = model.generate_latents(seqs, pv, grid)
+                        lat_cache["v"] = model.generate_latents(seqs, pv, grid, **extra)
                     return lat_cache["v"]
 
                 for k, (e, o, inputs) in enumerate(items):

@@ -59,3 +59,20 @@ def all_gather_metrics(local: torch.Tensor) -> torch.Tensor:
     got = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(got, pad)
     return torch.cat([g[:l] for g, l in zip(got, lens)])
+
+
+def pin_host_threads(local_rank: int, local_world: int) -> int:
+    """Give each rank of a node its own slice of the host cores (contiguous block local_rank of local_world) and size torch's CPU
+    thread pool to it: the per-step host post-processing (traj_to_actions per env, prompt building, tokenisation) of 8 ranks must not
+    contend for the same cores. Returns the number of cores this rank owns. No-op where the OS offers no affinity control."""
+    if local_world <= 1 or not hasattr(os, "sched_getaffinity"):
+        return os.cpu_count() or 1
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return len(cores)
+    torch.set_num_threads(max(1, len(mine)))
+    return len(mine)

@@ -243,13 +243,22 @@ class InternVLAN1ForCausalLM:
     # ---- System 2
     def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, attention_mask=None, max_new_tokens: int = 128,
                  do_sample: bool = False, use_cache: bool = True, past_key_values=None, return_dict_in_generate: bool = False,
-                 decode_chunk: int = 8, eos_token_id=None, **_):
+                 decode_chunk: int = 8, eos_token_id=None, cached_image_embeds: Optional[list] = None, **_):
         """greedy decoding (do_sample=False is the only mode the reference uses, internvla_n1_policy.py:169-176). Decodes in chunks of
-        `decode_chunk` device-side steps and stops once every sequence has emitted EOS. Sequences are right-filled with EOS."""
+        `decode_chunk` device-side steps and stops once every sequence has emitted EOS. Sequences are right-filled with EOS.
+        cached_image_embeds (extension, per-frame ViT cache): one entry per image of the batch, None = encode it (its patches are in
+        pixel_values), else the embeddings an earlier call returned through `last_image_embeds()`."""
         assert not do_sample, "the reference only decodes greedily"
         eos = self.qwen.cfg["eos_token_id"] if eos_token_id is None else eos_token_id
-        pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None else None
-        state = self.qwen.prefill(input_ids, pv, image_grid_thw)
+        pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None and pixel_values.numel() else None
+        B, S = input_ids.shape
+        # ragged batch (extension; the reference is batch 1): prompts RIGHT-padded to a common length, real lengths from attention_mask
+        plens = np.full(B, S, dtype=np.int64) if attention_mask is None else np.asarray(attention_mask.cpu().long().sum(1), dtype=np.int64)
+        if attention_mask is not None:
+            am = attention_mask.cpu().long()
+            assert bool((am[:, 1:] <= am[:, :-1]).all()), "ragged System-2 batches are right-padded (mask = 1...1 0...0)"
+        state = self.qwen.prefill(input_ids, pv, image_grid_thw, cached_embeds=cached_image_embeds, seq_lens=plens if attention_mask is not None else None)
+        self._fresh = self.qwen.fresh_image_embeds(state["plan"]) if cached_image_embeds is not None else {}
         chunks, n = [], 0
         while n < max_new_tokens:
             k = min(decode_chunk, max_new_tokens - n)
@@ -266,22 +275,36 @@ class InternVLAN1ForCausalLM:
             e = int(hit[0]) + 1 if hit.numel() else toks.shape[1]
             toks[b, e:] = eos
             lens.append(e)
-        self._gen = dict(state=state, tokens=toks, lens=np.asarray(lens), prompt_len=input_ids.shape[1])
-        seqs = torch.cat([input_ids.cpu().long(), toks], dim=1).to(self.device)
+        self._gen = dict(state=state, tokens=toks, lens=np.asarray(lens), prompt_lens=plens)
+        # every row = its own prompt, then its answer, right-filled with EOS to the common width S + n
+        ids_cpu = input_ids.cpu().long()
+        seqs = torch.full((B, S + toks.shape[1]), eos, dtype=torch.long)
+        for b in range(B):
+            L = int(plens[b])
+            seqs[b, :L] = ids_cpu[b, :L]
+            seqs[b, L:L + toks.shape[1]] = toks[b]
+        seqs = seqs.to(self.device)
         return SimpleNamespace(sequences=seqs) if return_dict_in_generate else seqs
 
-    def generate_latents(self, output_ids, pixel_values, image_grid_thw):
+    def last_image_embeds(self) -> Dict[int, torch.Tensor]:
+        """image index (position in the last generate() call's image list) -> merged embeddings bf16 [tokens, 3584] of every image that
+        call encoded; only filled when generate() was given `cached_image_embeds` (i.e. by callers that keep a frame cache)."""
+        return getattr(self, "_fresh", {})
+
+    def generate_latents(self, output_ids, pixel_values, image_grid_thw, cached_image_embeds: Optional[list] = None):
         """[B, N_QUERY, 3584] hidden states of the latent trajectory queries (internvla_n1.py:320-347). When called right after
         generate() on its own output (the reference's only usage, internvla_n1_policy.py:191) the KV cache is reused: the queries
         are placed behind each sequence's last kept token; otherwise the full prompt is re-run."""
         g = getattr(self, "_gen", None)
-        if g is not None and output_ids.shape[1] == g["prompt_len"] + g["tokens"].shape[1] and \
-                torch.equal(output_ids[:, g["prompt_len"]:].cpu().long(), g["tokens"]):
-            S, lens, toks = g["prompt_len"], g["lens"], g["tokens"]
-            last = torch.stack([toks[b, lens[b] - 1] for b in range(toks.shape[0])]).to(self.device, torch.int32).view(-1, 1)
-            return self.qwen.latents(g["state"], last.contiguous(), seq_lens=S + lens - 1)
-        pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None else None
-        return self.qwen.generate_latents(output_ids, pv, image_grid_thw)
+        if g is not None and output_ids.shape[0] == g["tokens"].shape[0]:
+            pl, lens, toks = g["prompt_lens"], g["lens"], g["tokens"]
+            oc = output_ids.cpu().long()
+            nt = toks.shape[1]
+            if all(int(pl[b]) + nt <= oc.shape[1] and torch.equal(oc[b, int(pl[b]):int(pl[b]) + nt], toks[b]) for b in range(toks.shape[0])):
+                last = torch.stack([toks[b, lens[b] - 1] for b in range(toks.shape[0])]).to(self.device, torch.int32).view(-1, 1)
+                return self.qwen.latents(g["state"], last.contiguous(), seq_lens=pl + lens - 1)
+        pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None and pixel_values.numel() else None
+        return self.qwen.generate_latents(output_ids, pv, image_grid_thw, cached_embeds=cached_image_embeds)
 
     # ---- System 1
     def generate_traj(self, traj_latents, images_dp, depths_dp=None, predict_step_nums: int = 32, guidance_scale: float = 1.0,
@@ -376,7 +399,8 @@ class InternVLAN1Net:
     _shared: Dict[Any, Any] = {}   # (model_path, device) -> (model, processor): one set of engines per GPU process, shared by all envs
 
     def __init__(self, config=None, processor=None, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
-                 continuous_traj: bool = True, frame_preprocessor=None, model: Optional[InternVLAN1ForCausalLM] = None):
+                 continuous_traj: bool = True, frame_preprocessor=None, model: Optional[InternVLAN1ForCausalLM] = None,
+                 vit_cache: bool = False):
         """Two ways in, both ending in (model, processor, episode state):
           * the reference's: `InternVLAN1Net(config=InternVLAN1ModelConfig(model_cfg={'model': model_settings}))`
             (internvla_n1_agent.py:39-43, internvla_n1_policy.py:29-48) - loads the checkpoint at model_settings['model_path'] on
@@ -399,6 +423,10 @@ class InternVLAN1Net:
                 frame_preprocessor = FramePreprocessor(model.device, resize_w=resize_w, resize_h=resize_h)
         self.model_config = SimpleNamespace(num_history=num_history, resize_w=resize_w, resize_h=resize_h, continuous_traj=continuous_traj)
         self.model, self.processor, self.pre = model, processor, frame_preprocessor
+        # per-frame ViT cache (needs the device pre-processor): the embeddings of the frames of the previous System-2
+        # call are kept, so the look-down turn (which re-sends every image of the turn before, internvla_n1_policy.py:140-147) and
+        # re-sampled history frames (frame 0 is in every np.linspace sample) skip the vision tower. Exact: the tower attends per image.
+        self.vit_cache = bool(vit_cache or (config is not None and dict(config.model_cfg["model"]).get("vit_cache", False))) and frame_preprocessor is not None
         self.tokenizer = getattr(processor, "tokenizer", None)
         self.num_history, self.resize_w, self.resize_h, self.continuous_traj = num_history, resize_w, resize_h, continuous_traj
         self.device = model.device
@@ -431,7 +459,7 @@ class InternVLAN1Net:
     def spawn(self) -> "InternVLAN1Net":
         """a fresh episode state on the same model / processor (the batched agent keeps one per environment)."""
         return InternVLAN1Net(processor=self.processor, num_history=self.num_history, resize_w=self.resize_w, resize_h=self.resize_h,
-                              continuous_traj=self.continuous_traj, frame_preprocessor=self.pre, model=self.model)
+                              continuous_traj=self.continuous_traj, frame_preprocessor=self.pre, model=self.model, vit_cache=self.vit_cache)
 
     def eval(self):
         return self
@@ -442,6 +470,8 @@ class InternVLAN1Net:
         self.conversation_history = []
         self.llm_output = ""
         self.input_images = []
+        self.input_keys = []          # frame identity of every input image: index into rgb_list, or "look_down"
+        self._emb_cache = {}          # frame key -> (embeds bf16 [tokens, H], grid) of the frames of the last System-2 call
 
     def parse_actions(self, output: str) -> List[int]:
         regex = re.compile("|".join(re.escape(a) for a in self.ACTIONS2IDX))
@@ -473,10 +503,12 @@ class InternVLAN1Net:
                 history_id = np.unique(np.linspace(0, self.episode_idx - 1, self.num_history, dtype=np.int32)).tolist()
                 text += f" These are your historical observations: {('<image>' + chr(10)) * len(history_id)}."
             self.input_images = [self.rgb_list[i] for i in sorted(history_id)] + self.rgb_list[-1:]
+            self.input_keys = sorted(history_id) + [len(self.rgb_list) - 1]
             img_id = 0
             self.episode_idx += 1
         else:
             self.input_images.append(image)
+            self.input_keys = list(self.input_keys) + ["look_down"]
             img_id = -1
             assert self.llm_output != "", "Last llm_output should not be empty when look down"
             text = ""
@@ -495,7 +527,19 @@ class InternVLAN1Net:
             return self.processor(text=[chat], images=self.input_images, return_tensors="pt")
         # device pre-processing: pixel_values / grid from the raw frames; the text side restates Qwen2VLProcessor.__call__ - every
         # image placeholder is expanded to grid.prod() / merge^2 image tokens before tokenisation
-        pixel_values, grid = self.pre.processor_pixel_values(self.input_images)
+        cached = None
+        if self.vit_cache:
+            hit = [self._emb_cache.get(k) if k != "look_down" else None for k in self.input_keys]
+            cached = [h[0] if h is not None else None for h in hit]
+            fresh = [im for im, h in zip(self.input_images, hit) if h is None]
+            if fresh:
+                pixel_values, fgrid = self.pre.processor_pixel_values(fresh)
+            else:
+                pixel_values, fgrid = torch.empty(0, 1176, dtype=torch.bfloat16, device=self.pre.device), torch.empty(0, 3, dtype=torch.int64)
+            it = iter(fgrid.tolist())
+            grid = torch.tensor([h[1] if h is not None else next(it) for h in hit], dtype=torch.int64)
+        else:
+            pixel_values, grid = self.pre.processor_pixel_values(self.input_images)
         tok = getattr(self.processor, "image_token", "<|image_pad|>")
         merge2 = self.pre.merge ** 2
         parts = chat.split(tok)
@@ -504,7 +548,25 @@ class InternVLAN1Net:
         for g, rest in zip(grid.tolist(), parts[1:]):
             expanded += tok * (g[0] * g[1] * g[2] // merge2) + rest
         enc = self.processor.tokenizer([expanded], return_tensors="pt")
-        return {"input_ids": enc["input_ids"], "pixel_values": pixel_values, "image_grid_thw": grid}
+        out = {"input_ids": enc["input_ids"], "pixel_values": pixel_values, "image_grid_thw": grid}
+        if cached is not None:
+            out["cached_image_embeds"] = cached
+        return out
+
+    def update_frame_cache(self, inputs, fresh: Dict[int, torch.Tensor]):
+        """keep the embeddings of exactly the frames of this call (bounded: <= num_history + 2 frames of 196 - 391 tokens)."""
+        if not self.vit_cache:
+            return
+        grids = inputs["image_grid_thw"].tolist()
+        new = {}
+        for k, key in enumerate(self.input_keys):
+            if key == "look_down":
+                continue
+            c = inputs["cached_image_embeds"][k]
+            e = c if c is not None else fresh.get(k)
+            if e is not None:
+                new[key] = (e, grids[k])
+        self._emb_cache = new
 
     def finish_s2(self, inputs, output_ids, latents_fn) -> S2Output:
         """steps 3-4 of s2_step (internvla_n1_policy.py:177-197): decode text, pixel goal -> latents, else discrete actions."""
@@ -524,9 +586,12 @@ class InternVLAN1Net:
 
     def s2_step(self, rgb, depth, pose, instruction, intrinsic, look_down: bool = False) -> S2Output:
         inputs = self.build_s2_inputs(rgb, instruction, look_down)
+        extra = {"cached_image_embeds": inputs["cached_image_embeds"]} if "cached_image_embeds" in inputs else {}
         ids = self.model.generate(input_ids=inputs["input_ids"], pixel_values=inputs["pixel_values"], image_grid_thw=inputs["image_grid_thw"],
-                                  max_new_tokens=128, do_sample=False, use_cache=True, past_key_values=None, return_dict_in_generate=True).sequences
-        return self.finish_s2(inputs, ids, lambda: self.model.generate_latents(ids, inputs["pixel_values"], inputs["image_grid_thw"]))
+                                  max_new_tokens=128, do_sample=False, use_cache=True, past_key_values=None, return_dict_in_generate=True, **extra).sequences
+        if extra:
+            self.update_frame_cache(inputs, self.model.last_image_embeds())
+        return self.finish_s2(inputs, ids, lambda: self.model.generate_latents(ids, inputs["pixel_values"], inputs["image_grid_thw"], **extra))
 
     def s1_step_latent(self, rgb, depth, latent) -> S1Output:
         dp_actions = self.model.generate_traj(traj_latents=latent, images_dp=rgb, depths_dp=depth)

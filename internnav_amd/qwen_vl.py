@@ -163,6 +163,7 @@ class QwenVLEngine:
         self.ffv = torch.empty(Np, Ip, dtype=bf, device=dev)
         self.mh = torch.empty(Np // 4, 4 * D, dtype=bf, device=dev)
         self.emb = torch.empty(Np // 4, cfg["v_out"], dtype=bf, device=dev)
+        self.emb_tok = torch.empty(Np // 4, cfg["v_out"], dtype=bf, device=dev)   # the same rows in image-token order (what a per-frame cache keeps)
         self.v_cos = torch.empty(Np, self.vhd, dtype=f32, device=dev)
         self.v_sin = torch.empty(Np, self.vhd, dtype=f32, device=dev)
         # ---- text model
@@ -191,6 +192,7 @@ class QwenVLEngine:
         self.cos = torch.empty(rows, self.hd, dtype=f32, device=dev)
         self.sin = torch.empty(rows, self.hd, dtype=f32, device=dev)
         self.hl = torch.empty(max_seqs * 8, H, dtype=bf, device=dev)
+        self.xl = torch.empty(max_seqs, H, dtype=f32, device=dev)
         self.logits = torch.empty(max_seqs, cfg["vocab"], dtype=f32, device=dev)
         self.next_tok = torch.empty(max_seqs, dtype=torch.int32, device=dev)
         half = self.hd // 2
@@ -282,16 +284,24 @@ class QwenVLEngine:
             if self.tap is not None:
                 self.tap("llm", li, x)
 
-    def _last_logits(self, B: int, S: int, row_in_seq: int):
-        """final RMSNorm + lm_head on ONE row per sequence, greedy argmax on the device."""
-        ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
+    def _last_logits(self, B: int, S: int, row_in_seq, rows_idx: Optional[torch.Tensor] = None):
+        """final RMSNorm + lm_head on ONE row per sequence, greedy argmax on the device. row_in_seq: the same row for every sequence,
+        or (ragged batches) rows_idx int32 [B] = absolute row of each sequence's last real token."""
+        if rows_idx is not None:
+            ops.gather_rows(self.x[: B * S], self.xl[:B], src=rows_idx)
+            ops.norm(self.xl[:B], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B)
+        else:
+            ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
         ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B])
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)
-    def plan(self, input_ids, image_grid_thw, n_decode: int = 0, with_latents: bool = False) -> dict:
+    def plan(self, input_ids, image_grid_thw, n_decode: int = 0, with_latents: bool = False, cached_embeds: Optional[list] = None) -> dict:
         """Host-side plan of one S2 call for B equal-length prompts: embedding / scatter indices, vision plan, position ids and cache
-        rows of the prefill, of every decode step and of the latent-query pass (fixed-length answers of n_decode tokens)."""
+        rows of the prefill, of every decode step and of the latent-query pass (fixed-length answers of n_decode tokens).
+        cached_embeds: one entry per image (prompt order over the batch), None = run the vision tower on it, else its merged embeddings
+        bf16 [h*w/4, H] in token order from an earlier call (per-frame ViT cache, SURVEY.md 8f-1: the tower attends per image, so a
+        frame's embeddings do not depend on what else is in the batch). pixel_values then holds the patches of the fresh images only."""
         cfg, dev = self.cfg, self.device
         ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
         B, S = ids.shape
@@ -299,12 +309,27 @@ class QwenVLEngine:
             raise CapacityError(f"System-2 batch of {B} x {S} tokens exceeds the engine's max_seqs={self.B_max} / max_seq_len={self.S_max}")
         grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
         flat = ids.reshape(-1)
-        P = dict(B=B, S=S, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None)
+        P = dict(B=B, S=S, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None, cached=[], fresh_tokens=[])
         img_pos = np.nonzero(flat == cfg["image_token_id"])[0].astype(np.int32)
         if grids:
-            vp = self.plan_vision(grids)
-            assert img_pos.size == vp["inv"].size, f"Image features and image tokens do not match: tokens: {img_pos.size}, features {vp['inv'].size}"
-            P["vision"], P["img_src"], P["img_dst"] = vp, torch.from_numpy(vp["inv"]).to(dev), torch.from_numpy(img_pos).to(dev)
+            ntok = [t * h * w // 4 for t, h, w in grids]
+            assert img_pos.size == sum(ntok), f"Image features and image tokens do not match: tokens: {img_pos.size}, features {sum(ntok)}"
+            off = np.concatenate([[0], np.cumsum(ntok)])
+            cached = list(cached_embeds) if cached_embeds is not None else [None] * len(grids)
+            assert len(cached) == len(grids)
+            fresh = [k for k, c in enumerate(cached) if c is None]
+            if fresh:
+                vp = self.plan_vision([grids[k] for k in fresh])
+                dst = np.concatenate([img_pos[off[k]:off[k + 1]] for k in fresh])
+                P["vision"], P["img_src"], P["img_dst"] = vp, torch.from_numpy(vp["inv"]).to(dev), torch.from_numpy(dst).to(dev)
+                o = 0
+                for k in fresh:
+                    P["fresh_tokens"].append((k, o, o + ntok[k]))      # rows of emb_tok that hold image k after run_prefill
+                    o += ntok[k]
+            for k, c in enumerate(cached):
+                if c is not None:
+                    assert c.shape == (ntok[k], self.H) and c.dtype == torch.bfloat16, f"cached embeds of image {k}: {tuple(c.shape)} vs grid {grids[k]}"
+                    P["cached"].append((c, torch.from_numpy(img_pos[off[k]:off[k + 1]]).to(dev)))
         traj_pos = np.nonzero(flat == cfg["traj_token_id"])[0].astype(np.int32)
         if traj_pos.size:
             nq = self.latent_q.shape[0]
@@ -328,10 +353,19 @@ class QwenVLEngine:
         ops.gather_rows(self.embed, self.x_in, src=P["ids"])
         if P["vision"] is not None:
             emb = self.run_vision(P["vision"], pixel_values)
-            ops.gather_rows(emb, self.x_in, src=P["img_src"], dst=P["img_dst"])
+            n = P["img_src"].shape[0]
+            ops.gather_rows(emb, self.emb_tok[:n], src=P["img_src"])          # window order -> image-token order (kept for the frame cache)
+            ops.gather_rows(self.emb_tok[:n], self.x_in, dst=P["img_dst"])
+        for c, dst in P["cached"]:
+            ops.gather_rows(c, self.x_in, dst=dst)
         if "traj_src" in P:
             ops.gather_rows(self.latent_q, self.x_in, src=P["traj_src"], dst=P["traj_dst"])
         self._layers(P["prefill"])
+
+    def fresh_image_embeds(self, P: dict) -> Dict[int, torch.Tensor]:
+        """image index -> a copy of its merged embeddings bf16 [h*w/4, H] (token order) as computed by the last run_prefill(P):
+        what a caller stores in its per-frame cache and hands back through plan(..., cached_embeds=...)."""
+        return {k: self.emb_tok[a:b].clone() for k, a, b in P["fresh_tokens"]}
 
     def run_decode(self, P: dict, tokens_out: torch.Tensor):
         """n_decode greedy tokens: the first from the prompt's last position, then n_decode - 1 single-token passes."""
@@ -368,26 +402,50 @@ class QwenVLEngine:
             self.run_latents(P, latents_out)
 
     # ---- eager, stateful API (used by the policy layer: answers have data-dependent lengths)
-    def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor], image_grid_thw) -> dict:
-        P = self.plan(input_ids, image_grid_thw)
+    def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor], image_grid_thw, cached_embeds: Optional[list] = None,
+                seq_lens=None) -> dict:
+        """seq_lens [B] (optional): RAGGED batch - input_ids is right-padded to a common length S and sequence b has seq_lens[b] real
+        tokens. Causal attention keeps every real position independent of the padding behind it, so the prefill runs on the padded
+        rectangle; the first token is read at each sequence's own last position and the decode / latent passes append at per-sequence
+        cache positions with per-sequence key lengths (the pad rows' K/V are never attended and get overwritten)."""
+        P = self.plan(input_ids, image_grid_thw, cached_embeds=cached_embeds)
         self.run_prefill(P, pixel_values)
-        return dict(B=P["B"], S=P["S"], next_pos=P["next_pos"].copy())
+        st = dict(B=P["B"], S=P["S"], next_pos=P["next_pos"].copy(), plan=P)
+        if seq_lens is not None:
+            lens = np.asarray(seq_lens, dtype=np.int64)
+            assert lens.shape == (P["B"],) and int(lens.max()) <= P["S"] and int(lens.min()) >= 1
+            if bool((lens != P["S"]).any()):
+                ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
+                grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
+                pos3, _ = rope_index(ids, grids, self.cfg["image_token_id"], self.cfg["vision_start_id"])
+                st["next_pos"] = np.asarray([int(pos3[:, b, : lens[b]].max()) + 1 for b in range(P["B"])], dtype=np.int64)
+                st["lens"] = lens
+        return st
 
     def decode(self, state: dict, n_steps: int) -> torch.Tensor:
         """n greedy steps after prefill (or after a previous decode); returns int32 [B, n] generated tokens (device). The last
         returned token is sampled but not yet run through the layers (its K/V are not cached)."""
         B, S = state["B"], state["S"]
         out = torch.empty(B, n_steps, dtype=torch.int32, device=self.device)
+        lens = state.get("lens")
         if "cur" not in state:
-            self._last_logits(B, S, S - 1)
-            state["cur"] = S
+            if lens is None:
+                self._last_logits(B, S, S - 1)
+                state["cur"] = S
+            else:
+                rows = torch.from_numpy((np.arange(B) * S + lens - 1).astype(np.int32)).to(self.device)
+                self._last_logits(B, S, None, rows_idx=rows)
+                state["cur"] = lens.copy()
         for j in range(n_steps):
             out[:, j].copy_(self.next_tok[:B])
             if j == n_steps - 1:
                 break
             cur = state["cur"]
             ops.gather_rows(self.embed, self.x_in, src=self.next_tok[:B], rows=B)
-            self._layers(self._phase(B, 1, state["next_pos"][None, :, None], cur))
+            if lens is None:
+                self._layers(self._phase(B, 1, state["next_pos"][None, :, None], cur))
+            else:
+                self._layers(self._phase(B, 1, state["next_pos"][None, :, None], cur, k_len=cur + 1))
             self._last_logits(B, 1, 0)
             state["cur"] = cur + 1
             state["next_pos"] = state["next_pos"] + 1
@@ -402,13 +460,15 @@ class QwenVLEngine:
         nq = self.latent_q.shape[0]
         m = 0 if tail_tokens is None else tail_tokens.shape[1]
         rows = B * (m + nq)
-        cur = state.get("cur", state["S"])
+        cur = state.get("cur", state.get("lens", state["S"]))
         x3 = self.x_in[:rows].view(B, m + nq, H)
         if m:
             tmp = self.hl[: B * m]
             ops.gather_rows(self.embed, tmp, src=tail_tokens.reshape(-1).contiguous(), rows=B * m)
             x3[:, :m].copy_(tmp.view(B, m, H))
         x3[:, m:].copy_(self.latent_q.view(1, nq, H).expand(B, nq, H))
+        if seq_lens is None and np.ndim(cur) > 0:
+            seq_lens = cur                                            # ragged batch: keep everything cached so far, per sequence
         if seq_lens is None:
             p = state["next_pos"][None, :, None] + np.arange(m + nq)[None, None, :]
             ph = self._phase(B, m + nq, p, cur)
@@ -435,12 +495,12 @@ class QwenVLEngine:
         self._state = state
         return torch.cat([input_ids.cpu().long(), toks], dim=1)
 
-    def generate_latents(self, output_ids, pixel_values=None, image_grid_thw=None):
+    def generate_latents(self, output_ids, pixel_values=None, image_grid_thw=None, cached_embeds: Optional[list] = None):
         """reference signature (internvla_n1.py:320): full prefill over output_ids + N_QUERY latent queries (no cache reuse)."""
         cfg = self.cfg
         nq = self.latent_q.shape[0]
         ids = torch.cat([output_ids.cpu().long(), torch.full((output_ids.shape[0], nq), cfg["traj_token_id"], dtype=torch.long)], dim=1)
-        P = self.plan(ids, image_grid_thw)
+        P = self.plan(ids, image_grid_thw, cached_embeds=cached_embeds)
         self.run_prefill(P, pixel_values)
         B, S = P["B"], P["S"]
         out = torch.empty(B, nq, self.H, dtype=torch.bfloat16, device=self.device)

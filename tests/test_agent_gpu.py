@@ -42,11 +42,32 @@ def _write_tokenizer(path, cfg):
     fast.save_pretrained(str(path))
 
 
-def _load_processor(model_path):
+class _ScriptedDecode:
+    """the checkpoint's real tokenizer, except that decode() of an ANSWER returns a scripted System-2 reply: a random-weight LLM emits
+    noise, and the point of the agent test is to drive the pixel-goal / look-down / discrete-action branches through the real engines."""
+    ANSWERS = ["215 206", "↑↑→", "↓", "180 122", "←", "77"]
+
+    def __init__(self, tok):
+        self._tok, self.n = tok, 0
+
+    def __call__(self, *a, **k):
+        return self._tok(*a, **k)
+
+    def __getattr__(self, name):
+        return getattr(self._tok, name)
+
+    def decode(self, ids, skip_special_tokens=True):
+        self.n += 1
+        return self.ANSWERS[(self.n - 1) % len(self.ANSWERS)]
+
+
+def _load_processor(model_path, scripted=False):
     from transformers import AutoTokenizer
 
     tok = AutoTokenizer.from_pretrained(model_path, use_fast=True)
     tok.padding_side = "left"
+    if scripted:
+        tok = _ScriptedDecode(tok)
     return SimpleNamespace(tokenizer=tok, image_token="<|image_pad|>",
                            apply_chat_template=lambda conv, tokenize=False, add_generation_prompt=True: tok.apply_chat_template(
                                conv, tokenize=tokenize, add_generation_prompt=add_generation_prompt))
@@ -103,7 +124,7 @@ def test_agent_from_config_alone_steps_two_envs(ckpt, monkeypatch):
     from internnav_amd.policy import InternVLAN1Net
 
     d, _ = ckpt
-    monkeypatch.setattr(InternVLAN1Net, "load_processor", staticmethod(_load_processor))
+    monkeypatch.setattr(InternVLAN1Net, "load_processor", staticmethod(lambda path: _load_processor(path, scripted=True)))
     InternVLAN1Net._shared.clear()
     agent = InternVLAN1Agent(SimpleNamespace(model_name="internvla_n1", model_settings=_settings(d)))
     assert agent.model.qwen.S_max >= 2155 + 128 and agent.model.qwen.Np_max >= 2 * 8620     # sized for the harness defaults
@@ -118,10 +139,14 @@ def test_agent_from_config_alone_steps_two_envs(ckpt, monkeypatch):
         if step == 5:
             agent.reset([1])
     print("actions", seen, "S2 STOP fallbacks", agent.s2_failures)
+    flat = [a for row in seen for a in row]
+    assert -1 in flat and any(a in (1, 2, 3) for a in flat)       # a look-down turn (-1) and System-1 / discrete motion actions both occurred
+    assert agent.s2_failures <= 4                                 # only the scripted one-number answers ("77") end in the STOP fallback
     # a second agent in the same process re-uses the loaded engines (one set per GPU process)
     n_before = len(InternVLAN1Net._shared)
     InternVLAN1Agent(SimpleNamespace(model_name="internvla_n1", model_settings=_settings(d)))
-    assert len(InternVLAN1Net._shared) == n_before
+    assert len(InternVLAN1Net._shared) == n_before == 1
+    InternVLAN1Net._shared.clear()
 
 
 def test_full_history_plus_camera_size_lookdown_frame_fits(ckpt, monkeypatch):

@@ -188,19 +188,26 @@ class _FakeModel:
     device = torch.device("cpu")
 
     def __init__(self, answers):
-        self.answers, self.batches, self.fail_b = answers, [], None
+        self.answers, self.batches, self.fail_b, self.masks, self.fail_next = answers, [], None, [], 0
 
     def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, **kw):
         from types import SimpleNamespace
 
         B, S = input_ids.shape
         self.batches.append((B, S))
-        if self.fail_b == B:
+        self.masks.append(kw.get("attention_mask"))
+        if self.fail_b == B or self.fail_next > 0:
+            self.fail_next -= 1
             raise RuntimeError("injected S2 failure")
         ans = [self.answers.pop(0) for _ in range(B)]
         n = max(len(a) for a in ans)
-        toks = torch.tensor([[ord(c) for c in a] + [0] * (n - len(a)) for a in ans])
-        return SimpleNamespace(sequences=torch.cat([input_ids, toks], 1))
+        am = kw.get("attention_mask")
+        lens = [S] * B if am is None else am.sum(1).tolist()
+        seqs = torch.zeros(B, S + n, dtype=torch.long)
+        for b, a in enumerate(ans):            # the engine's contract for ragged batches: each row = its own prompt, then its answer
+            seqs[b, :lens[b]] = input_ids[b, :lens[b]]
+            seqs[b, lens[b]:lens[b] + len(a)] = torch.tensor([ord(c) for c in a])
+        return SimpleNamespace(sequences=seqs)
 
     def generate_latents(self, seqs, pv, grid):
         return torch.zeros(seqs.shape[0], 4, 8)
@@ -212,9 +219,10 @@ class _FakeModel:
         return t
 
 
-def test_agent_batches_s2_by_prompt_length_and_falls_back_to_stop_on_failure():
-    """real InternVLAN1Net prompt building (history sampling, chat template, processor call) inside the batched agent: envs with equal
-    prompt lengths share one generate() call; a failing group emits STOP ([0]) for its envs only and the agent never raises (:156-189)."""
+def test_agent_runs_ragged_s2_batches_retries_once_and_falls_back_to_stop():
+    """real InternVLAN1Net prompt building (history sampling, chat template, processor call) inside the batched agent: envs whose
+    prompts differ in length share ONE right-padded generate() call (attention_mask marks the real tokens); a failing call resets
+    its envs and is retried once without look-down, then emits STOP ([0]) - the agent never raises (:156-189)."""
     from internnav_amd.agent import InternVLAN1Agent
 
     model = _FakeModel(["↑↑", "←", "12 34"])
@@ -225,18 +233,23 @@ def test_agent_batches_s2_by_prompt_length_and_falls_back_to_stop_on_failure():
            {"rgb": rgb, "depth": dep, "instruction": "a much longer instruction than the other two"}]
     ag.reset()
     out = ag.step(obs)
-    assert sorted(model.batches) == sorted([(2, model.batches[0][1] if model.batches[0][0] == 2 else model.batches[1][1]), (1, max(b[1] for b in model.batches))])
+    assert len(model.batches) == 1 and model.batches[0][0] == 3            # one ragged batch, padded to the longest prompt
+    m = model.masks[0]
+    assert m is not None and m.sum(1).tolist() == sorted(m.sum(1).tolist()) and int(m.sum(1).max()) == model.batches[0][1] > int(m.sum(1).min())
     assert [o["action"] for o in out][:2] == [[1], [2]]
     assert out[2]["action"] == [1]          # pixel goal "12 34" -> latent -> System-1 -> forward
-    # failure of one length group: only its envs stop
-    model.answers = ["→", "→", "→"]
+    # one transient failure: the envs are reset and the retry (look_down=False) succeeds
     for e in ag.envs:
-        e.s2_output.output_action = None
-        e.s2_output.output_latent = None
-        e.s2_output.output_pixel = None
-    model.fail_b = 1                          # the singleton length group (env 2) fails inside generate()
+        e.s2_output.output_action = e.s2_output.output_latent = e.s2_output.output_pixel = None
+    model.answers, model.fail_next = ["→", "→", "→"], 1
     out = ag.step(obs)
-    assert [o["action"] for o in out] == [[3], [3], [0]]
+    assert [o["action"] for o in out] == [[3], [3], [3]] and ag.s2_failures == 0 and len(model.batches) == 3
+    # a persistent failure: STOP for every env of the call, counted
+    for e in ag.envs:
+        e.s2_output.output_action = e.s2_output.output_latent = e.s2_output.output_pixel = None
+    model.answers, model.fail_b = ["→", "→", "→"], 3
+    out = ag.step(obs)
+    assert [o["action"] for o in out] == [[0], [0], [0]] and ag.s2_failures == 3
 
 
 def test_bench_accounting_is_consistent():
@@ -263,3 +276,18 @@ def test_bench_accounting_is_consistent():
     for wl in ("n1_dual", "navdp_s1"):
         t = bench.pmc_traffic(wl)
         assert t and t["bytes_per_launch"] > 0 and (bench.ROOT / t["source"].split(" ")[0]).exists()
+
+
+def test_pin_host_threads_partitions_the_cores():
+    import subprocess
+    import sys
+
+    code = ("import os, torch; from internnav_amd.dist import pin_host_threads; "
+            "n = pin_host_threads(int(os.environ['LR']), 2); print(n, sorted(os.sched_getaffinity(0)))")
+    outs = []
+    for lr in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LR=str(lr)), cwd=str(Path(__file__).resolve().parent.parent))
+        assert r.returncode == 0, r.stderr
+        outs.append(eval(r.stdout.strip().split(" ", 1)[1]))
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert not set(outs[0]) & set(outs[1]) and outs[0] and outs[1]

@@ -285,3 +285,31 @@ def test_config1_cma_style_policy_through_the_registry(ref):
     a2 = [agent.act(obs, env=None, info={}) for _ in range(3)]
     assert a1 == a2 and all(a in (0, 1, 2, 3) for a in a1)             # deterministic, recurrent state threaded and reset
     internnav_amd._table().pop("CMA_Policy_stub")
+
+
+# ---------------------------------------------------------------------------------------------- f2: the real-world async driver, GPU-less
+def test_async_agent_driver_follows_the_reference_cadence():
+    """internvla_n1_agent_realworld.py:125-164 on a scripted model: S2 on the first frame / after PLAN_STEP_GAP frames / on a look-down
+    frame, discrete answers returned once, a pixel goal followed by one continuous System-1 trajectory per frame."""
+    from internnav_amd.async_agent import InternVLAN1AsyncAgent
+
+    model = _ScriptedModel(["↓", "215 206", "↑↑→"])
+    ag = InternVLAN1AsyncAgent(SimpleNamespace(device="cpu", model_path="unused", resize_w=64, resize_h=64, num_history=4, plan_step_gap=3),
+                               model=model, processor=_Proc())
+    rgb, depth = np.zeros((48, 64, 3), np.uint8), np.zeros((48, 64), np.float32)
+    out = ag.step(rgb, depth, None, "walk to the door", None)
+    assert out.output_action == [5] and out.output_trajectory is None          # look-down request, returned once
+    out = ag.step(rgb, depth, None, "walk to the door", None, look_down=True)   # the caller looks down and says so
+    assert out.output_pixel == [206, 215] and out.output_trajectory is not None and out.output_action is None
+    assert out.output_trajectory.shape == (33, 2) and abs(out.output_trajectory[-1, 0] - 3.2) < 1e-5   # 32 x 0.1 m straight ahead
+    n_gen = sum(1 for c in model.calls if c[0] == "generate")
+    for _ in range(4):                                                          # episode_idx - last_s2_idx <= PLAN_STEP_GAP: System-1 only, history grows
+        out = ag.step(rgb, depth, None, "walk to the door", None)
+        assert out.output_trajectory is not None and out.output_pixel is None
+    assert sum(1 for c in model.calls if c[0] == "generate") == n_gen and len(ag.rgb_list) == 5
+    out = ag.step(rgb, depth, None, "walk to the door", None)                   # older than PLAN_STEP_GAP -> System-2 again
+    assert out.output_action == [1, 1, 3] and sum(1 for c in model.calls if c[0] == "generate") == n_gen + 1
+    v, w = ag.trajectory_tovw(np.array([[0.0, 0.0, 0.0], [3.0, 4.0, 0.9]]))
+    assert v == 0.5 and w == 0.5
+    ag.reset()
+    assert ag.episode_idx == 0 and ag.output_latent is None

@@ -195,3 +195,55 @@ def test_ragged_answers_latents_after_early_eos(setup):
         d = (lat[b] - ref[0]).abs()
         print(f"seq {b}: latents mean|err| {d.mean():.3e} max|err| {d.max():.3e}")
         assert d.mean() < 1e-2 * ref.pow(2).mean().sqrt()
+
+
+def test_ragged_prompt_batch_vs_per_env_oracle(built_lib):
+    """f2: prompts of DIFFERENT lengths (a 1-image prompt with a short instruction, a 2-image prompt with a long one) run as one
+    right-padded batch (attention_mask) - prefill, greedy tokens and the latent queries of every sequence must equal the per-env
+    oracle (the reference's batch-1 semantics). Tokens are compared wherever the oracle's top-2 margin exceeds the logit tolerance."""
+    from internnav_amd import synthetic
+    from internnav_amd.policy import InternVLAN1ForCausalLM
+    from oracle import qwen_vl as o_q
+
+    cfg = W.QWEN_TEST_CFG
+    sd = synthetic.materialize(synthetic.n1_full_spec(cfg), seed=6)
+    qsd = {k: v for k, v in sd.items() if not k.startswith("model.traj_dit") and not k.startswith("model.rgb_")}
+    a = synthetic.qwen_inputs(1, 1, seed=31, cfg=cfg, n_text=10, n_tail=5)
+    b = synthetic.qwen_inputs(1, 2, seed=32, cfg=cfg, n_text=40, n_tail=9)
+    La, Lb = a["input_ids"].shape[1], b["input_ids"].shape[1]
+    assert La < Lb
+    ids = torch.zeros(2, Lb, dtype=torch.long)
+    mask = torch.zeros(2, Lb, dtype=torch.long)
+    ids[0, :La], mask[0, :La] = a["input_ids"][0], 1
+    ids[1], mask[1] = b["input_ids"][0], 1
+    pv = torch.cat([a["pixel_values"], b["pixel_values"]])
+    grid = torch.cat([a["grid_thw"], b["grid_thw"]])
+    m = InternVLAN1ForCausalLM(sd, cfg, "nextdit_async", device=DEV, max_envs=2, max_seq_len=768, max_patches=pv.shape[0])
+    n_new = 3
+    seqs = m.generate(input_ids=ids, pixel_values=pv, image_grid_thw=grid, attention_mask=mask, max_new_tokens=n_new, do_sample=False,
+                      return_dict_in_generate=True).sequences.cpu()
+    lat = m.generate_latents(seqs.to(DEV), pv, grid).float().cpu()
+    for r, (inp, L) in enumerate(((a, La), (b, Lb))):
+        assert torch.equal(seqs[r, :L], inp["input_ids"][0])
+        with torch.no_grad():
+            ref = o_q.generate(qsd, cfg, inp["input_ids"], inp["pixel_values"], inp["grid_thw"], n_new)
+            cur, same = inp["input_ids"], True
+            for j in range(n_new):                           # token by token, teacher-forced on the oracle's own continuation
+                logits, _ = o_q.forward_logits(qsd, cfg, cur, inp["pixel_values"], inp["grid_thw"])
+                top2 = logits[0, -1].topk(2).values
+                if same and int(seqs[r, L + j]) != int(ref[0, L + j]):
+                    assert float(top2[0] - top2[1]) < 0.05, f"seq {r} token {j} differs although the oracle margin is {float(top2[0] - top2[1]):.3f}"
+                    same = False
+                cur = ref[:, : L + j + 1]
+            if same:
+                rl = o_q.generate_latents(qsd, cfg, ref, inp["pixel_values"], inp["grid_thw"])
+                d = (lat[r] - rl[0]).abs()
+                print(f"ragged seq {r} (len {L}): tokens equal, latents mean|err| {d.mean():.3e} max|err| {d.max():.3e}")
+                assert d.mean() < 1e-2 * rl.pow(2).mean().sqrt()
+    # the padded batch and the two single-sequence calls agree (different GEMM tile shapes: tolerance, not bit equality)
+    for r, (inp, L) in enumerate(((a, La), (b, Lb))):
+        s1 = m.generate(input_ids=inp["input_ids"], pixel_values=inp["pixel_values"], image_grid_thw=inp["grid_thw"], max_new_tokens=n_new,
+                        do_sample=False, return_dict_in_generate=True).sequences
+        l1 = m.generate_latents(s1, inp["pixel_values"], inp["grid_thw"]).float().cpu()
+        if torch.equal(s1.cpu()[0], seqs[r, : L + n_new]):
+            assert (l1[0] - lat[r]).abs().mean() < 1e-2 * l1.pow(2).mean().sqrt()
