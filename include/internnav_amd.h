@@ -29,6 +29,7 @@ extern "C" {
 #define INA_ACT_GELU_TANH_C 2
 #define INA_ACT_RELU_C 3
 #define INA_ACT_SILU_C 4
+#define INA_ACT_MISH_C 5
 /* dtype codes */
 #define INA_BF16 0
 #define INA_F32 1
@@ -37,7 +38,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn, 20 gn_mish, 21 pad_rows, 22 ddim_step):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -398,6 +399,42 @@ typedef struct ina_dit_attn_args {
     int32_t _pad;
 } ina_dit_attn_args;
 int ina_dit_attention(const ina_dit_attn_args* args, void* stream);
+
+/* ---- diffusion-policy ConditionalUnet1D head (vendored: internnav/model/encoder/diffusion_policy/model/diffusion/conditional_unet1d.py:14-241,
+ *      conv1d_components.py:7-40). Activations are channels-last, sequence-padded: row (b, t) of a level = b * (T + 2 pad) + pad + t.
+ *      The Conv1d / ConvTranspose1d themselves run on ina_gemm_bf16 over overlapping row windows (implicit GEMM); these three entry
+ *      points are what remains: gn_mish = GroupNorm -> Mish [-> FiLM] [-> + residual] of a Conv1dBlock / ConditionalResidualBlock1D,
+ *      pad_rows = zero the pad rows after a strided convolution (+ optional bias on the valid rows), ddim_step = DDIMScheduler.step
+ *      (diffusers, eta 0, epsilon prediction, clip_sample) on the fp32 sample + refresh of the bf16 network input. */
+typedef struct ina_gn_mish_args {
+    const void* X;          /* bf16 conv output, row (b, t) at b * in_seq_stride + t, row stride ldx */
+    void* Y;                /* bf16 padded output [seqs, T + 2 pad, C], row stride ldy (pad rows are zeroed) */
+    const void* R;          /* bf16 residual in the padded indexing of Y, row stride ldr, or NULL */
+    const float* gamma; const float* beta;      /* f32 [C] GroupNorm affine */
+    const float* film_env;  /* f32 [envs, film_ld]: this block's [scale C | bias C] at column film_off, or NULL */
+    const float* film_step; /* f32 [film_ld]: the timestep part, added to film_env */
+    int32_t seqs, T, C, groups, pad, in_seq_stride, ldx, ldy, ldr, seq_per_env, film_ld, film_off;
+    float eps;
+    int32_t _pad;
+} ina_gn_mish_args;
+int ina_gn_mish(const ina_gn_mish_args* args, void* stream);
+
+typedef struct ina_pad_rows_args {
+    void* X;                /* bf16 [seqs, T + 2 pad, C] */
+    const float* bias;      /* f32 [C] added to the valid rows, or NULL */
+    int32_t seqs, T, pad, C, ldx, _pad;
+} ina_pad_rows_args;
+int ina_pad_rows(const ina_pad_rows_args* args, void* stream);
+
+typedef struct ina_ddim_step_args {
+    const float* eps;       /* f32 predicted noise in the padded row indexing, row stride lde */
+    float* sample;          /* f32 [seqs * T, D], updated in place */
+    void* Xin;              /* bf16 padded network input [seqs, T + 2 pad, ldx], channels [0, D) refreshed */
+    int32_t seqs, T, D, pad, lde, ldx;
+    float inv_sqrt_a, sqrt_b, sqrt_ap, sqrt_bp, clip;   /* 1/sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev), clip range (0 = off) */
+    int32_t _pad;
+} ina_ddim_step_args;
+int ina_ddim_step(const ina_ddim_step_args* args, void* stream);
 
 #ifdef __cplusplus
 }

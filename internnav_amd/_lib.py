@@ -163,6 +163,21 @@ class DitFfnArgs(C.Structure):
     ]
 
 
+class GnMishArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("Y", c_void_p), ("R", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("film_env", c_void_p),
+                ("film_step", c_void_p)] + [(n, c_int32) for n in ("seqs", "T", "C", "groups", "pad", "in_seq_stride", "ldx", "ldy", "ldr",
+                                                                    "seq_per_env", "film_ld", "film_off")] + [("eps", c_float), ("_pad", c_int32)]
+
+
+class PadRowsArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("bias", c_void_p)] + [(n, c_int32) for n in ("seqs", "T", "pad", "C", "ldx", "_pad")]
+
+
+class DdimStepArgs(C.Structure):
+    _fields_ = [("eps", c_void_p), ("sample", c_void_p), ("Xin", c_void_p)] + [(n, c_int32) for n in ("seqs", "T", "D", "pad", "lde", "ldx")] + \
+               [(n, c_float) for n in ("inv_sqrt_a", "sqrt_b", "sqrt_ap", "sqrt_bp", "clip")] + [("_pad", c_int32)]
+
+
 class ResizeU8Args(C.Structure):
     _fields_ = [("in_", c_void_p), ("out", c_void_p), ("bounds", c_void_p), ("coefs", c_void_p),
                 ("outer", c_int32), ("n_in", c_int32), ("n_out", c_int32), ("inner", c_int32), ("ksize", c_int32), ("_pad", c_int32)]
@@ -215,6 +230,9 @@ SYMBOLS = {
     "ina_u8_lut": (C.c_int, [C.POINTER(U8LutArgs), c_void_p]),
     "ina_resize_f32": (C.c_int, [C.POINTER(ResizeF32Args), c_void_p]),
     "ina_dit_ffn": (C.c_int, [C.POINTER(DitFfnArgs), c_void_p]),
+    "ina_gn_mish": (C.c_int, [C.POINTER(GnMishArgs), c_void_p]),
+    "ina_pad_rows": (C.c_int, [C.POINTER(PadRowsArgs), c_void_p]),
+    "ina_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_workspace_retired": (C.c_int, []),

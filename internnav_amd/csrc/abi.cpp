@@ -192,6 +192,9 @@ int ina_struct_size(int k) {
         case 17: return (int)sizeof(ina_u8_lut_args);
         case 18: return (int)sizeof(ina_resize_f32_args);
         case 19: return (int)sizeof(ina_dit_ffn_args);
+        case 20: return (int)sizeof(ina_gn_mish_args);
+        case 21: return (int)sizeof(ina_pad_rows_args);
+        case 22: return (int)sizeof(ina_ddim_step_args);
         default: return -1;
     }
 }
@@ -218,6 +221,9 @@ INA_ENTRY(ina_u8_lut, ina_u8_lut_args, ina_launch_u8_lut)
 INA_ENTRY(ina_resize_f32, ina_resize_f32_args, ina_launch_resize_f32)
 INA_ENTRY(ina_argmax_rows, ina_argmax_args, ina_launch_argmax)
 INA_ENTRY(ina_dit_ffn, ina_dit_ffn_args, ina_launch_dit_ffn)
+INA_ENTRY(ina_gn_mish, ina_gn_mish_args, ina_launch_gn_mish)
+INA_ENTRY(ina_pad_rows, ina_pad_rows_args, ina_launch_pad_rows)
+INA_ENTRY(ina_ddim_step, ina_ddim_step_args, ina_launch_ddim_step)
 #undef INA_ENTRY
 
 }  // extern "C"

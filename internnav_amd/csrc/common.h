@@ -20,6 +20,7 @@ enum : int {
     INA_ACT_GELU_TANH = 2,  // nn.GELU(approximate="tanh") (cond_projector, caption_projection)
     INA_ACT_RELU = 3,       // nn.TransformerDecoderLayer default FFN, vlm_embed_mlp
     INA_ACT_SILU = 4,       // timestep embedder, adaLN SiLU
+    INA_ACT_MISH = 5,       // diffusion-policy ConditionalUnet1D (cond_encoder, Conv1dBlock)
 };
 
 enum : int { INA_DT_BF16 = 0, INA_DT_F32 = 1 };
@@ -38,6 +39,7 @@ __device__ __forceinline__ float ina_act(float v, int act) {
         case INA_ACT_GELU_TANH: return ina_gelu_tanh(v);
         case INA_ACT_RELU: return v > 0.f ? v : 0.f;
         case INA_ACT_SILU: return ina_silu(v);
+        case INA_ACT_MISH: return v * tanhf(v > 20.f ? v : log1pf(__expf(v)));
         default: return v;
     }
 }

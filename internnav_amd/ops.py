@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import AttnArgs, GemmArgs, NormArgs
 
-ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "relu": 3, "silu": 4}
+ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "relu": 3, "silu": 4, "mish": 5}
 _DT = {torch.bfloat16: 0, torch.float32: 1}
 
 
@@ -521,3 +521,43 @@ def resize_f32(x: torch.Tensor, out: torch.Tensor, bounds: torch.Tensor, coefs: 
     a.outer, a.n_in, a.n_out, a.inner, a.ksize = outer, x.shape[axis], n_out, inner, coefs.shape[1]
     _lib.check(_lib.lib().ina_resize_f32(C.byref(a), _stream()), "resize_f32")
     return out
+
+
+def gn_mish(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, seqs: int, T: int, pad: int, in_seq_stride: int,
+            groups: int = 8, residual: Optional[torch.Tensor] = None, film_env: Optional[torch.Tensor] = None, film_step: Optional[torch.Tensor] = None,
+            film_off: int = 0, seq_per_env: int = 1, eps: float = 1e-5) -> torch.Tensor:
+    """GroupNorm(groups) -> Mish [-> scale * y + bias (FiLM)] [-> + residual] of one ConditionalUnet1D Conv1dBlock.
+    x bf16 [rows, C]: conv output, row (b, t) at b * in_seq_stride + t; out / residual bf16 padded [seqs * (T + 2 pad), C]."""
+    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and x.stride(1) == 1 and out.stride(1) == 1
+    C_ = out.shape[1]
+    a = _lib.GnMishArgs()
+    a.X, a.Y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr()
+    a.seqs, a.T, a.C, a.groups, a.pad, a.in_seq_stride, a.ldx, a.ldy = seqs, T, C_, groups, pad, in_seq_stride, x.stride(0), out.stride(0)
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.stride(1) == 1
+        a.R, a.ldr = residual.data_ptr(), residual.stride(0)
+    if film_env is not None:
+        assert film_env.dtype == torch.float32 and film_step.dtype == torch.float32 and film_env.stride(1) == 1 and film_step.is_contiguous()
+        a.film_env, a.film_step, a.film_ld, a.film_off, a.seq_per_env = film_env.data_ptr(), film_step.data_ptr(), film_env.stride(0), film_off, seq_per_env
+    a.eps = eps
+    _lib.check(_lib.lib().ina_gn_mish(C.byref(a), _stream()), "gn_mish")
+    return out
+
+
+def pad_rows(x: torch.Tensor, seqs: int, T: int, pad: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """zero the pad rows of a padded bf16 buffer [seqs * (T + 2 pad), C] (+ optional per-channel bias on the valid rows)."""
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    a = _lib.PadRowsArgs()
+    a.X, a.bias, a.seqs, a.T, a.pad, a.C, a.ldx = x.data_ptr(), _ptr(_f32(bias)), seqs, T, pad, x.shape[1], x.stride(0)
+    _lib.check(_lib.lib().ina_pad_rows(C.byref(a), _stream()), "pad_rows")
+    return x
+
+
+def ddim_step(eps: torch.Tensor, sample: torch.Tensor, xin: torch.Tensor, seqs: int, T: int, D: int, pad: int, coefs, clip: float = 1.0):
+    """DDIMScheduler.step (eta 0) on the fp32 sample [seqs * T, D]; eps f32 in padded row indexing; xin bf16 padded network input."""
+    assert eps.dtype == torch.float32 and sample.dtype == torch.float32 and sample.is_contiguous() and xin.dtype == torch.bfloat16
+    a = _lib.DdimStepArgs()
+    a.eps, a.sample, a.Xin, a.seqs, a.T, a.D, a.pad, a.lde, a.ldx = eps.data_ptr(), sample.data_ptr(), xin.data_ptr(), seqs, T, D, pad, eps.stride(0), xin.stride(0)
+    a.inv_sqrt_a, a.sqrt_b, a.sqrt_ap, a.sqrt_bp, a.clip = [float(c) for c in coefs] + [float(clip)]
+    _lib.check(_lib.lib().ina_ddim_step(C.byref(a), _stream()), "ddim_step")
+    return sample

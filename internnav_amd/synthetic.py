@@ -327,6 +327,60 @@ def n1_nextdit_spec(cfg=N1_NEXTDIT_CFG) -> Spec:
     return s
 
 
+UNET1D_CFG = dict(input_dim=3, global_cond_dim=384, dsed=256, down_dims=(256, 512, 1024), kernel_size=5, n_groups=8, predict_size=32,
+                  sample_num=32, num_train_timesteps=100, num_inference_steps=10)
+"""diffusion-policy ConditionalUnet1D as an alternative System-1 head (SURVEY.md 8f-3): network hyper-parameters and DDIM schedule of the
+vendored config (diffusion_policy/config/train_diffusion_unet_ddim_lowdim_workspace.yaml:32-49: down_dims [256,512,1024], kernel 5,
+8 groups, cond_predict_scale, DDIM over 100 train steps), 3-d waypoints x 32 steps x 32 samples like the N1 heads, 10 DDIM steps
+(BASELINE.json north_star), conditioned on one 384-d vector per env."""
+
+
+def unet1d_spec(cfg=UNET1D_CFG) -> Spec:
+    """ConditionalUnet1D parameters (conditional_unet1d.py:69-187), cond_predict_scale=True, no local conditioning."""
+    s: Spec = {}
+    k, dsed = cfg["kernel_size"], cfg["dsed"]
+    cond = dsed + cfg["global_cond_dim"]
+    dims = [cfg["input_dim"]] + list(cfg["down_dims"])
+
+    def conv(p, co, ci, kk):
+        s[p + ".weight"] = ((co, ci, kk), "w")
+        s[p + ".bias"] = ((co,), "b")
+
+    def res(p, ci, co):
+        for j, c_in in ((0, ci), (1, co)):
+            conv(f"{p}.blocks.{j}.block.0", co, c_in, k)
+            _ln(s, f"{p}.blocks.{j}.block.1", co)
+        _lin(s, p + ".cond_encoder.1", 2 * co, cond, kind="w_small")
+        if ci != co:
+            conv(p + ".residual_conv", co, ci, 1)
+
+    _lin(s, "diffusion_step_encoder.1", 4 * dsed, dsed)
+    _lin(s, "diffusion_step_encoder.3", dsed, 4 * dsed)
+    n = len(dims) - 1
+    for i in range(n):
+        res(f"down_modules.{i}.0", dims[i], dims[i + 1])
+        res(f"down_modules.{i}.1", dims[i + 1], dims[i + 1])
+        if i < n - 1:
+            conv(f"down_modules.{i}.2.conv", dims[i + 1], dims[i + 1], 3)
+    for i in range(2):
+        res(f"mid_modules.{i}", dims[-1], dims[-1])
+    for i, (di, do) in enumerate(reversed(list(zip(dims[1:-1], dims[2:])))):
+        res(f"up_modules.{i}.0", 2 * do, di)
+        res(f"up_modules.{i}.1", di, di)
+        s[f"up_modules.{i}.2.conv.weight"] = ((di, di, 4), "w")      # ConvTranspose1d weight [in, out, k]
+        s[f"up_modules.{i}.2.conv.bias"] = ((di,), "b")
+    conv("final_conv.0.block.0", dims[1], dims[1], k)
+    _ln(s, "final_conv.0.block.1", dims[1])
+    conv("final_conv.1", cfg["input_dim"], dims[1], 1)
+    return s
+
+
+def unet1d_inputs(B: int, seed: int = 0, cfg=UNET1D_CFG):
+    g = torch.Generator().manual_seed(5000 + seed)
+    return dict(global_cond=torch.randn(B, cfg["global_cond_dim"], generator=g).to(torch.bfloat16).float(),
+                x_init=torch.randn(B, cfg["sample_num"], cfg["predict_size"], cfg["input_dim"], generator=g))
+
+
 def n1_full_spec(qwen_cfg=None, system1: str = "nextdit_async") -> Spec:
     """every parameter of an InternVLA-N1 checkpoint: Qwen2.5-VL (visual.*, model.*, lm_head) + the System-1 modules under `model.`."""
     s = qwen_spec(qwen_cfg or QWEN_N1_CFG)

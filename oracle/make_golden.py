@@ -278,6 +278,37 @@ def gold_qwen(B=2, n_img=2):
                 last_logits=logits[:, -1].clone(), generated=gen, latents=latents, oracle_max_abs_diff=d)
 
 
+def gold_unet1d(B=2):
+    """vendored diffusion-policy ConditionalUnet1D (conditional_unet1d.py:69-241) executed as-is: one noise prediction and a 10-step DDIM
+    sampling loop (scheduler = the restated diffusers DDIMScheduler, the package being absent) on seeded weights / inputs."""
+    import importlib
+
+    from . import unet1d as o_u
+    from .schedulers import DDIMScheduler
+
+    R.setup()
+    mod = importlib.import_module("diffusion_policy.model.diffusion.conditional_unet1d")
+    cfg = W.UNET1D_CFG
+    net = mod.ConditionalUnet1D(input_dim=cfg["input_dim"], global_cond_dim=cfg["global_cond_dim"], diffusion_step_embed_dim=cfg["dsed"],
+                                down_dims=list(cfg["down_dims"]), kernel_size=cfg["kernel_size"], n_groups=cfg["n_groups"], cond_predict_scale=True)
+    sd = W.materialize(W.unet1d_spec(cfg), seed=4)
+    net = _load_strict(net, sd)
+    inp = W.unet1d_inputs(B, seed=4, cfg=cfg)
+    S, T, D = cfg["sample_num"], cfg["predict_size"], cfg["input_dim"]
+    g = inp["global_cond"].repeat_interleave(S, dim=0)
+    x = inp["x_init"].reshape(B * S, T, D).clone()
+    sch = DDIMScheduler(num_train_timesteps=cfg["num_train_timesteps"])
+    sch.set_timesteps(cfg["num_inference_steps"])
+    with torch.no_grad():
+        eps0 = net(x, int(sch.timesteps[0]), global_cond=g)
+        for t in sch.timesteps.tolist():
+            x = sch.step(net(x, t, global_cond=g), t, x).prev_sample
+        mine = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"])
+        mine_eps = o_u.unet_forward(sd, inp["x_init"].reshape(B * S, T, D), int(sch.timesteps[0]), g)
+    d = max((x.reshape(B, S, T, D) - mine).abs().max().item(), (eps0 - mine_eps).abs().max().item())
+    return dict(seed=4, B=B, eps0=eps0.reshape(B, S, T, D).clone(), samples=x.reshape(B, S, T, D).clone(), timesteps=sch.timesteps.clone(), oracle_max_abs_diff=d)
+
+
 def gold_vln_utils():
     """The reference's own host post-processing (internnav/model/utils/vln_utils.py) on seeded trajectories: the integer action
     lists are the known answers for internnav_amd.policy.traj_to_actions / chunk_token / split_and_clean (bit-exact)."""
@@ -390,7 +421,7 @@ def gold_preprocess():
                 oracle_max_abs_diff=float(max(diffs)))
 
 
-UNITS = {"preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+UNITS = {"unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

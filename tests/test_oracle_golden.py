@@ -121,3 +121,39 @@ def test_qwen_s2_matches_transformers_and_reference_rope_index():
         assert (logits[:, -1] - gold["last_logits"]).abs().max().item() < 1e-3
         lat = o_q.generate_latents(sd, cfg, gold["generated"], inp["pixel_values"], inp["grid_thw"])
         assert (lat - gold["latents"]).abs().max().item() < 1e-3
+
+
+def test_unet1d_matches_vendored_reference():
+    """diffusion-policy ConditionalUnet1D (vendored, conditional_unet1d.py:69-241) executed by oracle/make_golden.py: one noise prediction and
+    the 10-step DDIM loop == the oracle restatement on the same seeded weights / inputs."""
+    from oracle import unet1d as o_u
+
+    gold = _load("unet1d")
+    cfg = W.UNET1D_CFG
+    sd = W.materialize(W.unet1d_spec(cfg), seed=gold["seed"])
+    inp = W.unet1d_inputs(gold["B"], seed=gold["seed"], cfg=cfg)
+    B, S, T, D = inp["x_init"].shape
+    with torch.no_grad():
+        eps = o_u.unet_forward(sd, inp["x_init"].reshape(B * S, T, D), int(gold["timesteps"][0]), inp["global_cond"].repeat_interleave(S, dim=0))
+        out = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"])
+    assert (eps.reshape(B, S, T, D) - gold["eps0"]).abs().max().item() < 1e-4
+    assert (out - gold["samples"]).abs().max().item() < 1e-4
+    assert float(out.abs().max()) <= 1.0 + 1e-6       # clip_sample
+
+
+def test_ddim_scheduler_known_properties():
+    """diffusers is absent (parity unpinned): closed-form properties of the restated DDIM step (eta = 0)."""
+    from oracle.schedulers import DDIMScheduler
+
+    sch = DDIMScheduler(num_train_timesteps=100)
+    sch.set_timesteps(10)
+    assert sch.timesteps.tolist() == [90, 80, 70, 60, 50, 40, 30, 20, 10, 0]
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.rand(4, 8, 3, generator=g) * 1.6 - 0.8
+    eps = torch.randn(4, 8, 3, generator=g)
+    for t in (90, 40):
+        xt = sch.add_noise(x0, eps, torch.tensor(t))
+        prev = sch.step(eps, t, xt).prev_sample                    # the true noise -> exactly the forward process at t - 10
+        assert torch.allclose(prev, sch.add_noise(x0, eps, torch.tensor(t - 10)), atol=1e-5)
+    xt = sch.add_noise(x0, eps, torch.tensor(0))
+    assert torch.allclose(sch.step(eps, 0, xt).prev_sample, x0, atol=1e-5)     # set_alpha_to_one: the last step returns x0
