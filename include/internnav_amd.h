@@ -371,7 +371,7 @@ typedef struct ina_dit_ffn_args {
     int32_t lda, ldw13, ldw2, ldx, ldh;
     int32_t mod_div, mod_ld;
     float eps;
-    int32_t _pad;
+    int32_t rotate;         /* 1: workgroup b starts at F chunk b % (F/128) (spreads the concurrent workgroups over the weight lines) */
 } ina_dit_ffn_args;
 int ina_dit_ffn(const ina_dit_ffn_args* args, void* stream);
 
@@ -407,7 +407,7 @@ int ina_dit_attention(const ina_dit_attn_args* args, void* stream);
  *      pad_rows = zero the pad rows after a strided convolution (+ optional bias on the valid rows), ddim_step = DDIMScheduler.step
  *      (diffusers, eta 0, epsilon prediction, clip_sample) on the fp32 sample + refresh of the bf16 network input. */
 typedef struct ina_gn_mish_args {
-    const void* X;          /* bf16 conv output, row (b, t) at b * in_seq_stride + t, row stride ldx */
+    const void* X;          /* bf16 (f32 when x_f32) conv output, row (b, t) at b * in_seq_stride + t, row stride ldx */
     void* Y;                /* bf16 padded output [seqs, T + 2 pad, C], row stride ldy (pad rows are zeroed) */
     const void* R;          /* bf16 residual in the padded indexing of Y, row stride ldr, or NULL */
     const float* gamma; const float* beta;      /* f32 [C] GroupNorm affine */
@@ -415,7 +415,7 @@ typedef struct ina_gn_mish_args {
     const float* film_step; /* f32 [film_ld]: the timestep part, added to film_env */
     int32_t seqs, T, C, groups, pad, in_seq_stride, ldx, ldy, ldr, seq_per_env, film_ld, film_off;
     float eps;
-    int32_t _pad;
+    int32_t x_f32;
 } ina_gn_mish_args;
 int ina_gn_mish(const ina_gn_mish_args* args, void* stream);
 

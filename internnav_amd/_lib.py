@@ -159,14 +159,14 @@ class DitFfnArgs(C.Structure):
         ("gamma2", c_void_p), ("mod_scale2", c_void_p),
         ("M", c_int32), ("D", c_int32), ("F", c_int32),
         ("lda", c_int32), ("ldw13", c_int32), ("ldw2", c_int32), ("ldx", c_int32), ("ldh", c_int32),
-        ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("_pad", c_int32),
+        ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("rotate", c_int32),
     ]
 
 
 class GnMishArgs(C.Structure):
     _fields_ = [("X", c_void_p), ("Y", c_void_p), ("R", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("film_env", c_void_p),
                 ("film_step", c_void_p)] + [(n, c_int32) for n in ("seqs", "T", "C", "groups", "pad", "in_seq_stride", "ldx", "ldy", "ldr",
-                                                                    "seq_per_env", "film_ld", "film_off")] + [("eps", c_float), ("_pad", c_int32)]
+                                                                    "seq_per_env", "film_ld", "film_off")] + [("eps", c_float), ("x_f32", c_int32)]
 
 
 class PadRowsArgs(C.Structure):

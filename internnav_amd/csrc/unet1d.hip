@@ -29,12 +29,25 @@ __global__ __launch_bounds__(256) void gn_mish_kernel(GnMishArgs p) {
     const int grp = chunk / (cpr / G);
     if (tid < 32) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
     __syncthreads();
-    const bf16* in = reinterpret_cast<const bf16*>(p.X) + (size_t)b * p.in_seq_stride * p.ldx + chunk * 8;
+    const size_t in0 = (size_t)b * p.in_seq_stride * p.ldx + chunk * 8;
+    auto load8 = [&](int t, float* f) {      // conv output row t of this sequence: fp32 (x_f32) or bf16
+        if (p.x_f32) {
+            const float* q = reinterpret_cast<const float*>(p.X) + in0 + (size_t)t * p.ldx;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(q), c = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = c[i]; }
+        } else {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.X) + in0 + (size_t)t * p.ldx);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+        }
+    };
     float sum = 0.f, sq = 0.f;
     for (int t = r0; t < T; t += rstep) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + (size_t)t * p.ldx);
+        float f[8];
+        load8(t, f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; sum += f; sq += f * f; }
+        for (int i = 0; i < 8; ++i) { sum += f[i]; sq += f[i] * f[i]; }
     }
     atomicAdd(&s_sum[grp], sum);
     atomicAdd(&s_sq[grp], sq);
@@ -70,12 +83,13 @@ __global__ __launch_bounds__(256) void gn_mish_kernel(GnMishArgs p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (bf16)0.f;
         } else {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + (size_t)tv * p.ldx);
+            float v[8];
+            load8(tv, v);
             bf16x8 rv;
             if (res) rv = *reinterpret_cast<const bf16x8*>(res + (size_t)t * p.ldr);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float y = mish_f((float)v[i] * ga[i] + be[i]);
+                float y = mish_f(v[i] * ga[i] + be[i]);
                 y = y * fs[i] + fb[i];
                 if (res) y += (float)rv[i];
                 o[i] = (bf16)y;
@@ -141,7 +155,7 @@ int ina_launch_gn_mish(const GnMishArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.C % 8 == 0 && (p.C / 8) % p.groups == 0 && 256 % (p.C / 8) == 0, "gn_mish: C=%d must give 16-byte chunks that tile 256 threads and %d groups", p.C, p.groups);
     INA_REQUIRE(p.ldx % 8 == 0 && p.ldy % 8 == 0 && (!p.R || p.ldr % 8 == 0), "gn_mish: row strides must keep 16-byte alignment");
     INA_REQUIRE(!p.film_env || (p.film_step && p.seq_per_env > 0), "gn_mish: FiLM needs film_step and seq_per_env");
-    InaProfScope prof(INA_PROF_NORM, 0.0, (double)p.seqs * p.T * p.C * (p.R ? 8.0 : 6.0), stream);
+    InaProfScope prof(INA_PROF_NORM, 0.0, (double)p.seqs * p.T * p.C * ((p.R ? 4.0 : 2.0) + (p.x_f32 ? 8.0 : 4.0)), stream);
     hipLaunchKernelGGL(gn_mish_kernel, dim3(p.seqs), dim3(256), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;

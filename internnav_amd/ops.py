@@ -433,7 +433,7 @@ def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: to
 
 def dit_ffn(h_in: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, gamma: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
             h: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None,
-            mod_div: int = 1, eps: float = 1e-5) -> torch.Tensor:
+            mod_div: int = 1, eps: float = 1e-5, rotate: int = 0) -> torch.Tensor:
     """SwiGLU feed-forward of a NextDiT block in one launch (the F = silu(h W1^T) * (h W3^T) intermediate never leaves the chip):
     x += tanh(gate[r // mod_div]) * rmsnorm((silu(h_in @ w1.T) * (h_in @ w3.T)) @ w2.T) * gamma;  h = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div]).
 
@@ -456,7 +456,7 @@ def dit_ffn(h_in: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, gamma: torc
         if mod_scale2 is not None:
             assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and a.mod_ld in (0, mod_scale2.stride(0))
             a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
-    a.mod_div, a.eps = mod_div, eps
+    a.mod_div, a.eps, a.rotate = mod_div, eps, int(rotate)
     _lib.check(_lib.lib().ina_dit_ffn(C.byref(a), _stream()), "dit_ffn")
     return x
 
@@ -527,10 +527,11 @@ def gn_mish(x: torch.Tensor, out: torch.Tensor, gamma: torch.Tensor, beta: torch
             groups: int = 8, residual: Optional[torch.Tensor] = None, film_env: Optional[torch.Tensor] = None, film_step: Optional[torch.Tensor] = None,
             film_off: int = 0, seq_per_env: int = 1, eps: float = 1e-5) -> torch.Tensor:
     """GroupNorm(groups) -> Mish [-> scale * y + bias (FiLM)] [-> + residual] of one ConditionalUnet1D Conv1dBlock.
-    x bf16 [rows, C]: conv output, row (b, t) at b * in_seq_stride + t; out / residual bf16 padded [seqs * (T + 2 pad), C]."""
-    assert x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and x.stride(1) == 1 and out.stride(1) == 1
+    x bf16|f32 [rows, C]: conv output, row (b, t) at b * in_seq_stride + t; out / residual bf16 padded [seqs * (T + 2 pad), C]."""
+    assert x.dtype in (torch.bfloat16, torch.float32) and out.dtype == torch.bfloat16 and x.stride(1) == 1 and out.stride(1) == 1
     C_ = out.shape[1]
     a = _lib.GnMishArgs()
+    a.x_f32 = 1 if x.dtype == torch.float32 else 0
     a.X, a.Y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), _f32(gamma).data_ptr(), _f32(beta).data_ptr()
     a.seqs, a.T, a.C, a.groups, a.pad, a.in_seq_stride, a.ldx, a.ldy = seqs, T, C_, groups, pad, in_seq_stride, x.stride(0), out.stride(0)
     if residual is not None:

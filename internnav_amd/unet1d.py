@@ -141,7 +141,9 @@ class UNet1DHead:
         self.P = [[buf(l, dims[l]) for _ in range(4)] for l in range(3)]
         self.U = {2: [buf(2, dims[1]) for _ in range(3)], 1: [buf(1, dims[0]) for _ in range(3)]}   # up-path blocks: 512 ch at T/4, 256 ch at T/2
         self.Dn = {1: buf(1, dims[0]), 2: buf(2, dims[1])}                                            # Downsample1d keeps the channel count
-        self._tmp = [torch.empty(R[l] * dims[l], dtype=bf, device=dev) for l in range(3)]           # conv outputs (row (b, t) at b * Tp + t)
+        # conv outputs (row (b, t) at b * Tp + t). bf16: fp32 outputs (supported by gn_mish) were measured at 78.8 vs 55.0 ms per 64-env
+        # call for mean |err| 1.50e-3 vs 1.53e-3 - the error budget is the bf16 activations between the blocks over 10 DDIM steps
+        self._tmp = [torch.empty(R[l] * dims[l], dtype=bf, device=dev) for l in range(3)]
         self._rtmp = [torch.empty(R[l] * dims[l], dtype=bf, device=dev) for l in range(3)]          # 1x1 residual-conv outputs (padded indexing)
         self._p32 = [torch.empty(R[l] * dims[l], dtype=f32, device=dev) for l in range(3)]          # first half of a concatenated-input GEMM
         self.eps = torch.zeros(R[0], 4, dtype=f32, device=dev)

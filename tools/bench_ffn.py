@@ -27,6 +27,10 @@ def fused():
     ops.dit_ffn(h, w13, w2, g1, x, gate=mod[:, :D], h=h2, gamma2=g1, mod_scale2=mod[:, D:], mod_div=div)
 
 
+def variant(flags):
+    return lambda: ops.dit_ffn(h, w13, w2, g1, x, gate=mod[:, :D], h=h2, gamma2=g1, mod_scale2=mod[:, D:], mod_div=div, rotate=flags)
+
+
 def unfused():
     ops.linear(h, w13, act="silu", glu=True, out=ff)
     ops.linear(ff, w2, out=pj)
@@ -47,6 +51,7 @@ def timeit(fn, n=30):
 
 
 fl = 2.0 * M * D * F * 3
-for name, fn in (("fused dit_ffn", fused), ("glu gemm + gemm + norm", unfused)):
+for name, fn in (("fused dit_ffn", fused), ("  dbg: rotated chunk order", variant(1)), ("  dbg: weights loaded once", variant(2)), ("  dbg: no x / h epilogue I/O", variant(4)),
+                 ("  dbg: neither", variant(6)), ("glu gemm + gemm + norm", unfused)):
     us = timeit(fn)
     print(f"{name:28s} M={M}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
