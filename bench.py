@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=64, help="environments per GPU")
-    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1"])
+    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1", "unet1d_s1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--overlap-at", choices=["start", "decode"], default="decode",
@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--priority", choices=["none", "decode", "s1"], default="none",
                     help="n1_dual experiment: high-priority stream for the System-2 decode graph or for the side-stream System-1")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
+    ap.add_argument("--vit-cache", action="store_true",
+                    help="n1_dual: per-frame ViT cache variant - the first history frame of every env (frame 0, present in every np.linspace history "
+                         "sample of the reference) comes from the cache, 3 of the 4 frames are encoded; algorithmic FLOPs are accounted accordingly")
     ap.add_argument("--no-raw-frames", action="store_true",
                     help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
     return ap.parse_args()
@@ -126,6 +129,62 @@ class NavDPS1:
                           "1 warm-up + median of 3 runs each for fp32 and bf16-autocast, value = the faster"}
 
 
+class UNet1DS1:
+    """diffusion-policy ConditionalUnet1D + 10 DDIM steps as a System-1 head, 64 envs x 32 samples per call."""
+
+    def __init__(self, a, dev, rank):
+        from internnav_amd import flops, synthetic
+        from internnav_amd.unet1d import UNet1DHead
+
+        self.cfg = cfg = synthetic.UNET1D_CFG
+        self.B = B = a.envs
+        self.name = f"unet1d_s1_b{B}"
+        self.desc = {"policy": "ConditionalUnet1D (diffusion-policy, down [256,512,1024], kernel 5, FiLM) + DDIM", "samples_per_env": cfg["sample_num"],
+                     "ddim_steps": cfg["num_inference_steps"], "condition": f"one {cfg['global_cond_dim']}-d vector per env"}
+        self.net = UNet1DHead(synthetic.materialize(synthetic.unet1d_spec(cfg), 0), cfg, dev, max_envs=B)
+        self.g = g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
+        self.inp = dict(global_cond=torch.randn(B, cfg["global_cond_dim"], device=dev, generator=g),
+                        x_init=torch.randn(B, cfg["sample_num"], cfg["predict_size"], cfg["input_dim"], device=dev, generator=g))
+        self.f_alg = flops.unet1d_flops_per_env(cfg)["total"]
+        self.graph = None
+        self.action_shape = (B, cfg["sample_num"], cfg["predict_size"], cfg["input_dim"])
+
+    def _call(self, global_cond, x_init):
+        return self.net.sample_traj(global_cond, x_init)
+
+    def capture(self):
+        from internnav_amd import runtime
+
+        self.graph = runtime.GraphedCall(self._call, self.inp)
+
+    def step(self, i):
+        self.inp["x_init"].normal_(generator=self.g)
+        out = self.graph() if self.graph else self._call(**self.inp)
+        self.last_out = out
+        return out
+
+    def instrumented(self):
+        self._call(**self.inp)
+
+    def step_output_for_check(self):
+        return self.last_out
+
+    def cpu_baseline(self):
+        from internnav_amd import synthetic
+        from oracle import unet1d as o_u  # cpu_baseline leg only
+
+        cores = min(64, os.cpu_count() or 1)
+        torch.set_num_threads(cores)
+        sd = synthetic.materialize(synthetic.unet1d_spec(self.cfg), 0)
+        inp = synthetic.unet1d_inputs(1, 0, self.cfg)
+        fn = lambda: o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], self.cfg["num_train_timesteps"], self.cfg["num_inference_steps"])  # noqa: E731
+        t32, t16 = _median_time(fn, 3), _median_time(fn, 3, autocast=True)
+        dt = min(t32, t16)
+        return {"value": round(1.0 / dt, 4), "unit": "policy steps/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
+                "seconds": {"fp32": round(t32, 2), "bf16_autocast": round(t16, 2)},
+                "sample": "1 env x 1 policy step (32 samples x 10 DDIM steps of the UNet), torch CPU; 1 warm-up + median of 3 runs each for fp32 and bf16-autocast"}
+
+
 class N1Dual:
     """InternVLA-N1 full dual system at the nominal cadence (the configuration the BASELINE metric is quoted on)."""
 
@@ -182,16 +241,29 @@ class N1Dual:
                                if self.raw else "pre-processed pixel_values / 224x224 frames resident in HBM"),
                      "s2": f"{self.N_IMG} frames x 784 patches + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
                      "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps", "s2_microbatches_per_10_steps": self.mb}
-        f2 = flops.s2_call_flops(self.S, [self.GRID] * self.N_IMG, self.N_DECODE, qcfg)
+        self.vit_cache = bool(getattr(a, "vit_cache", False)) and self.raw
+        n_fresh = self.N_IMG - 1 if self.vit_cache else self.N_IMG
+        f2 = flops.s2_call_flops(self.S, [self.GRID] * n_fresh, self.N_DECODE, qcfg)     # a cached frame costs no vision-tower FLOPs
         f1 = flops.nextdit_s1_flops_per_env(scfg)
         self.f_alg = f1["total"] + f2["total"] / self.CADENCE
         self.f_parts = {"s1_per_env": f1["total"], "s2_per_call": f2["total"]}
         # static S2 buffers per micro-batch size
         q = self.model.qwen
         self.s2 = {}
+        if self.vit_cache:
+            # frame-0 embeddings of every env, computed once (they would have been produced by the env's first System-2 call)
+            self.emb0 = torch.empty(B, per // 4, qcfg["t_hidden"], dtype=torch.bfloat16, device=dev)
+            for lo in range(0, B, mmax):
+                hi = min(B, lo + mmax)
+                pv0, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:hi, 0].contiguous())
+                emb, inv = q.vision(pv0, [self.GRID] * (hi - lo))
+                self.emb0[lo:hi].copy_(emb[torch.from_numpy(inv).to(dev).long()].view(hi - lo, per // 4, -1))
+            self.desc["vit_cache"] = "frame 0 of every env from the per-frame ViT cache (3 of 4 frames encoded per System-2 call)"
         for m in sorted(set(self.mb)):
-            P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True)
-            self.s2[m] = dict(P=P, pv=torch.empty(m * self.N_IMG * per, 1176, dtype=torch.bfloat16, device=dev),
+            cache0 = torch.empty(m, per // 4, qcfg["t_hidden"], dtype=torch.bfloat16, device=dev) if self.vit_cache else None
+            cached = [c for k in range(m) for c in ([cache0[k]] + [None] * (self.N_IMG - 1))] if self.vit_cache else None
+            P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True, cached_embeds=cached)
+            self.s2[m] = dict(P=P, cache0=cache0, pv=torch.empty(m * n_fresh * per, 1176, dtype=torch.bfloat16, device=dev),
                               toks=torch.zeros(m, self.N_DECODE, dtype=torch.int32, device=dev),
                               lat=torch.zeros(m, qcfg["n_query"], qcfg["t_hidden"], dtype=torch.bfloat16, device=dev), graph=None)
         self.s1_graph = None
@@ -230,7 +302,11 @@ class N1Dual:
 
     def _ingest_s2(self, lo, m, dst):
         """System-2 images of envs [lo, lo + m): raw frames -> pixel_values of the micro-batch (or the round-1 resident tensor)."""
-        if self.raw:
+        if self.vit_cache:
+            self.s2[m]["cache0"].copy_(self.emb0[lo:lo + m])
+            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, 1:].reshape(m * (self.N_IMG - 1), 480, 640, 3))
+            dst.copy_(pv)
+        elif self.raw:
             pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m].reshape(m * self.N_IMG, 480, 640, 3))
             dst.copy_(pv)
         else:
@@ -484,7 +560,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # own slice of the host cores per rank
-    wl = (N1Dual if a.workload == "n1_dual" else NavDPS1)(a, dev, rank)
+    wl = {"n1_dual": N1Dual, "navdp_s1": NavDPS1, "unet1d_s1": UNet1DS1}[a.workload](a, dev, rank)
     if not a.no_graph:
         wl.capture()
     gathered = torch.empty((world * wl.action_shape[0],) + tuple(wl.action_shape[1:]), device=dev,

@@ -110,3 +110,28 @@ def nextdit_s1_flops_per_env(cfg) -> dict:
     dit = cfg["num_inference_steps"] * (nl * per_layer + 2 * 2 * rows * 3 * D)
     total = vit + mem + qf + cond + dit
     return dict(vit=vit, memory_encoder=mem, qformer=qf, cond=cond, dit=dit, total=total)
+
+
+def unet1d_flops_per_env(cfg) -> dict:
+    """ConditionalUnet1D + DDIM head per env: num_inference_steps x one forward over sample_num sequences (2 M N K per convolution as an
+    implicit GEMM, K = taps x C_in; FiLM projections: condition half once per call)."""
+    T, S, k = cfg["predict_size"], cfg["sample_num"], cfg["kernel_size"]
+    d = list(cfg["down_dims"])
+    cond = cfg["dsed"] + cfg["global_cond_dim"]
+
+    def conv(rows, co, ci, taps):
+        return 2.0 * rows * co * ci * taps
+
+    def res(rows, ci, co):
+        return conv(rows, co, ci, k) + conv(rows, co, co, k) + (conv(rows, co, ci, 1) if ci != co else 0.0)
+
+    Ts = [T, T // 2, T // 4]
+    f = res(Ts[0], cfg["input_dim"], d[0]) + res(Ts[0], d[0], d[0]) + conv(Ts[1], d[0], d[0], 3)
+    f += res(Ts[1], d[0], d[1]) + res(Ts[1], d[1], d[1]) + conv(Ts[2], d[1], d[1], 3)
+    f += res(Ts[2], d[1], d[2]) + res(Ts[2], d[2], d[2]) + 2 * res(Ts[2], d[2], d[2])
+    f += res(Ts[2], 2 * d[2], d[1]) + res(Ts[2], d[1], d[1]) + conv(Ts[1], d[1], d[1], 4)        # ConvTranspose1d(4, 2, 1): 4 taps over T/4 inputs
+    f += res(Ts[1], 2 * d[1], d[0]) + res(Ts[1], d[0], d[0]) + conv(Ts[0], d[0], d[0], 4)
+    f += conv(Ts[0], d[0], d[0], k) + conv(Ts[0], cfg["input_dim"], d[0], 1)
+    film = 2.0 * cfg["global_cond_dim"] * 2 * (2 * d[0] + 2 * d[1] + 2 * d[2] + 2 * d[2] + 2 * d[1] + 2 * d[0])
+    total = cfg["num_inference_steps"] * S * f + film
+    return dict(forward_per_sequence=f, film=film, total=total)

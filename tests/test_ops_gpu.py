@@ -587,3 +587,41 @@ def test_dit_ffn_fused_swiglu_block(ops, M, with_h, alias):
     xu, hu = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device=_dev())
     ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
     _close(x, xu, rtol=1.0 / 128, atol=2e-2)
+
+
+def test_workspace_growth_never_frees_a_buffer_a_graph_has_seen(ops):
+    """library hardening: a hipGraph captured under a workspace slot keeps the scratch pointer it was captured with.
+    When a later eager launch under the same slot needs more scratch, the old buffer must stay alive (retired, not freed): the graph
+    replays into valid memory and reproduces its result."""
+    from internnav_amd import _lib
+
+    lib = _lib.lib()
+    _lib.check(lib.ina_set_workspace_slot(5), "slot")
+    g = torch.Generator().manual_seed(11)
+    B, H, Hkv, D, Lk = 2, 28, 4, 128, 512
+    q = _rand((B, 1, H, D), g)
+    k, v = _rand((B, Lk, Hkv, D), g), _rand((B, Lk, Hkv, D), g)
+    out = torch.zeros(B, 1, H, D, dtype=torch.bfloat16, device=_dev())
+    klen = torch.full((B,), Lk, dtype=torch.int32, device=_dev())
+    ops.attention(q, k, v, causal=True, out=out, k_len=klen)                     # eager once: the slot's scratch exists before capture
+    ref = out.clone()
+    retired0 = lib.ina_workspace_retired()
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            ops.attention(q, k, v, causal=True, out=out, k_len=klen)
+    torch.cuda.current_stream().wait_stream(s)
+    # a much larger decode-attention launch under the same slot: needs > 32 MiB of flash-decoding partials -> the slot grows
+    B2, Lk2 = 48, 8192
+    q2 = _rand((B2, 1, H, D), g)
+    k2, v2 = _rand((B2, Lk2, Hkv, D), g), _rand((B2, Lk2, Hkv, D), g)
+    ops.attention(q2, k2, v2, causal=True, k_len=torch.full((B2,), Lk2, dtype=torch.int32, device=_dev()))
+    torch.cuda.synchronize()
+    assert lib.ina_workspace_retired() == retired0 + 1                          # the captured buffer was retired, not freed
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    _lib.check(lib.ina_set_workspace_slot(0), "slot")
