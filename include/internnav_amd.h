@@ -249,6 +249,12 @@ typedef struct ina_rope_args {
     const int32_t* tab;     /* int32 [rows] table row per logical row, or NULL */
     ina_rowmap map;         /* logical row -> physical row of X */
     int32_t rows, heads, D, ldx, col0, _pad;
+    /* optional fused KV-cache append (decoder layers: q|k|v rows -> rotate q in place, write rotated k and the raw v of each row into
+     * the cache row kv_dst[r]): heads [kv_head0, heads) are the key heads, v_heads value heads follow them in X; the cache row holds
+     * [k heads | v heads] contiguously. KV == NULL: plain in-place rope on all heads. */
+    void* KV;               /* bf16 cache rows, row stride ldkv, or NULL */
+    const int32_t* kv_dst;  /* int32 [rows] cache row per logical row */
+    int32_t kv_head0, v_heads, ldkv, _pad2;
 } ina_rope_args;
 int ina_rope_bf16(const ina_rope_args* args, void* stream);
 

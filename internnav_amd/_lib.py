@@ -119,6 +119,7 @@ class RopeArgs(C.Structure):
         ("X", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("tab", c_void_p),
         ("map", RowMap),
         ("rows", c_int32), ("heads", c_int32), ("D", c_int32), ("ldx", c_int32), ("col0", c_int32), ("_pad", c_int32),
+        ("KV", c_void_p), ("kv_dst", c_void_p), ("kv_head0", c_int32), ("v_heads", c_int32), ("ldkv", c_int32), ("_pad2", c_int32),
     ]
 
 

@@ -26,29 +26,38 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs p) {
     }
 }
 
-// one thread handles 8 consecutive columns j..j+7 of the first half AND their partners j + D/2 of one head of one row
+// one thread handles 8 consecutive columns j..j+7 of the first half AND their partners j + D/2 of one head of one row.
+// With KV set (decoder layer, X rows = q | k | v): query heads are rotated in place, key heads are rotated INTO cache row kv_dst[r],
+// value heads (the v_heads heads behind the key heads) are copied there unrotated - rope + KV-cache append in one launch.
 __global__ __launch_bounds__(256) void rope_kernel(RopeArgs p) {
     const int half = p.D >> 1;
     const int groups = half >> 3;  // 8-wide groups per half
-    const long total = (long)p.rows * p.heads * groups;
+    const int hv = p.heads + (p.KV ? p.v_heads : 0);
+    const long total = (long)p.rows * hv * groups;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int g = (int)(i % groups);
-        const int h = (int)((i / groups) % p.heads);
-        const int r = (int)(i / ((long)groups * p.heads));
-        const int tr = p.tab ? p.tab[r] : r;
+        const int h = (int)((i / groups) % hv);
+        const int r = (int)(i / ((long)groups * hv));
         bf16* x = reinterpret_cast<bf16*>(p.X) + (size_t)map_row(p.map, r) * p.ldx + p.col0 + h * p.D + g * 8;
-        const float* c = p.cos + (size_t)tr * p.D + g * 8;
-        const float* s = p.sin + (size_t)tr * p.D + g * 8;
         bf16x8 lo = *reinterpret_cast<const bf16x8*>(x), hi = *reinterpret_cast<const bf16x8*>(x + half);
-        bf16x8 olo, ohi;
+        bf16* out = x;
+        if (p.KV && h >= p.kv_head0) out = reinterpret_cast<bf16*>(p.KV) + (size_t)p.kv_dst[r] * p.ldkv + (h - p.kv_head0) * p.D + g * 8;
+        if (h < p.heads) {
+            const int tr = p.tab ? p.tab[r] : r;
+            const float* c = p.cos + (size_t)tr * p.D + g * 8;
+            const float* s = p.sin + (size_t)tr * p.D + g * 8;
+            bf16x8 olo, ohi;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float a = (float)lo[j], b = (float)hi[j];
-            olo[j] = (bf16)(a * c[j] - b * s[j]);                  // x*cos + (-x2)*sin
-            ohi[j] = (bf16)(b * c[half + j] + a * s[half + j]);    // x2*cos + x1*sin
+            for (int j = 0; j < 8; ++j) {
+                const float a = (float)lo[j], b = (float)hi[j];
+                olo[j] = (bf16)(a * c[j] - b * s[j]);                  // x*cos + (-x2)*sin
+                ohi[j] = (bf16)(b * c[half + j] + a * s[half + j]);    // x2*cos + x1*sin
+            }
+            lo = olo;
+            hi = ohi;
         }
-        *reinterpret_cast<bf16x8*>(x) = olo;
-        *reinterpret_cast<bf16x8*>(x + half) = ohi;
+        *reinterpret_cast<bf16x8*>(out) = lo;
+        *reinterpret_cast<bf16x8*>(out + half) = hi;
     }
 }
 
@@ -116,8 +125,10 @@ int ina_launch_rope(const RopeArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.rows > 0 && p.heads > 0 && p.D % 16 == 0 && p.ldx % 8 == 0 && p.col0 % 8 == 0, "rope: bad shape rows=%d heads=%d D=%d ldx=%d col0=%d",
                 p.rows, p.heads, p.D, p.ldx, p.col0);
     INA_REQUIRE(p.X && p.cos && p.sin, "rope: X, cos, sin required");
-    InaProfScope prof(INA_PROF_ELEMENTWISE, 6.0 * p.rows * p.heads * p.D, 4.0 * p.rows * p.heads * p.D, stream);
-    const long total = (long)p.rows * p.heads * (p.D / 16);
+    INA_REQUIRE(!p.KV || (p.kv_dst && p.kv_head0 >= 0 && p.kv_head0 <= p.heads && p.v_heads >= 0 && p.ldkv % 8 == 0), "rope: bad KV-append arguments");
+    const int hv = p.heads + (p.KV ? p.v_heads : 0);
+    InaProfScope prof(INA_PROF_ELEMENTWISE, 6.0 * p.rows * p.heads * p.D, 4.0 * p.rows * hv * p.D, stream);
+    const long total = (long)p.rows * hv * (p.D / 16);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());

@@ -332,8 +332,12 @@ def gather_rows(x: torch.Tensor, out: torch.Tensor, src: Optional[torch.Tensor] 
 
 
 def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, D: int, col0: int = 0, rows: Optional[int] = None,
-         row_map=None, tab: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """in-place rotary embedding on `heads` heads of width D at columns [col0, col0 + heads*D) of bf16 rows x[row_map(r)]."""
+         row_map=None, tab: Optional[torch.Tensor] = None, kv_out: Optional[torch.Tensor] = None, kv_dst: Optional[torch.Tensor] = None,
+         kv_head0: int = 0, v_heads: int = 0) -> torch.Tensor:
+    """in-place rotary embedding on `heads` heads of width D at columns [col0, col0 + heads*D) of bf16 rows x[row_map(r)].
+    kv_out (fused KV-cache append of a decoder layer): heads [kv_head0, heads) are key heads - their rotated values go to cache row
+    kv_dst[r] of kv_out (not back into x) together with the v_heads value heads that follow them in x: one launch instead of rope +
+    gather."""
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
     assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == D
     a = _lib.RopeArgs()
@@ -341,6 +345,10 @@ def rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, heads: int, D: i
     a.map = _rowmap(row_map)
     a.rows = rows if rows is not None else x.shape[0]
     a.heads, a.D, a.ldx, a.col0 = heads, D, x.stride(0), col0
+    if kv_out is not None:
+        assert kv_out.dtype == torch.bfloat16 and kv_out.stride(1) == 1 and kv_dst.dtype == torch.int32 and kv_dst.is_contiguous()
+        assert kv_out.shape[1] >= (heads - kv_head0 + v_heads) * D
+        a.KV, a.kv_dst, a.kv_head0, a.v_heads, a.ldkv = kv_out.data_ptr(), kv_dst.data_ptr(), kv_head0, v_heads, kv_out.stride(0)
     _lib.check(_lib.lib().ina_rope_bf16(C.byref(a), _stream()), "rope_bf16")
     return x
 

@@ -273,8 +273,8 @@ class QwenVLEngine:
             src = self.x_in[:rows] if li == 0 else x
             ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
             ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
-            ops.rope(qkv, self.cos, self.sin, heads=nh + nkv, D=hd, col0=0, rows=rows)
-            ops.gather_rows(qkv[:, nh * hd:], L["kv"], dst=ph["rows"])
+            # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
+            ops.rope(qkv, self.cos, self.sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[:B, : ph["Lk"]]
             ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
             ops.linear(att, L["o_w"], residual=src, out=x)

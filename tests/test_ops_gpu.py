@@ -625,3 +625,23 @@ def test_workspace_growth_never_frees_a_buffer_a_graph_has_seen(ops):
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     _lib.check(lib.ina_set_workspace_slot(0), "slot")
+
+
+def test_rope_with_fused_kv_append_equals_rope_then_gather(ops):
+    """decoder-layer fusion: rope(q, k) + KV-cache append (rotated k | raw v -> cache rows) in one launch == the two launches it replaces,
+    bit for bit (q rotated in place, the k / v columns of the projection row are left untouched)."""
+    g = torch.Generator().manual_seed(5)
+    rows, nh, nkv, D = 37, 28, 4, 128
+    qkv = _rand((rows, (nh + 2 * nkv) * D), g)
+    cos, sin = torch.randn(rows, D, generator=g).to(_dev()), torch.randn(rows, D, generator=g).to(_dev())
+    dst = torch.randperm(64, generator=g)[:rows].to(torch.int32).to(_dev())
+    a = qkv.clone()
+    cache_a = torch.zeros(64, 2 * nkv * D, dtype=torch.bfloat16, device=_dev())
+    ops.rope(a, cos, sin, heads=nh + nkv, D=D, rows=rows)
+    ops.gather_rows(a[:, nh * D:], cache_a, dst=dst)
+    b = qkv.clone()
+    cache_b = torch.zeros(64, 2 * nkv * D, dtype=torch.bfloat16, device=_dev())
+    ops.rope(b, cos, sin, heads=nh + nkv, D=D, rows=rows, kv_out=cache_b, kv_dst=dst, kv_head0=nh, v_heads=nkv)
+    assert torch.equal(cache_a, cache_b)
+    assert torch.equal(a[:, : nh * D], b[:, : nh * D])                     # rotated queries
+    assert torch.equal(b[:, nh * D:], qkv[:, nh * D:])                      # k / v columns untouched in the fused form
