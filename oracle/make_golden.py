@@ -233,7 +233,9 @@ def gold_qwen(B=2, n_img=2):
     spec = importlib.util.spec_from_file_location("ref_rope2d", str(R.REF / "internnav" / "dataset" / "rope2d.py"))
     rope2d = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rope2d)
-    inp = W.qwen_inputs(B, n_img, seed=6, cfg=cfg)
+    # input seed 9: every greedy step of both sequences has a top-2 margin >= 0.13 logits (seed 6 had a 0.004 near-tie on the first token of
+    # sequence 1, which made exact-token tests depend on fp contraction choices of unrelated kernels)
+    inp = W.qwen_inputs(B, n_img, seed=9, cfg=cfg)
     ids, pv, grid = inp["input_ids"], inp["pixel_values"], inp["grid_thw"]
 
     def ref_rope(i):  # the reference's vendored implementation with the test config's token ids patched in
@@ -258,9 +260,13 @@ def gold_qwen(B=2, n_img=2):
 
     logits, h, emb, pos = ref_forward(ids)
     gen = ids.clone()
+    margins = []
     for _ in range(3):
         lg, _, _, _ = ref_forward(gen)
+        t2 = lg[:, -1].topk(2, dim=-1).values
+        margins.append(t2[:, 0] - t2[:, 1])
         gen = torch.cat([gen, lg[:, -1].argmax(-1)[:, None]], dim=1)
+    assert float(torch.stack(margins).min()) > 0.05, "pick an input seed without greedy near-ties"
     ids_q = torch.cat([gen, torch.full((B, cfg["n_query"]), cfg["traj_token_id"], dtype=torch.long)], dim=1)
     _, hq, _, _ = ref_forward(ids_q)
     latents = hq[:, -cfg["n_query"]:].clone()
@@ -274,8 +280,8 @@ def gold_qwen(B=2, n_img=2):
     assert torch.equal(o_gen, gen), "greedy tokens differ"
     d = max((o_emb - emb).abs().max().item(), (o_logits - logits).abs().max().item(), (o_lat - latents).abs().max().item())
     # fixtures stay small: every 8th row of the image embeds, last-position logits only
-    return dict(B=B, n_img=n_img, seed=6, image_embeds=emb[::8].clone(), embed_row_stride=8, position_ids=pos.to(torch.int32),
-                last_logits=logits[:, -1].clone(), generated=gen, latents=latents, oracle_max_abs_diff=d)
+    return dict(B=B, n_img=n_img, seed=6, input_seed=9, image_embeds=emb[::8].clone(), embed_row_stride=8, position_ids=pos.to(torch.int32),
+                last_logits=logits[:, -1].clone(), generated=gen, latents=latents, margins=torch.stack(margins, 1), oracle_max_abs_diff=d)
 
 
 def gold_unet1d(B=2):

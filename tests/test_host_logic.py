@@ -29,7 +29,7 @@ def test_rope_index_and_window_permutation_match_fixture_and_oracle():
 
     gold = torch.load(GOLD / "qwen.pt", weights_only=True)
     cfg = synthetic.QWEN_TEST_CFG
-    inp = synthetic.qwen_inputs(gold["B"], gold["n_img"], seed=gold["seed"], cfg=cfg)
+    inp = synthetic.qwen_inputs(gold["B"], gold["n_img"], seed=gold.get("input_seed", gold["seed"]), cfg=cfg)
     grids = [tuple(g) for g in inp["grid_thw"].tolist()]
     pos, deltas = rope_index(inp["input_ids"].numpy(), grids, cfg["image_token_id"], cfg["vision_start_id"])
     assert np.array_equal(pos, gold["position_ids"].numpy().astype(np.int64))

@@ -111,7 +111,7 @@ def test_qwen_s2_matches_transformers_and_reference_rope_index():
     gold = _load("qwen")
     cfg = W.QWEN_TEST_CFG
     sd = W.qwen_state_dict(seed=gold["seed"], cfg=cfg)
-    inp = W.qwen_inputs(gold["B"], gold["n_img"], seed=gold["seed"], cfg=cfg)
+    inp = W.qwen_inputs(gold["B"], gold["n_img"], seed=gold.get("input_seed", gold["seed"]), cfg=cfg)
     with torch.no_grad():
         pos, _ = o_q.rope_index(inp["input_ids"], inp["grid_thw"], cfg["image_token_id"], cfg["vision_start_id"])
         assert torch.equal(pos, gold["position_ids"].long())

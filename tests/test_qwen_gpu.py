@@ -21,7 +21,7 @@ def setup(built_lib):
     gold = torch.load(Path(__file__).resolve().parent / "golden" / "qwen.pt", weights_only=True)
     cfg = W.QWEN_TEST_CFG
     sd = W.qwen_state_dict(seed=gold["seed"], cfg=cfg)
-    inp = W.qwen_inputs(gold["B"], gold["n_img"], seed=gold["seed"], cfg=cfg)
+    inp = W.qwen_inputs(gold["B"], gold["n_img"], seed=gold.get("input_seed", gold["seed"]), cfg=cfg)
     eng = QwenVLEngine(sd, cfg, DEV, max_seqs=gold["B"], max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
     return gold, cfg, inp, eng
 
