@@ -197,6 +197,9 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         // (tile quantisation) x tile area / measured relative per-CU rate (profiles/r01f_gemm_tile_sweep.log):
         //   11: 128x128, 2 WG/CU, rate 0.85 | 14: 256x128 x 3 stages, 1 WG/CU, 0.92 | 18: 256x256 ping-pong, 1 WG/CU, 1.18 | 21: 192x256 ping-pong, 0.97 (long K only)
         cfg = p.K <= 1024 ? 22 : 11;   // short K: single-buffer 128x128 (32 KiB LDS, 4 workgroups per CU) beats the 2-stage ring by 3-13 %
+        // short K and a wide output (the d = 384 heads' fused q|k|v|q2 / SwiGLU projections, K = 384): 48 KiB single-buffer tiles with 85
+        // instead of 64 FLOP per operand byte, 3 workgroups per CU: +14-15 % (740-816 vs 632-704 TF/s, profiles/r02m_gemm_s1_tile_sweep.log)
+        if (p.K <= 512 && p.N >= 1024 && p.M >= 4096) cfg = p.N >= 1536 ? 26 : 27;
         if (p.K >= 768 && p.N > 512) {   // narrow outputs (N = 384 heads): 128x128 measured 6-15 % ahead of 256x128 at K = 1024 / 1536
             auto cost = [&](int bm, int bn, int wg_per_cu, double rate) {
                 const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch;
@@ -220,7 +223,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

@@ -517,6 +517,8 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
         case 22: return launch_glds<128, 128, 2, 2, 1>(p, stream);   // 128x128 single buffer, 4 workgroups per CU (2 waves of 128x64 wave tiles
                                                                       // instead of 4 of 64x64: 566 vs 726 TF/s at 65536x1536x384)
+        case 26: return launch_glds<128, 256, 2, 4, 1>(p, stream);   // 128x256 single buffer (48 KiB LDS, 3 workgroups per CU), 85 FLOP per operand byte
+        case 27: return launch_glds<256, 128, 4, 2, 1>(p, stream);   // 256x128 single buffer
         case 18: return launch_pp<256, 256, 4>(p, stream);           // 256x256, wave tile 128x64, ping-pong wave rows
         case 19: return launch_pp<128, 256, 4>(p, stream);           // 128x256, wave tile 64x64, ping-pong wave rows
         case 21: return launch_pp<192, 256, 4>(p, stream);           // 192x256, wave tile 96x64: finer row quantisation for M = 5520 / 6440

@@ -8,7 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from internnav_amd import ops  # noqa: E402
 
 
-def timeit(fn, iters=10, warmup=2):
+def timeit(fn, iters=int(__import__("os").environ.get("GEMM_ITERS", "10")), warmup=3):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -32,7 +32,9 @@ shapes = [
     (65536, 1536, 384, "bf16"), (65536, 384, 384, "f32r"), (65536, 2048, 384, "glu"), (65536, 384, 1024, "f32r"),
     (49152, 1152, 384, "bf16"), (49152, 384, 1536, "f32r"), (8192, 8192, 8192, "bf16"),
 ]
-cfgs = [int(c) for c in sys.argv[1:]] or [1, 6, 7, 8]
+cfgs = [int(c) for c in sys.argv[1:] if not c.startswith('s')] or [1, 6, 7, 8]
+if 's1' in sys.argv:
+    shapes = [s for s in shapes if s[0] >= 49152]
 for (M, N, K, mode) in shapes:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
