@@ -1,8 +1,8 @@
 """internnav_amd: MI355X-native InternVLA-N1 policy inference behind InternNav's agent / model plugin surface.
 
 `register_all()` is the one call a harness adds: it installs the batched HIP-backed agent under 'internvla_n1' in
-the reference's `Agent` registry and routes `get_policy('InternVLAN1_Policy')` / `get_config('InternVLAN1_Policy')` of
-`internnav.model` to this package's classes; every other policy name keeps going to the reference's own factory
+the reference's `Agent` registry and routes `get_policy` / `get_config` of `internnav.model` for 'InternVLAN1_Policy' and
+'NavDP_Policy' to this package's classes; every other policy name keeps going to the reference's own factory
 (internnav/model/__init__.py:1-56), so CMA / RDP / Seq2Seq agents are untouched.
 """
 from __future__ import annotations
@@ -14,9 +14,11 @@ _POLICIES = {}
 
 def _table():
     if not _POLICIES:
+        from .navdp import NavDPModelConfig, NavDPNet
         from .policy import InternVLAN1ModelConfig, InternVLAN1Net
 
         _POLICIES["InternVLAN1_Policy"] = (InternVLAN1Net, InternVLAN1ModelConfig)
+        _POLICIES["NavDP_Policy"] = (NavDPNet, NavDPModelConfig)        # constructed through NavDPNet.from_pretrained(path, config=...)
     return _POLICIES
 
 

@@ -263,6 +263,33 @@ class NavDPNet(_NavDPBase):
         self.neg = torch.empty(max_envs, 8, self.T, 3, dtype=f32, device=device)
         self.pos = torch.empty(max_envs, 8, self.T, 3, dtype=f32, device=device)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, max_envs: int = 64, **kwargs):
+        """the reference's loader (navdp_policy.py:36-64): `NavDPNet.from_pretrained(path, config=NavDPModelConfig(model_cfg=...))` with
+        `path` a directory holding pytorch_model.bin or a single state-dict file; model_cfg['il'] supplies memory_size / predict_size /
+        temporal_depth / heads / token_dim, model_cfg['local_rank'] the device (`cuda:{local_rank}`, :74)."""
+        import os
+
+        from . import synthetic
+
+        mc = getattr(config, "model_cfg", config) or {}
+        if hasattr(mc, "model_dump"):
+            mc = mc.model_dump()
+        il = dict(mc.get("il", {}))
+        cfg = dict(synthetic.NAVDPNET_CFG)
+        for k in ("image_size", "memory_size", "predict_size", "temporal_depth", "heads", "token_dim"):
+            if k in il:
+                cfg[k] = il[k]
+        f = os.path.join(pretrained_model_name_or_path, "pytorch_model.bin") if os.path.isdir(pretrained_model_name_or_path) else pretrained_model_name_or_path
+        sd = torch.load(f, map_location="cpu", weights_only=True)
+        missing = [k for k in synthetic.navdpnet_spec(cfg) if k not in sd]
+        if missing:
+            raise KeyError(f"NavDPNet checkpoint {f} lacks {len(missing)} parameters of the point-goal path, e.g. {missing[:4]}")
+        return cls(sd, cfg, device=f"cuda:{int(mc.get('local_rank', 0))}", max_envs=max_envs)
+
+    def eval(self):
+        return self
+
     def encode_rgbd(self, B: int, images: torch.Tensor, depths: torch.Tensor):
         """RGBDBackbone.forward (navdp_backbone.py:248-286): tokens -> cond rows 4.. (+ cond_pos_embed[4:])."""
         M, Lc, D = self.M, self.Lc, self.D
@@ -372,3 +399,14 @@ class NavDPPolicyDAT(_NavDPBase):
                    batched=True)
         sample = self._denoise(B, x_init, step_noise)
         return sample.view(B, self.S, self.T, 3)
+
+
+class NavDPModelConfig:
+    """holder of `model_cfg` as the reference's NavDPModelConfig is used by its callers (navdp_policy.py:22-33: model_cfg with the
+    'model', 'il' and 'local_rank' entries)."""
+    model_type = "navdp"
+
+    def __init__(self, model_cfg=None, **kwargs):
+        self.model_cfg = model_cfg if model_cfg is not None else {}
+        for k, v in kwargs.items():
+            setattr(self, k, v)

@@ -128,3 +128,25 @@ def test_navdpnet_batch_invariance(built_lib):
         assert (neg3[b] - neg1[0]).abs().max().item() < 5e-2
     if torch.equal((-cr3[b]).argsort()[:8], (-cr1).argsort()[:8]):
         assert (pos3[b] - pos1[0]).abs().max().item() < 5e-2
+
+
+def test_navdpnet_from_pretrained_reference_loader(built_lib, tmp_path):
+    """get_policy('NavDP_Policy') -> NavDPNet.from_pretrained(path, config=NavDPModelConfig(model_cfg={'il': ..., 'local_rank': 0})) as the
+    reference loads it (navdp_policy.py:36-64): a state-dict file on disk, hyper-parameters from model_cfg['il']; same outputs as the
+    engine built from the in-memory state dict."""
+    import internnav_amd
+
+    cls, cfg_cls = internnav_amd.get_policy("NavDP_Policy"), internnav_amd.get_config("NavDP_Policy")
+    sd = W.navdpnet_state_dict(seed=3)
+    torch.save(sd, tmp_path / "navdp.ckpt")
+    il = dict(image_size=224, memory_size=8, predict_size=24, temporal_depth=16, heads=8, token_dim=384, pixel_channel=4, channels=3, dropout=0.1,
+              scratch=False, finetune=False)
+    net = cls.from_pretrained(str(tmp_path / "navdp.ckpt"), config=cfg_cls(model_cfg={"model": {}, "il": il, "local_rank": 0}), max_envs=2)
+    ref = cls(sd, W.NAVDPNET_CFG, DEV, max_envs=2)
+    inp = {k: v.to(DEV) for k, v in W.navdpnet_inputs(2, seed=3).items()}
+    a = net.eval().predict_pointgoal_batch_action_vel(inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
+    b = ref.predict_pointgoal_batch_action_vel(inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    with pytest.raises(KeyError):
+        torch.save({k: v for k, v in sd.items() if not k.startswith("critic_head")}, tmp_path / "bad.ckpt")
+        cls.from_pretrained(str(tmp_path / "bad.ckpt"), config=cfg_cls(model_cfg={"il": il, "local_rank": 0}))
