@@ -38,7 +38,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn, 20 gn_mish, 21 pad_rows, 22 ddim_step):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn, 20 gn_mish, 21 pad_rows, 22 ddim_step, 23 ew, 24 colsum, 25 norm_bwd, 26 transpose, 27 sparse_rows, 28 small_linear, 29 mse, 30 adamw, 31 gemm_nn, 32 attn_bwd):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -441,6 +441,117 @@ typedef struct ina_ddim_step_args {
     int32_t _pad;
 } ina_ddim_step_args;
 int ina_ddim_step(const ina_ddim_step_args* args, void* stream);
+
+/* ======================================================================================================================
+ * SFT step (BASELINE config #5): backward and optimiser kernels. The reference has no FFI here either:
+ * these replace torch autograd of InternVLAN1ForCausalLM.forward(labels=...) (internvla_n1.py:222-286) and the HF Trainer's
+ * adamw_torch + clip_grad_norm_ (train_dual_system.sh:72-77). Backward GEMMs go through ina_gemm_bf16 on transposed copies.
+ * Tensors with a *_dt field are bf16 (0) or f32 (1).
+ * ====================================================================================================================== */
+#define INA_ACT_TANH_C 6
+#define INA_EW_AFFINE 0     /* Y = A * f(S[r / s_div]) + B + tab[r % tab_mod]   (f: 0 s, 1 1+s, 2 tanh s; S, B, tab optional) */
+#define INA_EW_ACT_FWD 1    /* Y = act(A) */
+#define INA_EW_ACT_BWD 2    /* Y = B * act'(A)            (A = pre-activation, B = dy) */
+#define INA_EW_GLU_FWD 3    /* Y = silu(A) * B */
+#define INA_EW_GLU_BWD 4    /* Y = D * B * silu'(A), Y2 = D * silu(A)   (D = dy) */
+typedef struct ina_ew_args {
+    const void* A; const void* B; const void* D; const void* S;
+    void* Y; void* Y2;
+    const float* tab;       /* f32 [tab_mod, C] or NULL */
+    int32_t op, rows, C;
+    int32_t a_dt, b_dt, d_dt, s_dt, y_dt, y2_dt;
+    int32_t lda, ldb, ldd, lds, ldy, ldy2;
+    int32_t s_div, s_f, tab_mod, act, accumulate; /* accumulate: Y += */
+} ina_ew_args;
+int ina_ew(const ina_ew_args* args, void* stream);
+
+/* out[g, c] (+)= scale * sum_{r in group g} X[r, c] * X2[r, c]  (bias / gain / LayerScale / modulation gradients, squared norms).
+ * x_cs / x2_cs: column stride of X / X2 (1 = dense, 0 = broadcast one value per row); out_cs: element stride between output columns. */
+typedef struct ina_colsum_args {
+    const void* X; const void* X2;  /* X2 optional */
+    float* out;
+    float* partial;         /* f32 scratch [groups * ceil(group_rows / 256) * C], needed when a group has more than 256 rows */
+    int64_t partial_elems;
+    int32_t rows, C, group_rows;    /* group_rows 0 = one group of all rows */
+    int32_t x_dt, x2_dt, ldx, ldx2, x_cs, x2_cs, ldo, out_cs;
+    int32_t accumulate;
+    float scale;            /* 0 means 1 */
+} ina_colsum_args;
+int ina_colsum(const ina_colsum_args* args, void* stream);
+
+/* backward of y = norm(x) * gamma (+ beta), LayerNorm or RMSNorm over the last dim; DX (+)=; XHAT (bf16, optional) for dgamma */
+typedef struct ina_norm_bwd_args {
+    const void* X; const void* DY; const float* gamma;
+    void* DX; void* XHAT;
+    int32_t rows, C, x_dt, dy_dt, dx_dt, ldx, lddy, lddx, ldxh, rms, accumulate;
+    float eps;
+} ina_norm_bwd_args;
+int ina_norm_bwd(const ina_norm_bwd_args* args, void* stream);
+
+/* Y[c, r] = bf16(X[r, c]); Y rows are ldy >= rows long (multiple of 8 for the GEMM), the tail is zero-filled */
+typedef struct ina_transpose_args {
+    const void* X; void* Y;
+    int32_t rows, cols, x_dt, ldx, ldy, _pad;
+} ina_transpose_args;
+int ina_transpose(const ina_transpose_args* args, void* stream);
+
+/* out[t, :] (+)= sum_j coef[t, j] * in[idx[t, j], :]  (idx < 0 = unused tap): DINOv2 bicubic pos-embed interpolation
+ * (dinov2.py:180-211) and, with the transposed tap table, its gradient */
+typedef struct ina_sparse_rows_args {
+    const float* in; float* out; const int32_t* idx; const float* coef;
+    int32_t n_out, C, taps, accumulate;
+} ina_sparse_rows_args;
+int ina_sparse_rows(const ina_sparse_rows_args* args, void* stream);
+
+/* Y[r, n] = sum_k X[r, k] * W[n * w_ns + k * w_ks] + bias[n] + tab[r % tab_mod, n]: nn.Linear(3, 384) / nn.Linear(384, 3)
+ * (internvla_n1_arch.py:129-131) forward and input gradient */
+typedef struct ina_small_linear_args {
+    const void* X; const float* W; const float* bias; const float* tab; void* Y;
+    int32_t rows, N, K, x_dt, y_dt, ldx, ldy, w_ns, w_ks, tab_mod;
+} ina_small_linear_args;
+int ina_small_linear(const ina_small_linear_args* args, void* stream);
+
+/* masked flow-matching MSE of internvla_n1.py:283-286 and its gradient: pred [nseq * T, D] (row stride ldp), mask [nseq] */
+typedef struct ina_mse_args {
+    const void* pred; const float* target; const float* mask; float* loss; void* dpred;
+    int32_t nseq, T, D, pred_dt, dpred_dt, ldp, lddp;
+    float loss_scale;
+} ina_mse_args;
+int ina_mse_masked(const ina_mse_args* args, void* stream);
+
+/* fused AdamW (torch.optim.AdamW update order) on a flat f32 buffer + clip_grad_norm_(max_norm) + 1 / world averaging + bf16 copy */
+typedef struct ina_adamw_args {
+    float* p; float* g; float* m; float* v;
+    void* p_bf16;               /* bf16 [n] working copy or NULL */
+    const float* sumsq_parts;   /* f32 [n_parts]: partial sums of g^2 (ina_colsum with X2 = X), or NULL when max_norm == 0 */
+    float* norm_out;            /* f32 [1]: the total gradient norm (after grad_scale), or NULL */
+    int64_t n;
+    int32_t n_parts, zero_grad;
+    float lr, beta1, beta2, eps, wd, bc1, bc2, max_norm, grad_scale;   /* bc = 1 - beta^step */
+    int32_t _pad;
+} ina_adamw_args;
+int ina_adamw(const ina_adamw_args* args, void* stream);
+
+/* partial[(split * 4 + w) * MR + m, k] = sum_{n in slice} X[m, n] * W[n, k]  (MR = 8 for M <= 8, else 16): dX of a frozen nn.Linear
+ * whose weight W [N, K] stays in its stored layout; reduce the splits * 4 slots with ina_colsum. M <= 16. */
+typedef struct ina_gemm_nn_args {
+    const void* X; const void* W; float* partial;
+    int64_t partial_elems;
+    int32_t M, N, K, ldx, ldw, splits;
+} ina_gemm_nn_args;
+int ina_gemm_nn_bf16(const ina_gemm_nn_args* args, void* stream);
+
+/* backward of ina_attention_bf16 (dense layouts only): f describes the forward call (Q, K, V, O and their strides);
+ * dO has O's strides. dQ pass writes lse / delta [B, H, Lq] f32, the dK / dV pass (optional) reads them. dK / dV are indexed by the
+ * QUERY head (sum the heads of a GQA group afterwards) and hold the key rows [kv_row0, Lk). */
+typedef struct ina_attn_bwd_args {
+    ina_attn_args f;
+    const void* dO; void* dQ; void* dK; void* dV;
+    float* lse; float* delta;
+    int64_t dq_bs, dq_rs, dq_hs, dkv_bs, dkv_rs, dkv_hs;
+    int32_t kv_row0, _pad;
+} ina_attn_bwd_args;
+int ina_attention_bwd_bf16(const ina_attn_bwd_args* args, void* stream);
 
 #ifdef __cplusplus
 }

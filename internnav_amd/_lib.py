@@ -207,6 +207,70 @@ class SelectArgs(C.Structure):
 
 
 # every symbol include/internnav_amd.h declares: name -> (restype, argtypes)
+
+# ---- SFT step (include/internnav_amd.h, second half) ------------------------------------------------------------------
+class EwArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("D", c_void_p), ("S", c_void_p), ("Y", c_void_p), ("Y2", c_void_p), ("tab", c_void_p),
+                ("op", c_int32), ("rows", c_int32), ("C", c_int32),
+                ("a_dt", c_int32), ("b_dt", c_int32), ("d_dt", c_int32), ("s_dt", c_int32), ("y_dt", c_int32), ("y2_dt", c_int32),
+                ("lda", c_int32), ("ldb", c_int32), ("ldd", c_int32), ("lds", c_int32), ("ldy", c_int32), ("ldy2", c_int32),
+                ("s_div", c_int32), ("s_f", c_int32), ("tab_mod", c_int32), ("act", c_int32), ("accumulate", c_int32)]
+
+
+class ColsumArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("X2", c_void_p), ("out", c_void_p), ("partial", c_void_p), ("partial_elems", c_int64),
+                ("rows", c_int32), ("C", c_int32), ("group_rows", c_int32),
+                ("x_dt", c_int32), ("x2_dt", c_int32), ("ldx", c_int32), ("ldx2", c_int32), ("x_cs", c_int32), ("x2_cs", c_int32),
+                ("ldo", c_int32), ("out_cs", c_int32), ("accumulate", c_int32), ("scale", c_float)]
+
+
+class NormBwdArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("DY", c_void_p), ("gamma", c_void_p), ("DX", c_void_p), ("XHAT", c_void_p),
+                ("rows", c_int32), ("C", c_int32), ("x_dt", c_int32), ("dy_dt", c_int32), ("dx_dt", c_int32),
+                ("ldx", c_int32), ("lddy", c_int32), ("lddx", c_int32), ("ldxh", c_int32), ("rms", c_int32), ("accumulate", c_int32),
+                ("eps", c_float)]
+
+
+class TransposeArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("Y", c_void_p), ("rows", c_int32), ("cols", c_int32), ("x_dt", c_int32), ("ldx", c_int32),
+                ("ldy", c_int32), ("_pad", c_int32)]
+
+
+class SparseRowsArgs(C.Structure):
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("idx", c_void_p), ("coef", c_void_p),
+                ("n_out", c_int32), ("C", c_int32), ("taps", c_int32), ("accumulate", c_int32)]
+
+
+class SmallLinearArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("tab", c_void_p), ("Y", c_void_p),
+                ("rows", c_int32), ("N", c_int32), ("K", c_int32), ("x_dt", c_int32), ("y_dt", c_int32), ("ldx", c_int32), ("ldy", c_int32),
+                ("w_ns", c_int32), ("w_ks", c_int32), ("tab_mod", c_int32)]
+
+
+class MseArgs(C.Structure):
+    _fields_ = [("pred", c_void_p), ("target", c_void_p), ("mask", c_void_p), ("loss", c_void_p), ("dpred", c_void_p),
+                ("nseq", c_int32), ("T", c_int32), ("D", c_int32), ("pred_dt", c_int32), ("dpred_dt", c_int32), ("ldp", c_int32),
+                ("lddp", c_int32), ("loss_scale", c_float)]
+
+
+class AdamwArgs(C.Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("p_bf16", c_void_p), ("sumsq_parts", c_void_p),
+                ("norm_out", c_void_p), ("n", c_int64), ("n_parts", c_int32), ("zero_grad", c_int32),
+                ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("wd", c_float), ("bc1", c_float), ("bc2", c_float),
+                ("max_norm", c_float), ("grad_scale", c_float), ("_pad", c_int32)]
+
+
+class GemmNnArgs(C.Structure):
+    _fields_ = [("X", c_void_p), ("W", c_void_p), ("partial", c_void_p), ("partial_elems", c_int64),
+                ("M", c_int32), ("N", c_int32), ("K", c_int32), ("ldx", c_int32), ("ldw", c_int32), ("splits", c_int32)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("f", AttnArgs), ("dO", c_void_p), ("dQ", c_void_p), ("dK", c_void_p), ("dV", c_void_p), ("lse", c_void_p), ("delta", c_void_p),
+                ("dq_bs", c_int64), ("dq_rs", c_int64), ("dq_hs", c_int64), ("dkv_bs", c_int64), ("dkv_rs", c_int64), ("dkv_hs", c_int64),
+                ("kv_row0", c_int32), ("_pad", c_int32)]
+
+
 SYMBOLS = {
     "ina_abi_version": (C.c_int, []),
     "ina_last_error": (C.c_char_p, []),
@@ -234,6 +298,16 @@ SYMBOLS = {
     "ina_gn_mish": (C.c_int, [C.POINTER(GnMishArgs), c_void_p]),
     "ina_pad_rows": (C.c_int, [C.POINTER(PadRowsArgs), c_void_p]),
     "ina_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), c_void_p]),
+    "ina_ew": (C.c_int, [C.POINTER(EwArgs), c_void_p]),
+    "ina_colsum": (C.c_int, [C.POINTER(ColsumArgs), c_void_p]),
+    "ina_norm_bwd": (C.c_int, [C.POINTER(NormBwdArgs), c_void_p]),
+    "ina_transpose": (C.c_int, [C.POINTER(TransposeArgs), c_void_p]),
+    "ina_sparse_rows": (C.c_int, [C.POINTER(SparseRowsArgs), c_void_p]),
+    "ina_small_linear": (C.c_int, [C.POINTER(SmallLinearArgs), c_void_p]),
+    "ina_mse_masked": (C.c_int, [C.POINTER(MseArgs), c_void_p]),
+    "ina_adamw": (C.c_int, [C.POINTER(AdamwArgs), c_void_p]),
+    "ina_gemm_nn_bf16": (C.c_int, [C.POINTER(GemmNnArgs), c_void_p]),
+    "ina_attention_bwd_bf16": (C.c_int, [C.POINTER(AttnBwdArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
     "ina_workspace_retired": (C.c_int, []),

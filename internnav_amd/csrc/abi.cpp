@@ -195,6 +195,16 @@ int ina_struct_size(int k) {
         case 20: return (int)sizeof(ina_gn_mish_args);
         case 21: return (int)sizeof(ina_pad_rows_args);
         case 22: return (int)sizeof(ina_ddim_step_args);
+        case 23: return (int)sizeof(ina_ew_args);
+        case 24: return (int)sizeof(ina_colsum_args);
+        case 25: return (int)sizeof(ina_norm_bwd_args);
+        case 26: return (int)sizeof(ina_transpose_args);
+        case 27: return (int)sizeof(ina_sparse_rows_args);
+        case 28: return (int)sizeof(ina_small_linear_args);
+        case 29: return (int)sizeof(ina_mse_args);
+        case 30: return (int)sizeof(ina_adamw_args);
+        case 31: return (int)sizeof(ina_gemm_nn_args);
+        case 32: return (int)sizeof(ina_attn_bwd_args);
         default: return -1;
     }
 }
@@ -224,6 +234,16 @@ INA_ENTRY(ina_dit_ffn, ina_dit_ffn_args, ina_launch_dit_ffn)
 INA_ENTRY(ina_gn_mish, ina_gn_mish_args, ina_launch_gn_mish)
 INA_ENTRY(ina_pad_rows, ina_pad_rows_args, ina_launch_pad_rows)
 INA_ENTRY(ina_ddim_step, ina_ddim_step_args, ina_launch_ddim_step)
+INA_ENTRY(ina_ew, ina_ew_args, ina_launch_ew)
+INA_ENTRY(ina_colsum, ina_colsum_args, ina_launch_colsum)
+INA_ENTRY(ina_norm_bwd, ina_norm_bwd_args, ina_launch_norm_bwd)
+INA_ENTRY(ina_transpose, ina_transpose_args, ina_launch_transpose)
+INA_ENTRY(ina_sparse_rows, ina_sparse_rows_args, ina_launch_sparse_rows)
+INA_ENTRY(ina_small_linear, ina_small_linear_args, ina_launch_small_linear)
+INA_ENTRY(ina_mse_masked, ina_mse_args, ina_launch_mse)
+INA_ENTRY(ina_adamw, ina_adamw_args, ina_launch_adamw)
+INA_ENTRY(ina_gemm_nn_bf16, ina_gemm_nn_args, ina_launch_gemm_nn)
+INA_ENTRY(ina_attention_bwd_bf16, ina_attn_bwd_args, ina_launch_attention_bwd)
 #undef INA_ENTRY
 
 }  // extern "C"

@@ -21,6 +21,7 @@ enum : int {
     INA_ACT_RELU = 3,       // nn.TransformerDecoderLayer default FFN, vlm_embed_mlp
     INA_ACT_SILU = 4,       // timestep embedder, adaLN SiLU
     INA_ACT_MISH = 5,       // diffusion-policy ConditionalUnet1D (cond_encoder, Conv1dBlock)
+    INA_ACT_TANH = 6,       // NextDiT gates (training path: ina_ew)
 };
 
 enum : int { INA_DT_BF16 = 0, INA_DT_F32 = 1 };
@@ -40,6 +41,7 @@ __device__ __forceinline__ float ina_act(float v, int act) {
         case INA_ACT_RELU: return v > 0.f ? v : 0.f;
         case INA_ACT_SILU: return ina_silu(v);
         case INA_ACT_MISH: return v * tanhf(v > 20.f ? v : log1pf(__expf(v)));
+        case INA_ACT_TANH: return tanhf(v);
         default: return v;
     }
 }

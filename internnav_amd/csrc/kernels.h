@@ -31,6 +31,16 @@ using DitFfnArgs = ina_dit_ffn_args;
 using GnMishArgs = ina_gn_mish_args;
 using PadRowsArgs = ina_pad_rows_args;
 using DdimStepArgs = ina_ddim_step_args;
+using EwArgs = ina_ew_args;
+using ColsumArgs = ina_colsum_args;
+using NormBwdArgs = ina_norm_bwd_args;
+using TransposeArgs = ina_transpose_args;
+using SparseRowsArgs = ina_sparse_rows_args;
+using SmallLinearArgs = ina_small_linear_args;
+using MseArgs = ina_mse_args;
+using AdamwArgs = ina_adamw_args;
+using GemmNnArgs = ina_gemm_nn_args;
+using AttnBwdArgs = ina_attn_bwd_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
@@ -58,3 +68,14 @@ int ina_launch_dit_ffn(const DitFfnArgs& p, hipStream_t stream);  // fused SwiGL
 int ina_launch_gn_mish(const GnMishArgs& p, hipStream_t stream);      // GroupNorm + Mish (+ FiLM, + residual) of a ConditionalUnet1D block
 int ina_launch_pad_rows(const PadRowsArgs& p, hipStream_t stream);
 int ina_launch_ddim_step(const DdimStepArgs& p, hipStream_t stream);
+// SFT step (train.hip, attention_bwd.hip)
+int ina_launch_ew(const EwArgs& p, hipStream_t stream);
+int ina_launch_colsum(const ColsumArgs& p, hipStream_t stream);
+int ina_launch_norm_bwd(const NormBwdArgs& p, hipStream_t stream);
+int ina_launch_transpose(const TransposeArgs& p, hipStream_t stream);
+int ina_launch_sparse_rows(const SparseRowsArgs& p, hipStream_t stream);
+int ina_launch_small_linear(const SmallLinearArgs& p, hipStream_t stream);
+int ina_launch_mse(const MseArgs& p, hipStream_t stream);
+int ina_launch_adamw(const AdamwArgs& p, hipStream_t stream);
+int ina_launch_gemm_nn(const GemmNnArgs& p, hipStream_t stream);
+int ina_launch_attention_bwd(const AttnBwdArgs& p, hipStream_t stream);
