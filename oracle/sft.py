@@ -1,0 +1,45 @@
+"""Oracle of the SFT loss of the `nextdit_async` System-1 (BASELINE config #5).  TEST INFRASTRUCTURE ONLY.
+
+Restates the `labels is not None` branch of InternVLAN1ForCausalLM.forward
+  internnav/model/basemodel/internvla_n1/internvla_n1.py:222-286   (trajectory hidden states -> flow-matching MSE)
+  internnav/model/basemodel/internvla_n1/internvla_n1_arch.py:189-198  get_sigmas
+on the fp32 functional modules of oracle/nextdit.py / oracle/dinov2.py; torch autograd of this function is the reference gradient.
+The noise and the time-step indices the reference draws inside forward (torch.randn / torch.rand, :261-264) are arguments here.
+FlowMatchEulerDiscreteScheduler() (diffusers 0.33.1, un-vendored) default state: timesteps = [1000, 999, ..., 1], sigmas = t / 1000.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import dinov2
+from .nextdit import RESNET_MEAN, RESNET_STD, memory_encoder, qformer, sinusoidal_positional_encoding, traj_dit
+from .nn_ref import linear
+
+
+def nextdit_sft_loss(sd, hidden_q, traj_images, traj_poses, video_frame_num, noise, t_index, num_train_timesteps=1000):
+    """hidden_q [B, n_query, 3584] (hidden_states[b, t_s_pos[b] : t_s_pos[b] + n_query]); traj_images [B, T, 224, 224, 3] in 0..1;
+    traj_poses [B, T, 32, 3]; video_frame_num [B]; noise [B*T, 32, 3]; t_index long [B*T]. Returns the scalar loss."""
+    B, Tn = traj_images.shape[:2]
+    ths = hidden_q.unsqueeze(1).repeat(1, Tn, 1, 1).flatten(0, 1)                                  # :229
+    loss_mask = torch.arange(Tn).expand(B, Tn) < video_frame_num.unsqueeze(1)                      # :230-232
+    cur = traj_images.flatten(0, 1)
+    goal = traj_images[:, 0:1].repeat(1, Tn, 1, 1, 1).flatten(0, 1)
+    bsz = cur.size(0)
+    images_dp = torch.stack([goal, cur], dim=1).permute(0, 1, 4, 2, 3)                             # :239
+    norm = (images_dp.float() - RESNET_MEAN.view(1, 1, 3, 1, 1)) / RESNET_STD.view(1, 1, 3, 1, 1)
+    feat = dinov2.forward_tokens(norm.flatten(0, 1), sd, "rgb_model.").unflatten(0, (bsz, -1))     # :242-246
+    mem = memory_encoder(feat.flatten(1, 2), sd)                                                   # :248-250
+    tokens = qformer(torch.cat([feat.flatten(1, 2), mem], dim=-1), sd)                             # :251-252
+    lat = linear(F.gelu(linear(ths.float(), sd, "cond_projector.0"), approximate="tanh"), sd, "cond_projector.2")
+    latents = torch.cat([tokens, lat], dim=1)                                                      # :255
+    x = traj_poses.flatten(0, 1).float()
+    timesteps = (num_train_timesteps - t_index).float()
+    sig = (timesteps / num_train_timesteps).view(-1, 1, 1)
+    noisy = (1 - sig) * x + sig * noise                                                            # :270
+    feats = linear(noisy, sd, "action_encoder") + sinusoidal_positional_encoding(x.shape[1], 384)  # :271-274
+    pred = linear(traj_dit(feats, timesteps, latents, sd), sd, "action_decoder")                   # :276-281
+    target = noise - x
+    loss = F.mse_loss(pred.float(), target.float(), reduction="none")
+    mask = loss_mask.flatten(0, 1)[:, None, None]
+    return (loss * mask).sum() / mask.sum() / (loss.shape[1] * loss.shape[2])                      # :283-286

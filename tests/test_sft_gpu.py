@@ -1,0 +1,110 @@
+"""SFT step (BASELINE config #5): loss, every parameter gradient and the AdamW update of the HIP tape against torch
+autograd of the fp32 oracle (oracle/sft.py, pinned to the reference's own modules by tests/golden/sft.pt), with bf16-autocast PyTorch
+autograd of the same functions as the yardstick: the engine's gradient error must not exceed what bf16 PyTorch itself shows."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _inputs(B, T, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return dict(hidden_q=torch.randn(B, 4, 3584, generator=g).bfloat16().float(), traj_images=torch.rand(B, T, 224, 224, 3, generator=g),
+                traj_poses=torch.randn(B, T, 32, 3, generator=g), video_frame_num=torch.tensor([T] + [max(1, T - 1)] * (B - 1)),
+                noise=torch.randn(B * T, 32, 3, generator=g), t_index=torch.randint(0, 1000, (B * T,), generator=g))
+
+
+def _oracle(sd0, inp, autocast):
+    from oracle import sft as O
+
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    hq = inp["hidden_q"].clone().requires_grad_(True)
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+        loss = O.nextdit_sft_loss(sd, hq, inp["traj_images"], inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"])
+    loss.backward()
+    return loss.item(), hq.grad.float(), {k: v.grad.float() for k, v in sd.items() if v.grad is not None}, sd
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+@pytest.fixture(scope="module")
+def case(dev):
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+
+    sd0 = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
+    inp = _inputs(2, 2)
+    ref = _oracle(sd0, inp, False)
+    yard = _oracle(sd0, inp, True)
+    head = E.NextDiTSftHead(sd0, dev)
+    loss, dh = head.loss_and_grads(inp["hidden_q"].to(dev), inp["traj_images"].to(dev), inp["traj_poses"], inp["video_frame_num"],
+                                   inp["noise"], inp["t_index"])
+    return sd0, inp, ref, yard, head, loss, dh
+
+
+def test_loss_and_input_gradient(case):
+    sd0, inp, (l32, dh32, g32, _), (l16, dh16, g16, _), head, loss, dh = case
+    assert abs(loss.item() - l32) <= max(abs(l16 - l32), 2e-3 * abs(l32)), (loss.item(), l32, l16)
+    e, y = _rel(dh.float().cpu().view_as(dh32), dh32), _rel(dh16, dh32)
+    assert e <= 1.1 * y, f"d loss / d hidden: engine {e:.3e} vs bf16 PyTorch {y:.3e}"
+
+
+def test_every_parameter_gradient(case):
+    sd0, inp, (l32, dh32, g32, _), (l16, dh16, g16, _), head, loss, dh = case
+    errs, yards, bad = [], [], []
+    scale = max(g.norm().item() for g in g32.values())
+    for k, ref in g32.items():
+        assert k in head.P, f"{k} has a reference gradient but is not in the trainable store"
+        got = head.P.grad(k).cpu().view_as(ref)
+        if ref.norm().item() < 1e-6 * scale:
+            # identically-zero gradients (norm_k.bias: a bias on every key shifts all scores of a query equally) - compare absolutely
+            assert got.norm().item() < 1e-4 * scale, k
+            continue
+        e, y = _rel(got, ref), _rel(g16[k], ref)
+        errs.append(e)
+        yards.append(y)
+        if e > 2.5 * y + 2e-3 or e > 3e-2:
+            bad.append((k, e, y))
+    assert not bad, bad[:10]
+    assert sum(errs) / len(errs) <= sum(yards) / len(yards), (sum(errs) / len(errs), sum(yards) / len(yards))
+    # the trainable set is exactly the reference's freeze map for system1 = nextdit (internvla_n1_trainer.py:104-117) minus tensors
+    # that never reach the loss (rgb_model.mask_token, the unused QFormer.visual_proj)
+    assert set(head.P.index) - set(g32) <= {k for k in head.P.index if "visual_proj" in k}
+
+
+def test_adamw_steps_follow_torch(case, dev):
+    """3 optimiser steps: given the tape's gradients, the flat fused update (global-norm clip + AdamW + bf16 working copy + grad reset)
+    equals torch.nn.utils.clip_grad_norm_(1.0) + torch.optim.AdamW (HF `adamw_torch`) on per-tensor parameters."""
+    from internnav_amd import sft as E
+
+    sd0, inp = case[0], case[1]
+    LR = 1e-4
+    head = E.NextDiTSftHead(sd0, dev)
+    ref = {k: torch.nn.Parameter(head.P.w32(k).clone()) for k in head.P.index}
+    opt = torch.optim.AdamW(list(ref.values()), lr=LR, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    norm = torch.zeros(1, device=dev)
+    losses = []
+    for step in range(3):
+        l2, _ = head.loss_and_grads(inp["hidden_q"].to(dev), inp["traj_images"].to(dev), inp["traj_poses"], inp["video_frame_num"],
+                                    inp["noise"], inp["t_index"])
+        losses.append(l2.item())
+        for k, p in ref.items():
+            p.grad = head.P.grad(k).clone()
+        tn = torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        opt.step()
+        head.P.adamw_step(LR, max_norm=1.0, norm_out=norm)
+        assert abs(norm.item() - tn.item()) < 1e-4 * tn.item(), (step, norm.item(), tn.item())
+        assert float(head.P.g32.abs().max()) == 0.0
+        for k, p in ref.items():
+            assert (head.P.w32(k) - p.detach()).abs().max().item() <= 5e-7 * max(1.0, p.detach().abs().max().item()), (step, k)   # fp32 rounding of the same update
+        assert torch.equal(head.P.p16, head.P.p32.bfloat16())
+    assert len(set(losses)) == 3, losses        # the bf16 working weights did move
