@@ -427,7 +427,104 @@ def gold_preprocess():
                 oracle_max_abs_diff=float(max(diffs)))
 
 
-UNITS = {"unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_sft(B=1, T=2):
+    """SFT loss of the nextdit_async branch (internvla_n1.py:222-286) through the reference's own System-1 modules under autograd
+    (dropout off: .eval()), transcribed line by line; the noise / time-step draws of :261-264 are seeded inputs. Saves the loss, the
+    gradient w.r.t. the trajectory hidden states and, per parameter, the gradient norm + 32 sampled entries."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from . import sft as o_sft
+    from .schedulers import FlowMatchEulerDiscreteScheduler
+
+    nd, arch = R.nextdit_module(), R.n1_arch_module()
+    sd = W.n1_nextdit_state_dict(seed=6)
+
+    class S1(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.traj_dit = nd.NextDiTCrossAttn(nd.NextDiTCrossAttnConfig(latent_embedding_size=768))
+            self.noise_scheduler = FlowMatchEulerDiscreteScheduler()
+            self.action_encoder = nn.Linear(3, 384, bias=True)
+            self.pos_encoding = arch.SinusoidalPositionalEncoding(384)
+            self.action_decoder = nn.Linear(384, 3, bias=True)
+            self.cond_projector = nn.Sequential(nn.Linear(3584, 768), nn.GELU(approximate="tanh"), nn.Linear(768, 768))
+            self.rgb_model = R.dinov2_vits()
+            self.memory_encoder = arch.MemoryEncoder()
+            self.rgb_resampler = arch.QFormer()
+
+    m = _load_strict(S1(), sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.", "rgb_resampler.visual_proj."))
+    g = torch.Generator().manual_seed(6)
+    hidden_q = torch.randn(B, 4, 3584, generator=g).requires_grad_(True)
+    traj_images = torch.rand(B, T, 224, 224, 3, generator=g)
+    traj_poses = torch.randn(B, T, 32, 3, generator=g)
+    video_frame_num = torch.tensor([T] * (B - 1) + [max(1, T - 1)])
+    noise = torch.randn(B * T, 32, 3, generator=g)
+    indices = torch.randint(0, 1000, (B * T,), generator=g)
+    mean = torch.FloatTensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)
+    std = torch.FloatTensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
+
+    traj_hidden_states = hidden_q.unsqueeze(1).repeat(1, traj_poses.size(1), 1, 1).flatten(0, 1)
+    loss_mask = torch.arange(traj_images.size(1)).expand(traj_images.size(0), traj_images.size(1)) < video_frame_num.unsqueeze(1)
+    cur_images = traj_images.flatten(0, 1)
+    pix_goal_images = traj_images[:, 0:1].repeat(1, traj_images.size(1), 1, 1, 1).flatten(0, 1)
+    bsz = cur_images.size(0)
+    images_dp = torch.stack([pix_goal_images, cur_images], dim=1).permute(0, 1, 4, 2, 3)
+    images_dp_norm = (images_dp - mean) / std
+    images_dp_feat = m.rgb_model.get_intermediate_layers(images_dp_norm.flatten(0, 1))[0].unflatten(dim=0, sizes=(bsz, -1))
+    memory_feat = m.memory_encoder(images_dp_feat.flatten(1, 2))
+    memory_feat = torch.cat([images_dp_feat.flatten(1, 2), memory_feat], dim=-1)
+    memory_tokens = m.rgb_resampler(memory_feat)
+    ths = m.cond_projector(traj_hidden_states)
+    latents = torch.cat([memory_tokens, ths], dim=1)
+    relative_poses = traj_poses.flatten(0, 1)
+    timesteps = m.noise_scheduler.timesteps[indices]
+    schedule_timesteps = m.noise_scheduler.timesteps
+    step_indices = [(schedule_timesteps == t).nonzero().item() for t in timesteps]      # get_sigmas, internvla_n1_arch.py:189-198
+    sigmas = m.noise_scheduler.sigmas[step_indices].flatten()
+    while len(sigmas.shape) < relative_poses.dim():
+        sigmas = sigmas.unsqueeze(-1)
+    noisy_trajectory = (1 - sigmas) * relative_poses + sigmas * noise
+    action_features = m.action_encoder(noisy_trajectory)
+    pos_ids = torch.arange(relative_poses.shape[1]).reshape(1, -1).repeat(bsz, 1)
+    action_features = action_features + m.pos_encoding(pos_ids)
+    noise_pred = m.traj_dit(x=action_features, timestep=timesteps, z_latents=latents)
+    noise_pred = m.action_decoder(noise_pred)
+    target = noise - relative_poses
+    loss = F.mse_loss(noise_pred.float(), target.float(), reduction="none")
+    mask = loss_mask.flatten(0, 1)[:, None, None]
+    loss = (loss * mask).sum() / mask.sum() / (loss.shape[1] * loss.shape[2])
+    loss.backward()
+    ref_grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+    sd_o = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    hq_o = hidden_q.detach().clone().requires_grad_(True)
+    loss_o = o_sft.nextdit_sft_loss(sd_o, hq_o, traj_images, traj_poses, video_frame_num, noise, indices)
+    loss_o.backward()
+    worst = abs(loss_o.item() - loss.item())
+    samples = {}
+    gscale = max(g.abs().max().item() for g in ref_grads.values())
+    for k, gr in ref_grads.items():
+        assert k in sd_o and sd_o[k].grad is not None, f"reference parameter {k} has a gradient, the oracle's has none"
+        scale = gr.abs().max().item()
+        rel_k = (gr - sd_o[k].grad).abs().max().item() / max(scale, 1e-12)
+        if scale < 1e-6 * gscale:        # identically-zero gradients (norm_k.bias: softmax is invariant to a bias on every key): fp32 noise
+            rel_k = 0.0
+        if rel_k > 1e-3:
+            print(f"  [sft] {k}: rel {rel_k:.3e} scale {scale:.3e}")
+        worst = max(worst, rel_k)
+        flat = gr.flatten()
+        pick = torch.linspace(0, flat.numel() - 1, min(32, flat.numel())).long()
+        samples[k] = dict(norm=gr.norm().item(), idx=pick, val=flat[pick].clone())
+    worst = max(worst, ((hidden_q.grad - hq_o.grad).abs().max() / hidden_q.grad.abs().max()).item())
+    no_grad = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    return dict(B=B, T=T, seed=6, weights_seed=6, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples, params_without_grad=no_grad,
+                inputs=dict(hidden_q=hidden_q.detach(), traj_images=traj_images, traj_poses=traj_poses, video_frame_num=video_frame_num,
+                            noise=noise, t_index=indices),
+                oracle_max_abs_diff=worst)
+
+
+UNITS = {"sft": gold_sft, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

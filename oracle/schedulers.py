@@ -89,8 +89,12 @@ class FlowMatchEulerDiscreteScheduler:
 
     def __init__(self, num_train_timesteps=1000, shift=1.0, **_):
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift)
-        self.timesteps = None
-        self.sigmas = None
+        # state after construction (what the SFT loss indexes, internvla_n1.py:264-268): timesteps N..1, sigmas = t / N (shifted)
+        t = torch.from_numpy(np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy())
+        sig = t / num_train_timesteps
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = sig * num_train_timesteps
+        self.sigmas = sig
         self._step_index = None
 
     def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None):

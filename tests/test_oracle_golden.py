@@ -157,3 +157,38 @@ def test_ddim_scheduler_known_properties():
         assert torch.allclose(prev, sch.add_noise(x0, eps, torch.tensor(t - 10)), atol=1e-5)
     xt = sch.add_noise(x0, eps, torch.tensor(0))
     assert torch.allclose(sch.step(eps, 0, xt).prev_sample, x0, atol=1e-5)     # set_alpha_to_one: the last step returns x0
+
+
+def test_sft_loss_and_gradients_match_reference_autograd():
+    """SFT loss of the nextdit_async branch (internvla_n1.py:222-286): torch autograd of the oracle restatement against the fixture made
+    by back-propagating through the reference's own NextDiT / MemoryEncoder / QFormer / DINOv2 modules (oracle/make_golden.py gold_sft)."""
+    from oracle import sft as o_sft
+
+    gold = _load("sft")
+    sd = {k: v.float().clone().requires_grad_(True) for k, v in W.n1_nextdit_state_dict(seed=gold["weights_seed"]).items()}
+    inp = gold["inputs"]
+    hq = inp["hidden_q"].clone().requires_grad_(True)
+    loss = o_sft.nextdit_sft_loss(sd, hq, inp["traj_images"], inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"])
+    loss.backward()
+    assert abs(loss.item() - gold["loss"]) < 1e-5 * abs(gold["loss"])
+    assert ((hq.grad - gold["d_hidden"]).abs().max() / gold["d_hidden"].abs().max()).item() < 1e-4
+    gscale = max(g["norm"] for g in gold["grads"].values())
+    for k, g in gold["grads"].items():
+        mine = sd[k].grad
+        assert mine is not None, k
+        if g["norm"] < 1e-6 * gscale:          # identically zero (norm_k.bias)
+            assert mine.norm().item() < 1e-5 * gscale, k
+            continue
+        assert abs(mine.norm().item() - g["norm"]) < 1e-4 * g["norm"], k
+        assert (mine.flatten()[g["idx"]] - g["val"]).abs().max().item() < 1e-4 * max(g["val"].abs().max().item(), g["norm"] / mine.numel() ** 0.5), k
+    # tensors the loss never touches in the reference: the same ones get no gradient here
+    for k in gold["params_without_grad"]:
+        if k in sd:
+            assert sd[k].grad is None or float(sd[k].grad.abs().max()) == 0.0, k
+
+
+def test_flow_match_scheduler_default_state():
+    """FlowMatchEulerDiscreteScheduler() as constructed (what the SFT loss indexes): timesteps 1000..1, sigmas = t / 1000."""
+    s = FlowMatchEulerDiscreteScheduler()
+    assert s.timesteps.shape == (1000,) and s.timesteps[0].item() == 1000.0 and s.timesteps[-1].item() == 1.0
+    assert torch.allclose(s.sigmas, s.timesteps / 1000.0)
