@@ -543,7 +543,8 @@ int ina_gemm_nn_bf16(const ina_gemm_nn_args* args, void* stream);
 
 /* backward of ina_attention_bf16 (dense layouts only): f describes the forward call (Q, K, V, O and their strides);
  * dO has O's strides. dQ pass writes lse / delta [B, H, Lq] f32, the dK / dV pass (optional) reads them. dK / dV are indexed by the
- * QUERY head (sum the heads of a GQA group afterwards) and hold the key rows [kv_row0, Lk). */
+ * QUERY head (sum the heads of a GQA group afterwards) and hold the key rows [kv_row0, Lk); kv_row0 = -1: the last Lq key rows of every
+ * sequence (k_len - Lq .. k_len: the query rows' own keys in a cached causal pass). */
 typedef struct ina_attn_bwd_args {
     ina_attn_args f;
     const void* dO; void* dQ; void* dK; void* dV;

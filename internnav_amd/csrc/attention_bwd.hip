@@ -194,7 +194,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
             *reinterpret_cast<bf16x4*>(dQ + d) = o;
         }
     } else {
-        const int kt0 = a.kv_row0 + blockIdx.x * (NW * 16);
+        const int row0 = a.kv_row0 < 0 ? max(0, len_k - len_q) : a.kv_row0;   // -1: the last Lq keys of every sequence (ragged k_len)
+        const int kt0 = row0 + blockIdx.x * (NW * 16);
         if (kt0 >= len_k) return;
         const int k_abs = kt0 + wave * 16 + lq;
         const bool live = k_abs < len_k;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
             }
         }
         if (!live) return;
-        const size_t off = (size_t)b * a.dkv_bs + (size_t)h * a.dkv_hs + (size_t)(k_abs - a.kv_row0) * a.dkv_rs;
+        const size_t off = (size_t)b * a.dkv_bs + (size_t)h * a.dkv_hs + (size_t)(k_abs - row0) * a.dkv_rs;
         bf16* dK = reinterpret_cast<bf16*>(a.dK) + off;
         bf16* dV = reinterpret_cast<bf16*>(a.dV) + off;
 #pragma unroll
@@ -301,7 +302,7 @@ int ina_launch_attention_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     INA_REQUIRE(!p.head_gate && p.kv_start == 0 && !p.accumulate, "attention_bwd: head_gate / kv_start / accumulate are forward-only");
     INA_REQUIRE(p.D % 8 == 0 && p.D <= 128, "attention_bwd: head dim %d unsupported (multiple of 8, <= 128)", p.D);
     INA_REQUIRE(p.H % p.Hkv == 0, "attention_bwd: H %d not a multiple of Hkv %d", p.H, p.Hkv);
-    INA_REQUIRE(a.kv_row0 >= 0 && a.kv_row0 <= p.Lk, "attention_bwd: kv_row0 %d out of range", a.kv_row0);
+    INA_REQUIRE(a.kv_row0 >= -1 && a.kv_row0 <= p.Lk, "attention_bwd: kv_row0 %d out of range (-1 = the last Lq keys of every sequence)", a.kv_row0);
     const bool d64 = p.D <= 64;
     const bool small_q = p.Lq <= 32;
     if (a.dQ) {
@@ -312,7 +313,7 @@ int ina_launch_attention_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     if (a.dK) {
         INA_REQUIRE(a.dV != nullptr, "attention_bwd: dK without dV");
         INA_REQUIRE(a.dQ != nullptr, "attention_bwd: dK / dV need the lse / delta statistics written by the dQ pass of the same call");
-        const int rows = p.Lk - a.kv_row0;
+        const int rows = a.kv_row0 < 0 ? min(p.Lq, p.Lk) : p.Lk - a.kv_row0;
         if (rows > 0) {
             const bool small_k = rows <= 32;
             int rc = d64 ? (small_k ? launch_bwd<64, 2, 1>(a, rows, stream) : launch_bwd<64, 4, 1>(a, rows, stream))

@@ -268,7 +268,7 @@ def gemm_nn(x, w, out=None, out_dtype=torch.float32, splits: Optional[int] = Non
     mr = 8 if M <= 8 else 16
     if splits is None:
         colblocks = (K + 511) // 512
-        splits = max(1, min((N + 15) // 16, (1024 + colblocks - 1) // colblocks))
+        splits = max(1, min((N + 15) // 16, (512 + colblocks - 1) // colblocks))      # ~2 workgroups per CU
         while (N + splits - 1) // splits * mr * 4 > 48 * 1024:
             splits *= 2
     part = torch.empty(splits * 4, mr * K, dtype=torch.float32, device=x.device)
@@ -314,7 +314,7 @@ def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=
     stats = torch.empty(2, B, H, Lq, dtype=torch.float32, device=q.device)
     a.lse, a.delta = stats[0].data_ptr(), stats[1].data_ptr()
     if need_dkv:
-        rows = Lk - kv_row0
+        rows = min(Lq, Lk) if kv_row0 < 0 else Lk - kv_row0
         if dk is None:
             dk = torch.empty(B, rows, H, D, dtype=torch.bfloat16, device=q.device)
         if dv is None:
