@@ -610,8 +610,9 @@ S1_TRAINABLE_PREFIXES = ("action_encoder", "action_decoder", "traj_dit", "cond_p
 class NextDiTSftHead:
     """Loss + gradients of the nextdit_async branch of InternVLAN1ForCausalLM.forward(labels=...) (internvla_n1.py:222-286)."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], device, n_query: int = 4):
-        keep = {k: v for k, v in sd.items() if k.startswith(S1_TRAINABLE_PREFIXES) and not k.endswith("mask_token")}
+    def __init__(self, sd: Dict[str, torch.Tensor], device, n_query: int = 4, extra_trainable: Sequence[str] = ()):
+        """extra_trainable: further tensors of `sd` to keep in the same flat store (`latent_queries`, whose gradient the caller adds)."""
+        keep = {k: v for k, v in sd.items() if (k.startswith(S1_TRAINABLE_PREFIXES) and not k.endswith("mask_token")) or k in extra_trainable}
         self.P = ParamStore(keep, device)
         self.device = device
         self.n_query = n_query

@@ -1,0 +1,141 @@
+"""One SFT step of InternVLA-N1 (`system1 = nextdit_async`) as the reference trains it (BASELINE config #5):
+`InternVLAN1ForCausalLM.forward(labels=...)` + HF Trainer optimiser step, on the HIP kernels.
+
+Batch layout = `DataCollatorForSupervisedDataset` output (internvla_n1_lerobot_dataset.py:1150-1280): `input_ids` [B, S] right-padded with
+the N_QUERY `<traj>` tokens appended behind each sample's own tokens (`t_s_pos[b]` = where they start, :1168-1183), `pixel_values` /
+`image_grid_thw` of the Qwen processor, `traj_images` [B, T, 224, 224, 3], `traj_poses` [B, T, 32, 3], `video_frame_num` [B].
+
+Step = frozen System-2 forward of the tokens before `t_s_pos` (ViT + LLM prefill, ragged batch, KV cache kept)  ->  latent-query rows
+(`sft_llm.LatentQueryGrad`)  ->  System-1 loss and gradients (`sft.NextDiTSftHead`)  ->  latent-query backward  ->  gradient reduction
+over the data-parallel ranks (ONE flat bucket; all-reduce, or reduce-scatter + sharded update + all-gather = ZeRO-2)  ->  fused
+clip + AdamW. Optimiser / schedule: adamw_torch, lr 1e-4 -> cosine_with_min_lr 1e-5, warm-up ratio 0.003, weight decay 0, clip 1.0
+(train_dual_system.sh:72-77).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import train_ops as T
+from .qwen_vl import QwenVLEngine
+from .sft import NextDiTSftHead
+from .sft_llm import LatentQueryGrad
+
+LQ = "latent_queries"
+
+
+def cosine_with_min_lr(step: int, total_steps: int, warmup_steps: int, lr: float, min_lr: float) -> float:
+    """transformers.get_cosine_with_min_lr_schedule_with_warmup (num_cycles 0.5) evaluated at optimiser step `step` (0-based)."""
+    if step < warmup_steps:
+        return lr * step / max(1, warmup_steps)
+    progress = (step - warmup_steps) / max(1, total_steps - warmup_steps)
+    factor = 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * progress))
+    rate = min_lr / lr
+    return lr * max(0.0, factor * (1 - rate) + rate)
+
+
+def shard_bounds(numel: int, world: int, rank: int, align: int = 1024):
+    """[lo, hi) of rank's slice of a flat buffer whose length is a multiple of `align`: equal slices of whole `align` blocks, the last
+    ranks may be shorter / empty (ZeRO-2 partition of the flat gradient / moment buffers)."""
+    blocks = numel // align
+    per = (blocks + world - 1) // world
+    lo = min(blocks, rank * per) * align
+    hi = min(blocks, (rank + 1) * per) * align
+    return lo, hi
+
+
+class InternVLAN1SftTrainer:
+    def __init__(self, engine: QwenVLEngine, s1_state_dict: Dict[str, torch.Tensor], device, total_steps: int = 1000, lr: float = 1e-4,
+                 min_lr: float = 1e-5, warmup_ratio: float = 0.003, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False):
+        self.engine, self.device = engine, torch.device(device)
+        nq, H = engine.latent_q.shape
+        sd = dict(s1_state_dict)
+        sd[LQ] = sd.get(LQ, engine.latent_q.float().view(1, nq, H).cpu())
+        self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,))
+        self.P = self.head.P
+        self.lq = LatentQueryGrad(engine)
+        self.total_steps, self.lr, self.min_lr = total_steps, lr, min_lr
+        self.warmup_steps = math.ceil(total_steps * warmup_ratio)
+        self.wd, self.max_norm, self.betas, self.eps = weight_decay, max_grad_norm, betas, eps
+        self.pg, self.zero2 = process_group, zero2
+        self.world = torch.distributed.get_world_size(process_group) if self._dist() else 1
+        self.rank = torch.distributed.get_rank(process_group) if self._dist() else 0
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.step_idx = 0
+
+    def _dist(self) -> bool:
+        return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    # ---------------------------------------------------------------------------------------------------------------- one step
+    def forward_backward(self, batch: dict, noise: Optional[torch.Tensor] = None, t_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """loss of the micro-batch; gradients are accumulated into the flat store (call several times for gradient accumulation)."""
+        e, dev = self.engine, self.device
+        ids = batch["input_ids"]
+        t_s_pos = np.asarray(batch["t_s_pos"], dtype=np.int64)
+        B = ids.shape[0]
+        nq = e.latent_q.shape[0]
+        S0 = int(t_s_pos.max())
+        prefix = ids[:, :S0].clone()
+        for b in range(B):           # right-pad rows of shorter samples: the <traj> tokens / padding behind t_s_pos are not part of the prefix
+            prefix[b, t_s_pos[b]:] = 0
+        pv = batch["pixel_values"].to(dev, torch.bfloat16)
+        state = e.prefill(prefix, pv, batch["image_grid_thw"], seq_lens=t_s_pos)
+        hq = self.lq.forward(state)
+        Tn = batch["traj_images"].shape[1]
+        if noise is None:            # internvla_n1.py:261-264 (the reference draws u on the CPU generator)
+            noise = torch.randn(B * Tn, *batch["traj_poses"].shape[2:], device=dev)
+        if t_index is None:
+            t_index = (torch.rand(B * Tn) * 1000).long()
+        loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index)
+        self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
+        return loss
+
+    def reduce_gradients(self):
+        """sum the flat gradient bucket over the data-parallel ranks (the 1 / world average is folded into the AdamW launch)."""
+        if self.world == 1:
+            return
+        if self.zero2:
+            lo, hi = shard_bounds(self.P.numel, self.world, self.rank)
+            per = shard_bounds(self.P.numel, self.world, 0)[1]
+            padded = self.P.g32 if per * self.world == self.P.numel else torch.cat([self.P.g32, self.P.g32.new_zeros(per * self.world - self.P.numel)])
+            out = torch.empty(per, dtype=torch.float32, device=self.device)
+            torch.distributed.reduce_scatter_tensor(out, padded, group=self.pg)
+            self.P.g32[lo:hi].copy_(out[: hi - lo])
+        else:
+            torch.distributed.all_reduce(self.P.g32, group=self.pg)
+
+    def optimizer_step(self) -> float:
+        lr = cosine_with_min_lr(self.step_idx, self.total_steps, self.warmup_steps, self.lr, self.min_lr)
+        P = self.P
+        if self.world > 1 and self.zero2:
+            lo, hi = shard_bounds(P.numel, self.world, self.rank)
+            parts = T.sumsq_parts(P.g32[lo:hi]) if hi > lo else torch.zeros(1024, dtype=torch.float32, device=self.device)
+            torch.distributed.all_reduce(parts, group=self.pg)          # global gradient norm from the shards' partial sums
+            P.step_count += 1
+            if hi > lo:
+                T.adamw(P.p32[lo:hi], P.g32[lo:hi], P.m[lo:hi], P.v[lo:hi], lr, self.betas[0], self.betas[1], self.eps, self.wd, P.step_count,
+                        p_bf16=P.p16[lo:hi], sumsq_parts=parts, max_norm=self.max_norm, grad_scale=1.0 / self.world, norm_out=self.grad_norm)
+            P.g32.zero_()
+            per = shard_bounds(P.numel, self.world, 0)[1]
+            for buf in (P.p32, P.p16):                                  # all-gather the updated master / working weights
+                full = torch.empty(per * self.world, dtype=buf.dtype, device=self.device)
+                mine = torch.zeros(per, dtype=buf.dtype, device=self.device)
+                mine[: hi - lo].copy_(buf[lo:hi])
+                torch.distributed.all_gather_into_tensor(full, mine, group=self.pg)
+                buf.copy_(full[: P.numel])
+            P.version += 1
+        else:
+            P.adamw_step(lr, self.betas, self.eps, self.wd, self.max_norm, grad_scale=1.0 / self.world, norm_out=self.grad_norm)
+        self.engine.latent_q.copy_(P.w16(LQ).view(self.engine.latent_q.shape))
+        self.step_idx += 1
+        return lr
+
+    def training_step(self, batch: dict, noise=None, t_index=None) -> torch.Tensor:
+        loss = self.forward_backward(batch, noise, t_index)
+        self.reduce_gradients()
+        self.optimizer_step()
+        return loss

@@ -1,0 +1,82 @@
+"""End-to-end SFT step (internnav_amd.trainer): collator-style batch -> frozen S2 prefill -> latent queries -> S1 loss -> gradients of the
+S1 modules AND of latent_queries (through the frozen LLM) -> fused AdamW; against torch autograd of the chained fp32 oracles."""
+import pytest
+import torch
+
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(cfg, B, T, seed=3):
+    inp = W.qwen_inputs(B, 2, seed=9, cfg=cfg)
+    g = torch.Generator().manual_seed(seed)
+    S = inp["input_ids"].shape[1]
+    lens = [S, S - 5][:B]
+    nq = cfg["n_query"]
+    ids = torch.zeros(B, S + nq, dtype=torch.long)
+    for b in range(B):
+        ids[b, : lens[b]] = inp["input_ids"][b, : lens[b]]
+        ids[b, lens[b]: lens[b] + nq] = cfg["traj_token_id"]
+    batch = dict(input_ids=ids, t_s_pos=lens, pixel_values=inp["pixel_values"], image_grid_thw=inp["grid_thw"],
+                 traj_images=torch.rand(B, T, 224, 224, 3, generator=g), traj_poses=torch.randn(B, T, 32, 3, generator=g),
+                 video_frame_num=torch.tensor([T, max(1, T - 1)][:B]))
+    noise = torch.randn(B * T, 32, 3, generator=g)
+    t_index = torch.randint(0, 1000, (B * T,), generator=g)
+    return batch, noise, t_index, inp
+
+
+def _oracle(sd_q0, sd_s0, cfg, batch, noise, t_index, inp, autocast):
+    from oracle import qwen_vl as o_q
+    from oracle import sft as o_sft
+
+    sd_q = {k: v.float() for k, v in sd_q0.items()}
+    lq = sd_q["model.latent_queries"].clone().requires_grad_(True)
+    sd_q["model.latent_queries"] = lq
+    sd_s = {k: v.clone().requires_grad_(True) for k, v in sd_s0.items()}
+    B = batch["input_ids"].shape[0]
+    per_pv, per_g = inp["pixel_values"].shape[0] // B, inp["grid_thw"].shape[0] // B
+    hs = []
+    with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+        for b in range(B):        # the oracle runs unpadded sequences one by one
+            L = batch["t_s_pos"][b]
+            hs.append(o_q.generate_latents(sd_q, cfg, batch["input_ids"][b:b + 1, :L], inp["pixel_values"][b * per_pv:(b + 1) * per_pv].float(),
+                                           inp["grid_thw"][b * per_g:(b + 1) * per_g]))
+        loss = o_sft.nextdit_sft_loss(sd_s, torch.cat(hs).float(), batch["traj_images"], batch["traj_poses"], batch["video_frame_num"], noise, t_index)
+    loss.backward()
+    return loss.item(), lq.grad.reshape(-1, lq.shape[-1]), {k: v.grad for k, v in sd_s.items() if v.grad is not None}
+
+
+def test_training_step_matches_chained_oracles(built_lib):
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+    from internnav_amd.trainer import LQ, InternVLAN1SftTrainer
+
+    cfg = W.QWEN_TEST_CFG
+    B, T = 2, 2
+    sd_q = W.qwen_state_dict(seed=11, cfg=cfg)
+    sd_s = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
+    batch, noise, t_index, inp = _batch(cfg, B, T)
+    eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+    tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100)
+    loss = tr.forward_backward(batch, noise, t_index)
+    l32, glq32, g32 = _oracle(sd_q, sd_s, cfg, batch, noise, t_index, inp, False)
+    l16, glq16, g16 = _oracle(sd_q, sd_s, cfg, batch, noise, t_index, inp, True)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    e_lq, y_lq = rel(tr.P.grad(LQ).cpu().view_as(glq32), glq32), rel(glq16, glq32)
+    errs = [rel(tr.P.grad(k).cpu().view_as(g), g) for k, g in g32.items() if g.norm() > 1e-6 * max(x.norm() for x in g32.values())]
+    yard = [rel(g16[k], g) for k, g in g32.items() if g.norm() > 1e-6 * max(x.norm() for x in g32.values())]
+    print(f"loss {loss.item():.5f} oracle {l32:.5f} (bf16 autocast {l16:.5f}); d latent_queries engine {e_lq:.3e} vs bf16 {y_lq:.3e}; "
+          f"S1 grads mean engine {sum(errs) / len(errs):.3e} vs bf16 {sum(yard) / len(yard):.3e}")
+    assert abs(loss.item() - l32) <= max(2 * abs(l16 - l32), 3e-3 * abs(l32))
+    assert e_lq <= 1.25 * y_lq + 1e-3
+    assert sum(errs) / len(errs) <= 1.1 * sum(yard) / len(yard)
+    # optimiser step: latent_queries move in the engine too, schedule advances, gradients are reset
+    before = eng.latent_q.clone()
+    tr.reduce_gradients()
+    lr = tr.optimizer_step()
+    assert lr == 0.0 and torch.equal(before, eng.latent_q)          # step 0 of the warm-up has lr 0 (HF schedule)
+    l2 = tr.training_step(batch, noise, t_index)
+    assert torch.isfinite(l2).all() and not torch.equal(before, eng.latent_q) and float(tr.P.g32.abs().max()) == 0.0
+    assert tr.step_idx == 2 and tr.grad_norm.item() > 0
