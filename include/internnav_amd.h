@@ -550,7 +550,12 @@ typedef struct ina_attn_bwd_args {
     const void* dO; void* dQ; void* dK; void* dV;
     float* lse; float* delta;
     int64_t dq_bs, dq_rs, dq_hs, dkv_bs, dkv_rs, dkv_hs;
-    int32_t kv_row0, _pad;
+    int32_t kv_row0;
+    int32_t nsplit;         /* > 1: split the keys of the dQ pass over nsplit workgroups per query tile (few query rows, long key axis):
+                             * dQ is then accumulated with f32 atomics into dq32 (dense [B, Lq, H, D], zeroed by the caller; dQ is not written) */
+    float* part;            /* f32 scratch [B, H, nsplit, 2, Lq] (nsplit > 1) */
+    float* dq32;
+    int32_t stage, _pad;    /* internal (set by the launcher) */
 } ina_attn_bwd_args;
 int ina_attention_bwd_bf16(const ina_attn_bwd_args* args, void* stream);
 

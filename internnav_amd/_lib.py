@@ -268,7 +268,7 @@ class GemmNnArgs(C.Structure):
 class AttnBwdArgs(C.Structure):
     _fields_ = [("f", AttnArgs), ("dO", c_void_p), ("dQ", c_void_p), ("dK", c_void_p), ("dV", c_void_p), ("lse", c_void_p), ("delta", c_void_p),
                 ("dq_bs", c_int64), ("dq_rs", c_int64), ("dq_hs", c_int64), ("dkv_bs", c_int64), ("dkv_rs", c_int64), ("dkv_hs", c_int64),
-                ("kv_row0", c_int32), ("_pad", c_int32)]
+                ("kv_row0", c_int32), ("nsplit", c_int32), ("part", c_void_p), ("dq32", c_void_p), ("stage", c_int32), ("_pad", c_int32)]
 
 
 SYMBOLS = {

@@ -85,7 +85,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
     };
 
     if constexpr (MODE == 0) {
-        const int qt0 = blockIdx.x * (NW * 16);
+        // few query rows against a long key axis (the latent-query rows of the LLM): the keys are split over gridDim.x / q-tiles workgroups.
+        //   stage 1: every split writes its partial softmax statistics (m, l);  stage 2: combine them, dS / dQ of the split's keys, fp32
+        //   atomics into dq32.  stage 0 (nsplit 1) = both passes over all keys in one launch, bf16 dQ stored directly.
+        const int nsplit = a.nsplit > 1 ? a.nsplit : 1;
+        const int qt0 = (blockIdx.x / nsplit) * (NW * 16), split = blockIdx.x % nsplit;
         if (qt0 >= len_q) return;
         const int q_abs = qt0 + wave * 16 + lq;
         const bool live = q_abs < len_q;
@@ -106,9 +110,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
 
         int kv_end = len_k;
         if (p.causal) kv_end = min(len_k, min(qt0 + NW * 16, len_q) + causal_shift);
+        int ks = 0, ke = kv_end;
+        if (nsplit > 1) {
+            const int nblk = (kv_end + CB - 1) / CB, per = (nblk + nsplit - 1) / nsplit;
+            ks = min(kv_end, split * per * CB);
+            ke = min(kv_end, ks + per * CB);
+        }
+        float* pm = a.part + (((size_t)b * p.H + h) * nsplit) * 2 * p.Lq;   // [split][m | l][Lq]
         // ---- pass 1: softmax statistics
         float m_run = -INFINITY, l_run = 0.f;
-        for (int kv0 = 0; kv0 < kv_end; kv0 += CB) {
+        if (a.stage != 2) {
+          for (int kv0 = ks; kv0 < ke; kv0 += CB) {
             __syncthreads();
             load_rows(Y1, K, p.k_rs, kv0, len_k);
             __syncthreads();
@@ -140,15 +152,34 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
             rs += __shfl_xor(rs, 32);
             l_run = l_run * exp2f(m_run - m_use) + rs;
             m_run = m_new;
+          }
+        }
+        if (a.stage == 1) {
+            if (live && g == 0) {
+                pm[(size_t)split * 2 * p.Lq + q_abs] = m_run;
+                pm[(size_t)split * 2 * p.Lq + p.Lq + q_abs] = l_run;
+                if (split == 0) dlt[q_abs] = dl;
+            }
+            return;
+        }
+        if (a.stage == 2) {
+            for (int sidx = 0; sidx < nsplit; ++sidx) {
+                const float m2 = live ? pm[(size_t)sidx * 2 * p.Lq + q_abs] : -INFINITY;
+                const float l2 = live ? pm[(size_t)sidx * 2 * p.Lq + p.Lq + q_abs] : 0.f;
+                const float m_new = fmaxf(m_run, m2);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                l_run = l_run * exp2f(m_run - m_use) + l2 * exp2f(m2 - m_use);
+                m_run = m_new;
+            }
         }
         const float lse2 = (l_run > 0.f) ? m_run + log2f(l_run) : INFINITY;
-        if (live && g == 0) { lse[q_abs] = lse2; dlt[q_abs] = dl; }
+        if (live && g == 0 && split == 0) { lse[q_abs] = lse2; dlt[q_abs] = dl; }
 
         // ---- pass 2: dQ
         f32x4 acc[NDT];
 #pragma unroll
         for (int i = 0; i < NDT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kv0 = 0; kv0 < kv_end; kv0 += CB) {
+        for (int kv0 = ks; kv0 < ke; kv0 += CB) {
             __syncthreads();
             load_rows(Y1, K, p.k_rs, kv0, len_k);
             load_rows(Y2, V, p.v_rs, kv0, len_k);
@@ -185,6 +216,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
             }
         }
         if (!live) return;
+        if (nsplit > 1) {
+            float* dq32 = a.dq32 + (((size_t)b * p.Lq + q_abs) * p.H + h) * p.D;      // dense f32 [B, Lq, H, D]
+#pragma unroll
+            for (int nt = 0; nt < NDT; ++nt) {
+                const int d = nt * 16 + g * 4;
+                if (d >= p.D) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dq32 + d + r, acc[nt][r]);
+            }
+            return;
+        }
         bf16* dQ = reinterpret_cast<bf16*>(a.dQ) + (size_t)b * a.dq_bs + (size_t)h * a.dq_hs + (size_t)q_abs * a.dq_rs;
 #pragma unroll
         for (int nt = 0; nt < NDT; ++nt) {
@@ -277,7 +319,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
 }
 
 template <int DP, int NW, int MODE>
-int launch_bwd(const AttnBwdArgs& a, int rows, hipStream_t stream) {
+int launch_bwd(const AttnBwdArgs& a_in, int rows, hipStream_t stream) {
+    AttnBwdArgs a = a_in;
+    const int nsplit = (MODE == 0 && a.nsplit > 1) ? a.nsplit : 1;
+    if (MODE == 0) a.nsplit = nsplit;
     constexpr size_t lds = (size_t)(2 * CB * (DP + 8) + (MODE == 1 ? 2 : 1) * DP * T_LD) * sizeof(bf16) + (MODE == 1 ? 2 * CB * sizeof(float) : 0);
     auto kern = attn_bwd_kernel<DP, NW, MODE>;
     static bool attr_done = false;
@@ -285,10 +330,18 @@ int launch_bwd(const AttnBwdArgs& a, int rows, hipStream_t stream) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    dim3 grid((rows + NW * 16 - 1) / (NW * 16), a.f.H, a.f.B);
-    const double fl = 2.0 * a.f.B * a.f.H * (double)a.f.Lq * a.f.Lk * DP * (MODE == 0 ? 4.0 : 4.0);
+    dim3 grid(((rows + NW * 16 - 1) / (NW * 16)) * nsplit, a.f.H, a.f.B);
+    const double fl = 2.0 * a.f.B * a.f.H * (double)a.f.Lq * a.f.Lk * DP * 4.0;
     InaProfScope prof(INA_PROF_ATTN, fl, 0.0, stream);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
+    if (nsplit > 1) {
+        a.stage = 1;
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
+        a.stage = 2;
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
+    } else {
+        a.stage = 0;
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, a);
+    }
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -303,6 +356,8 @@ int ina_launch_attention_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     INA_REQUIRE(p.D % 8 == 0 && p.D <= 128, "attention_bwd: head dim %d unsupported (multiple of 8, <= 128)", p.D);
     INA_REQUIRE(p.H % p.Hkv == 0, "attention_bwd: H %d not a multiple of Hkv %d", p.H, p.Hkv);
     INA_REQUIRE(a.kv_row0 >= -1 && a.kv_row0 <= p.Lk, "attention_bwd: kv_row0 %d out of range (-1 = the last Lq keys of every sequence)", a.kv_row0);
+    INA_REQUIRE(a.nsplit <= 1 || (a.part && a.dq32), "attention_bwd: key splits need the `part` statistics scratch and the zeroed f32 `dq32` accumulator");
+    INA_REQUIRE(a.nsplit <= 64, "attention_bwd: at most 64 key splits");
     const bool d64 = p.D <= 64;
     const bool small_q = p.Lq <= 32;
     if (a.dQ) {

@@ -85,10 +85,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs p, int nchunk, i
     const int r0 = grp * group_rows + chunk * CS_ROWS, r1 = min(grp * group_rows + group_rows, r0 + CS_ROWS);
     float acc = 0.f;
     if (c < p.C) {
-        for (int r = r0 + wave; r < r1; r += 4) {
-            float v = ldf(p.X, p.x_dt, (size_t)r * p.ldx + (size_t)c * p.x_cs);
-            if (p.X2) v *= ldf(p.X2, p.x2_dt, (size_t)r * p.ldx2 + (size_t)c * p.x2_cs);
-            acc += v;
+        // 8 independent loads in flight per lane: the loop is latency-bound otherwise (64 dependent round trips per workgroup)
+        constexpr int U = 8;
+        for (int r = r0 + wave; r < r1; r += 4 * U) {
+            float v[U], w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + 4 * u;
+                const bool ok = rr < r1;
+                v[u] = ok ? ldf(p.X, p.x_dt, (size_t)rr * p.ldx + (size_t)c * p.x_cs) : 0.f;
+                w[u] = (ok && p.X2) ? ldf(p.X2, p.x2_dt, (size_t)rr * p.ldx2 + (size_t)c * p.x2_cs) : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u] * w[u];
         }
     }
     red[wave][lane] = acc;
@@ -100,6 +109,60 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs p, int nchunk, i
             *o = (p.accumulate ? *o : 0.f) + s * p.scale;
         } else {
             p.partial[((size_t)grp * nchunk + chunk) * p.C + c] = s;
+        }
+    }
+}
+// 4 columns per lane (8- / 16-byte loads): the dense case of every bias / gain / modulation gradient. XB: X is bf16; X2M: 0 none, 1 bf16, 2 f32
+template <bool XB, int X2M>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(ColsumArgs p, int nchunk, int group_rows) {
+    __shared__ float red[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4, chunk = blockIdx.y, grp = blockIdx.z;
+    const int r0 = grp * group_rows + chunk * CS_ROWS, r1 = min(grp * group_rows + group_rows, r0 + CS_ROWS);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.C) {
+        constexpr int U = 4;
+        for (int r = r0 + wave; r < r1; r += 4 * U) {
+            f32x4 v[U], w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rr = r + 4 * u;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                w[u] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (rr < r1) {
+                    if constexpr (XB) {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.X) + (size_t)rr * p.ldx + c);
+                        v[u] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                    } else {
+                        v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.X) + (size_t)rr * p.ldx + c);
+                    }
+                    if constexpr (X2M == 1) {
+                        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.X2) + (size_t)rr * p.ldx2 + c);
+                        w[u] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+                    } else if constexpr (X2M == 2) {
+                        w[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.X2) + (size_t)rr * p.ldx2 + c);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += v[u][j] * w[u][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave][lane][j] = acc[j];
+    __syncthreads();
+    if (wave == 0 && c < p.C) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sm = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+            if (nchunk == 1) {
+                float* o = p.out + (size_t)grp * p.ldo + c + j;
+                *o = (p.accumulate ? *o : 0.f) + sm * p.scale;
+            } else {
+                p.partial[((size_t)grp * nchunk + chunk) * p.C + c + j] = sm;
+            }
         }
     }
 }
@@ -149,6 +212,85 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(NormBwdArgs p) {
         if (p.accumulate) dx += ldf(p.DX, p.dx_dt, o);
         stf(p.DX, p.dx_dt, o, dx);
         if (p.XHAT) reinterpret_cast<bf16*>(p.XHAT)[(size_t)row * p.ldxh + c] = (bf16)xh;
+    }
+}
+
+// 4 columns per lane, the row kept in registers (C <= 4096): one pass over x / dy instead of four
+template <bool XB, bool DYB>
+__global__ __launch_bounds__(256) void norm_bwd_vec_kernel(NormBwdArgs p) {
+    constexpr int MAXV = 16;                                   // 16 x 4 x 64 = 4096 columns
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    f32x4 xv[MAXV], gv[MAXV];
+    const int nv = (p.C / 4 + 63) / 64;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < nv && c < p.C) {
+            if constexpr (XB) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.X) + (size_t)row * p.ldx + c);
+                xv[i] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            } else {
+                xv[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.X) + (size_t)row * p.ldx + c);
+            }
+            if constexpr (DYB) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.DY) + (size_t)row * p.lddy + c);
+                gv[i] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            } else {
+                gv[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.DY) + (size_t)row * p.lddy + c);
+            }
+            if (p.gamma) {
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + c);
+                gv[i] *= gm;
+            }
+            s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+        }
+    }
+    const float mean = p.rms ? 0.f : wave_sum(s) / p.C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (i < nv && c < p.C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[i][j] -= mean; v += xv[i][j] * xv[i][j]; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / p.C + p.eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (i < nv && c < p.C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xv[i][j] *= rstd; s1 += gv[i][j]; s2 += gv[i][j] * xv[i][j]; }
+        }
+    }
+    s1 = p.rms ? 0.f : wave_sum(s1) / p.C;
+    s2 = wave_sum(s2) / p.C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (i < nv && c < p.C) {
+            f32x4 dx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dx[j] = rstd * (gv[i][j] - s1 - xv[i][j] * s2);
+            const size_t o = (size_t)row * p.lddx + c;
+            if (p.dx_dt == INA_DT_BF16) {
+                bf16* d = reinterpret_cast<bf16*>(p.DX) + o;
+                if (p.accumulate) { const bf16x4 t = *reinterpret_cast<const bf16x4*>(d); for (int j = 0; j < 4; ++j) dx[j] += (float)t[j]; }
+                *reinterpret_cast<bf16x4*>(d) = bf16x4{(bf16)dx[0], (bf16)dx[1], (bf16)dx[2], (bf16)dx[3]};
+            } else {
+                float* d = reinterpret_cast<float*>(p.DX) + o;
+                if (p.accumulate) dx += *reinterpret_cast<const f32x4*>(d);
+                *reinterpret_cast<f32x4*>(d) = dx;
+            }
+            if (p.XHAT) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.XHAT) + (size_t)row * p.ldxh + c) =
+                            bf16x4{(bf16)xv[i][0], (bf16)xv[i][1], (bf16)xv[i][2], (bf16)xv[i][3]};
+        }
     }
 }
 
@@ -328,7 +470,20 @@ int ina_launch_colsum(const ColsumArgs& p_in, hipStream_t stream) {
     INA_REQUIRE(nchunk == 1 || (p.partial && p.partial_elems >= (int64_t)groups * nchunk * p.C),
                 "colsum: needs a partial buffer of %lld floats", (long long)groups * nchunk * p.C);
     InaProfScope prof(INA_PROF_ELEMENTWISE, 0.0, 0.0, stream);
-    hipLaunchKernelGGL(colsum_kernel, dim3((p.C + 63) / 64, nchunk, groups), dim3(256), 0, stream, p, nchunk, group_rows);
+    const size_t xes = p.x_dt == INA_DT_BF16 ? 2 : 4, x2es = p.x2_dt == INA_DT_BF16 ? 2 : 4;
+    const bool vec = p.x_cs == 1 && p.out_cs == 1 && p.C % 4 == 0 && p.ldx % 4 == 0 && ((uintptr_t)p.X % (4 * xes)) == 0 &&
+                     (!p.X2 || (p.x2_cs == 1 && p.ldx2 % 4 == 0 && ((uintptr_t)p.X2 % (4 * x2es)) == 0));
+    if (vec) {
+        const dim3 grid((p.C + 255) / 256, nchunk, groups);
+        const int x2m = !p.X2 ? 0 : (p.x2_dt == INA_DT_BF16 ? 1 : 2);
+        const bool xb = p.x_dt == INA_DT_BF16;
+#define INA_CS(XB, M) hipLaunchKernelGGL((colsum_vec_kernel<XB, M>), grid, dim3(256), 0, stream, p, nchunk, group_rows)
+        if (xb) { if (x2m == 0) INA_CS(true, 0); else if (x2m == 1) INA_CS(true, 1); else INA_CS(true, 2); }
+        else { if (x2m == 0) INA_CS(false, 0); else if (x2m == 1) INA_CS(false, 1); else INA_CS(false, 2); }
+#undef INA_CS
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3((p.C + 63) / 64, nchunk, groups), dim3(256), 0, stream, p, nchunk, group_rows);
+    }
     if (nchunk > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((p.C + 255) / 256, groups), dim3(256), 0, stream, p, nchunk);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
@@ -337,7 +492,20 @@ int ina_launch_colsum(const ColsumArgs& p_in, hipStream_t stream) {
 int ina_launch_norm_bwd(const NormBwdArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.rows > 0 && p.C > 0 && p.X && p.DY && p.DX, "norm_bwd: empty problem or null tensor");
     InaProfScope prof(INA_PROF_NORM, 0.0, 0.0, stream);
-    hipLaunchKernelGGL(norm_bwd_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, stream, p);
+    const size_t xes = p.x_dt == INA_DT_BF16 ? 2 : 4, des = p.dy_dt == INA_DT_BF16 ? 2 : 4, oes = p.dx_dt == INA_DT_BF16 ? 2 : 4;
+    const bool vec = p.C % 4 == 0 && p.C <= 4096 && p.ldx % 4 == 0 && p.lddy % 4 == 0 && p.lddx % 4 == 0 && (!p.XHAT || p.ldxh % 4 == 0) &&
+                     ((uintptr_t)p.X % (4 * xes)) == 0 && ((uintptr_t)p.DY % (4 * des)) == 0 && ((uintptr_t)p.DX % (4 * oes)) == 0 &&
+                     (!p.XHAT || ((uintptr_t)p.XHAT % 8) == 0) && (!p.gamma || ((uintptr_t)p.gamma % 16) == 0);
+    const dim3 grid((p.rows + 3) / 4);
+    if (vec) {
+        const bool xb = p.x_dt == INA_DT_BF16, db = p.dy_dt == INA_DT_BF16;
+        if (xb && db) hipLaunchKernelGGL((norm_bwd_vec_kernel<true, true>), grid, dim3(256), 0, stream, p);
+        else if (xb) hipLaunchKernelGGL((norm_bwd_vec_kernel<true, false>), grid, dim3(256), 0, stream, p);
+        else if (db) hipLaunchKernelGGL((norm_bwd_vec_kernel<false, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((norm_bwd_vec_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(norm_bwd_kernel, grid, dim3(256), 0, stream, p);
+    }
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -284,7 +284,8 @@ def gemm_nn(x, w, out=None, out_dtype=torch.float32, splits: Optional[int] = Non
     return affine(red, out=out)
 
 
-def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=1, dq=None, dk=None, dv=None, kv_row0=0, need_dkv=True):
+def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=1, dq=None, dk=None, dv=None, kv_row0=0, need_dkv=True,
+                  nsplit: Optional[int] = None):
     """backward of ops.attention (dense): q/o/do [B, Lq, H, D], k/v [Bk, Lk, Hkv, D] (last dim contiguous, other strides free).
     Returns (dq [B,Lq,H,D], dk, dv [B, Lk - kv_row0, H, D]) - dk / dv are per QUERY head (sum GQA groups outside)."""
     assert q.dtype == k.dtype == v.dtype == o.dtype == do.dtype == torch.bfloat16
@@ -313,6 +314,13 @@ def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=
     a.dq_bs, a.dq_rs, a.dq_hs = dq.stride(0), dq.stride(1), dq.stride(2)
     stats = torch.empty(2, B, H, Lq, dtype=torch.float32, device=q.device)
     a.lse, a.delta = stats[0].data_ptr(), stats[1].data_ptr()
+    if nsplit is None:      # few query rows against a long key axis: spread the keys over the chip
+        nsplit = min(32, (Lk + 127) // 128) if (Lq <= 32 and Lk >= 512) else 1
+    dq32 = None
+    if nsplit > 1:
+        part = torch.empty(B, H, nsplit, 2, Lq, dtype=torch.float32, device=q.device)
+        dq32 = torch.zeros(B, Lq, H, D, dtype=torch.float32, device=q.device)
+        a.nsplit, a.part, a.dq32 = nsplit, part.data_ptr(), dq32.data_ptr()
     if need_dkv:
         rows = min(Lq, Lk) if kv_row0 < 0 else Lk - kv_row0
         if dk is None:
@@ -324,4 +332,6 @@ def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=
         a.dkv_bs, a.dkv_rs, a.dkv_hs = dk.stride(0), dk.stride(1), dk.stride(2)
         a.kv_row0 = kv_row0
     _lib.check(_lib.lib().ina_attention_bwd_bf16(C.byref(a), _stream()), "attention_bwd_bf16")
+    if dq32 is not None:
+        dq.copy_(dq32)
     return dq, dk, dv
