@@ -75,6 +75,67 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
     }
 }
 
+__device__ __forceinline__ f32x4 ld4(const void* p, int dt, size_t i) {
+    if (dt == INA_DT_BF16) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + i);
+        return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    }
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ void st4(void* p, int dt, size_t i, f32x4 v) {
+    if (dt == INA_DT_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p) + i) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + i) = v;
+}
+// the same operations on 4 consecutive columns per thread (8- / 16-byte accesses) when every operand allows it
+__global__ __launch_bounds__(256) void ew_vec_kernel(EwArgs p) {
+    const int C4 = p.C / 4;
+    const size_t n = (size_t)p.rows * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / C4), c = (int)(i % C4) * 4;
+        f32x4 y = f32x4{0.f, 0.f, 0.f, 0.f}, y2 = y;
+        const f32x4 av = ld4(p.A, p.a_dt, (size_t)r * p.lda + c);
+        switch (p.op) {
+            case INA_EW_AFFINE: {
+                y = av;
+                if (p.S) {
+                    const f32x4 sv = ld4(p.S, p.s_dt, (size_t)(r / p.s_div) * p.lds + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] *= scale_fn(sv[j], p.s_f);
+                }
+                if (p.B) y += ld4(p.B, p.b_dt, (size_t)r * p.ldb + c);
+                if (p.tab) y += *reinterpret_cast<const f32x4*>(p.tab + (size_t)(r % p.tab_mod) * p.C + c);
+                break;
+            }
+            case INA_EW_ACT_FWD:
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = ina_act(av[j], p.act);
+                break;
+            case INA_EW_ACT_BWD: {
+                const f32x4 bv = ld4(p.B, p.b_dt, (size_t)r * p.ldb + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = bv[j] * act_grad(av[j], p.act);
+                break;
+            }
+            case INA_EW_GLU_FWD: {
+                const f32x4 bv = ld4(p.B, p.b_dt, (size_t)r * p.ldb + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = ina_silu(av[j]) * bv[j];
+                break;
+            }
+            case INA_EW_GLU_BWD: {
+                const f32x4 bv = ld4(p.B, p.b_dt, (size_t)r * p.ldb + c), dy = ld4(p.D, p.d_dt, (size_t)r * p.ldd + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { y[j] = dy[j] * bv[j] * act_grad(av[j], INA_ACT_SILU); y2[j] = dy[j] * ina_silu(av[j]); }
+                break;
+            }
+            default: break;
+        }
+        if (p.accumulate) y += ld4(p.Y, p.y_dt, (size_t)r * p.ldy + c);
+        st4(p.Y, p.y_dt, (size_t)r * p.ldy + c, y);
+        if (p.op == INA_EW_GLU_BWD) st4(p.Y2, p.y2_dt, (size_t)r * p.ldy2 + c, y2);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- column sums
 // out[g, c] (+)= scale * sum over the rows of group g of X[r, c] * X2[r, c]; chunks of 256 rows per workgroup, deterministic two-stage
 constexpr int CS_ROWS = 256;
@@ -449,10 +510,14 @@ int ina_launch_ew(const EwArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.op != INA_EW_GLU_BWD || (p.D && p.Y2), "ew: glu backward needs dy and the second output");
     INA_REQUIRE(!p.S || p.s_div > 0, "ew: s_div must be positive");
     INA_REQUIRE(!p.tab || p.tab_mod > 0, "ew: tab_mod must be positive");
-    const size_t n = (size_t)p.rows * p.C;
+    auto ok4 = [](const void* ptr, int dt, int ld) { return !ptr || (ld % 4 == 0 && ((uintptr_t)ptr % (dt == INA_DT_BF16 ? 8 : 16)) == 0); };
+    const bool vec = p.C % 4 == 0 && ok4(p.A, p.a_dt, p.lda) && ok4(p.B, p.b_dt, p.ldb) && ok4(p.D, p.d_dt, p.ldd) && ok4(p.S, p.s_dt, p.lds) &&
+                     ok4(p.Y, p.y_dt, p.ldy) && ok4(p.Y2, p.y2_dt, p.ldy2) && ok4(p.tab, INA_DT_F32, 4);
+    const size_t n = vec ? (size_t)p.rows * (p.C / 4) : (size_t)p.rows * p.C;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     InaProfScope prof(INA_PROF_ELEMENTWISE, 0.0, 0.0, stream);
-    hipLaunchKernelGGL(ew_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    if (vec) hipLaunchKernelGGL(ew_vec_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ew_kernel, dim3(blocks), dim3(256), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -34,6 +34,9 @@ def test_ew_affine_act_glu(dev):
         assert _rel(out, ref) < 1e-6
         outb = T.affine(x.bfloat16(), scale=s, s_div=div, s_f=f, base=base, out_dtype=torch.float32)
         assert _rel(outb, x.bfloat16().float() * fn(s).repeat_interleave(div, 0) + base) < 1e-6
+    # odd widths / unaligned column views take the scalar kernel
+    xv, bv = x[:, 1:7], base[:, 3:9]
+    assert _rel(T.affine(xv, scale=s[:, 2:8], s_div=div, s_f="tanh", base=bv), xv * torch.tanh(s[:, 2:8]).repeat_interleave(div, 0) + bv) < 1e-6
     acc = base.clone()
     T.affine(x, out=acc, accumulate=True)
     assert _rel(acc, base + x) < 1e-6
