@@ -49,3 +49,59 @@ def test_action_all_gather_over_rccl():
             exp[:, 0] = k
             assert torch.equal(g[k], exp)                      # rank-major, bit-equal integers on every rank
         assert m == [float(v + 10 * k) for k in range(world) for v in range(3 + k)]
+
+
+def _sft_worker(rank, world, port, q):
+    """the SFT trainer's flat-bucket reduction + fused AdamW: ZeRO-2 (reduce-scatter, sharded update, all-gather) must land on exactly the
+    all-reduce (replicated update) weights, and every rank must hold the same ones."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", device_id=dev)
+    from internnav_amd.sft import ParamStore
+    from internnav_amd.trainer import InternVLAN1SftTrainer
+
+    out = []
+    for zero2 in (False, True):
+        g = torch.Generator().manual_seed(0)
+        P = ParamStore({"a": torch.randn(3000, 7, generator=g), "b": torch.randn(5000, generator=g), "latent_queries": torch.randn(1, 4, 64, generator=g)}, dev)
+        tr = object.__new__(InternVLAN1SftTrainer)
+        tr.P, tr.world, tr.rank, tr.pg, tr.zero2, tr.device = P, world, rank, None, zero2, dev
+        tr.total_steps, tr.lr, tr.min_lr, tr.warmup_steps, tr.wd, tr.max_norm, tr.betas, tr.eps = 100, 1e-2, 1e-3, 0, 0.01, 1.0, (0.9, 0.999), 1e-8
+        tr.grad_norm, tr.step_idx = torch.zeros(1, device=dev), 0
+
+        class _E:
+            latent_q = torch.zeros(4, 64, dtype=torch.bfloat16, device=dev)
+        tr.engine = _E()
+        for step in range(3):
+            gg = torch.Generator().manual_seed(100 * step + rank)
+            P.g32[: 3000 * 7 + 5000 + 8].copy_(torch.randn(3000 * 7 + 5000 + 8, generator=gg))
+            tr.reduce_gradients()
+            tr.optimizer_step()
+        out.append((P.p32.cpu().clone(), tr.grad_norm.item(), tr.engine.latent_q.float().cpu().clone()))
+    q.put((rank, out[0][0].tolist()[:64], float((out[0][0] - out[1][0]).abs().max()), out[0][1], out[1][1], float((out[0][2] - out[1][2]).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on one node (RCCL over xGMI)")
+def test_sft_flat_bucket_zero2_equals_all_reduce_over_rccl():
+    import torch.multiprocessing as mp
+
+    world = min(torch.cuda.device_count(), 8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_sft_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in ps:
+        p.join(120)
+    for r, head, diff, n_ar, n_z2, dlq in res:
+        assert head == res[0][1]                       # identical weights on every rank
+        assert diff <= 1e-6 and dlq == 0.0             # sharded update == replicated update
+        assert abs(n_ar - n_z2) <= 1e-4 * n_ar and n_ar == res[0][3]
