@@ -40,7 +40,9 @@ class ParamStore:
 
     ALIGN = 8
 
-    def __init__(self, tensors: Dict[str, torch.Tensor], device):
+    def __init__(self, tensors: Dict[str, torch.Tensor], device, trainable: bool = True):
+        """trainable=False: weights only (fp32 + bf16 views under the same names), no gradient / moment buffers - frozen modules."""
+        self.trainable = trainable
         self.index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
         for k, t in tensors.items():
@@ -51,9 +53,10 @@ class ParamStore:
         for k, t in tensors.items():
             o, _ = self.index[k]
             self.p32[o:o + t.numel()].copy_(t.detach().reshape(-1).to(device=device, dtype=F32))
-        self.g32 = torch.zeros(self.numel, dtype=F32, device=device)
-        self.m = torch.zeros(self.numel, dtype=F32, device=device)
-        self.v = torch.zeros(self.numel, dtype=F32, device=device)
+        if trainable:
+            self.g32 = torch.zeros(self.numel, dtype=F32, device=device)
+            self.m = torch.zeros(self.numel, dtype=F32, device=device)
+            self.v = torch.zeros(self.numel, dtype=F32, device=device)
         self.p16 = self.p32.to(BF)
         self.step_count = 0
         self.version = 0          # bumped by every optimiser step: transposed weight copies are cached per version
@@ -103,27 +106,54 @@ class Var:
 
 
 def _acc(var: Var, g: torch.Tensor, own: bool = True):
-    """var.g += g. `own` = the caller hands the buffer over (it may be updated in place later)."""
+    """var.g += g. `own` = the caller hands the buffer over (it may be updated in place later). The first contribution is kept as it
+    comes (bf16 or f32); from the second one on the sum lives in fp32 - a value with many consumers (the condition tokens of 16 decoder
+    layers, the adaLN embedding of 12 DiT blocks) would otherwise round its gradient to bf16 after every addition."""
     if not var.req:
         return
     assert g.shape == var.v.shape, f"gradient {tuple(g.shape)} for a value {tuple(var.v.shape)}"
-    if g.dtype != var.v.dtype:
-        g, own = T.affine(g, out_dtype=var.v.dtype), True
     if var.g is None:
         var.g, var.own = g, own
-    elif var.own:
+    elif var.own and var.g.dtype == F32:
         T.affine(g, out=var.g, accumulate=True)
     else:
-        var.g, var.own = T.affine(g, base=var.g), True
+        var.g, var.own = T.affine(g, base=var.g, out_dtype=F32), True
 
 
 def _bf(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == BF else T.affine(t, out_dtype=BF)
 
 
+class _Params:
+    """name -> views over a trainable store and an optional frozen one; `trains(name)` says whether the tensor gets a gradient."""
+
+    def __init__(self, P: ParamStore, frozen: Optional[ParamStore] = None):
+        self.P, self.F = P, frozen
+        self.version = 0
+
+    def _s(self, name):
+        if name in self.P.index:
+            return self.P
+        assert self.F is not None and name in self.F.index, f"unknown parameter {name}"
+        return self.F
+
+    def trains(self, name) -> bool:
+        return name in self.P.index
+
+    def w16(self, name):
+        return self._s(name).w16(name)
+
+    def w32(self, name):
+        return self._s(name).w32(name)
+
+    def grad(self, name):
+        return self.P.grad(name)
+
+
 class Tape:
-    def __init__(self, P: ParamStore):
-        self.P = P
+    def __init__(self, P: ParamStore, frozen: Optional[ParamStore] = None):
+        self.store = P
+        self.P = _Params(P, frozen)
         self.nodes: List[Callable[[], None]] = []
         self._wt: Dict[Tuple[str, Optional[Tuple[int, int]]], Tuple[int, torch.Tensor]] = {}
 
@@ -139,8 +169,8 @@ class Tape:
     def _w_transposed(self, w, rows):
         key = (w, rows)
         hit = self._wt.get(key)
-        if hit is None or hit[0] != self.P.version:
-            hit = (self.P.version, T.transpose(self._rows(self.P.w16(w), rows)))
+        if hit is None or hit[0] != self.store.version:
+            hit = (self.store.version, T.transpose(self._rows(self.P.w16(w), rows)))
             self._wt[key] = hit
         return hit[1]
 
@@ -155,7 +185,11 @@ class Tape:
         xb = _bf(x.v)
         if out_dtype is None:
             out_dtype = residual.v.dtype if residual is not None else BF
-        y = Var(ops.linear(xb, W, bias=bias, residual=None if residual is None else residual.v, out_dtype=out_dtype))
+        train = P.trains(w)
+        y = Var(ops.linear(xb, W, bias=bias, residual=None if residual is None else residual.v, out_dtype=out_dtype),
+                req=train or x.req or (residual is not None and residual.req))
+        if not y.req:
+            return y
 
         def bwd():
             dy = y.g
@@ -167,10 +201,11 @@ class Tape:
             if x.req:
                 assert W.shape[0] % 8 == 0, "dX GEMM needs an output width that is a multiple of 8"
                 _acc(x, ops.linear(dyb, self._w_transposed(w, rows), out_dtype=x.v.dtype))
-            gW = self._rows(P.grad(w), rows)
-            ops.linear(T.transpose(dyb), T.transpose(xb), out=gW, residual=gW)
-            if b:
-                T.colsum(dy, out=self._rows(P.grad(b), rows), accumulate=True)
+            if train:
+                gW = self._rows(P.grad(w), rows)
+                ops.linear(T.transpose(dyb), T.transpose(xb), out=gW, residual=gW)
+                if b:
+                    T.colsum(dy, out=self._rows(P.grad(b), rows), accumulate=True)
         self.nodes.append(bwd)
         return y
 
@@ -178,28 +213,33 @@ class Tape:
         P = self.P
         g32 = P.w32(gamma) if gamma else None
         b32 = P.w32(beta) if beta else None
+        train = bool(gamma) and P.trains(gamma)
         if out_dtype == BF:
-            y = Var(ops.norm(x.v, g32, b32, eps=eps, rms=rms))
+            y = Var(ops.norm(x.v, g32, b32, eps=eps, rms=rms), req=train or x.req)
         else:
             o = torch.empty(x.v.shape, dtype=F32, device=x.v.device)
             ops.norm(x.v, g32, b32, eps=eps, rms=rms, out32=o)
-            y = Var(o)
+            y = Var(o, req=train or x.req)
+        if not y.req:
+            return y
 
         def bwd():
             dy = y.g
             if dy is None:
                 return
-            dx, xhat = T.norm_bwd(x.v, dy, g32, eps, rms, want_xhat=gamma is not None, dx_dtype=x.v.dtype)
-            if gamma:
+            dx, xhat = T.norm_bwd(x.v, dy, g32, eps, rms, want_xhat=train, dx_dtype=x.v.dtype)
+            if train:
                 T.colsum(dy, xhat, out=P.grad(gamma), accumulate=True)
-            if beta:
-                T.colsum(dy, out=P.grad(beta), accumulate=True)
+                if beta:
+                    T.colsum(dy, out=P.grad(beta), accumulate=True)
             _acc(x, dx)
         self.nodes.append(bwd)
         return y
 
     def act(self, x: Var, kind: str) -> Var:
-        y = Var(T.act_fwd(x.v, kind))
+        y = Var(T.act_fwd(x.v, kind), req=x.req)
+        if not y.req:
+            return y
 
         def bwd():
             if y.g is not None:
@@ -220,7 +260,7 @@ class Tape:
         return y
 
     def add(self, a: Var, b: Var) -> Var:
-        y = Var(T.affine(a.v, base=b.v, out_dtype=F32 if F32 in (a.v.dtype, b.v.dtype) else BF))
+        y = Var(T.affine(a.v, base=b.v, out_dtype=F32 if F32 in (a.v.dtype, b.v.dtype) else BF), req=a.req or b.req)
 
         def bwd():
             if y.g is not None:
@@ -260,8 +300,11 @@ class Tape:
         else:
             gvec = P.w32(gname).view(1, Cd)
         rows = x.v.shape[0]
+        train = P.trains(gname)
         y = Var(T.affine(x.v, scale=gvec, s_div=rows, base=None if base is None else base.v,
-                         out_dtype=base.v.dtype if base is not None else x.v.dtype))
+                         out_dtype=base.v.dtype if base is not None else x.v.dtype), req=train or x.req or (base is not None and base.req))
+        if not y.req:
+            return y
 
         def bwd():
             dy = y.g
@@ -269,7 +312,10 @@ class Tape:
                 return
             if base is not None:
                 _acc(base, dy, own=False)
-            _acc(x, T.affine(dy, scale=gvec, s_div=rows, out_dtype=x.v.dtype))
+            if x.req:
+                _acc(x, T.affine(dy, scale=gvec, s_div=rows, out_dtype=x.v.dtype))
+            if not train:
+                return
             dg = T.colsum(dy, x.v).view(-1)
             if tanh_heads:
                 g = P.w32(gname)
@@ -282,20 +328,26 @@ class Tape:
     def add_table(self, x: Var, tname: str, mod: int, out_dtype=None) -> Var:
         """y = x + table[r % mod]  (learned positional embeddings, broadcast over the batch)."""
         P = self.P
-        tab = P.w32(tname)[:mod].contiguous()
-        y = Var(T.affine(x.v, tab=tab, out_dtype=out_dtype or x.v.dtype))
+        Cd = x.v.shape[1]
+        tab = P.w32(tname).reshape(-1, Cd)[:mod].contiguous()
+        train = P.trains(tname)
+        y = Var(T.affine(x.v, tab=tab, out_dtype=out_dtype or x.v.dtype), req=train or x.req)
+        if not y.req:
+            return y
 
         def bwd():
             dy = y.g
             if dy is None:
                 return
             _acc(x, dy, own=False)
-            n = dy.shape[0] // mod
-            T.colsum(dy.contiguous().view(n, -1), out=P.grad(tname)[:mod].view(1, -1), accumulate=True)
+            if train:
+                n = dy.shape[0] // mod
+                T.colsum(dy.contiguous().view(n, -1), out=P.grad(tname).view(-1, Cd)[:mod].view(1, -1), accumulate=True)
         self.nodes.append(bwd)
         return y
 
-    def attention(self, q: Tuple[Var, int], k: Tuple[Var, int], v: Tuple[Var, int], B: int, Lq: int, Lk: int, H: int, D: int) -> Var:
+    def attention(self, q: Tuple[Var, int], k: Tuple[Var, int], v: Tuple[Var, int], B: int, Lq: int, Lk: int, H: int, D: int,
+                  causal: bool = False) -> Var:
         """softmax(q k^T / sqrt(D)) v; q / k / v are (source, first column) pairs: column blocks of width H*D of 2-D activations
         (a packed qkv projection, or separate ones)."""
         Cd = H * D
@@ -304,13 +356,16 @@ class Tape:
             var, c0 = src
             return var.v[:, c0:c0 + Cd].unflatten(0, (B, L)).unflatten(-1, (H, D))
         qv, kv, vv = view(q, Lq), view(k, Lk), view(v, Lk)
-        o = ops.attention(qv, kv, vv)
-        y = Var(o.view(B * Lq, Cd))
+        o = ops.attention(qv, kv, vv, causal=causal)
+        y = Var(o.view(B * Lq, Cd), req=q[0].req or k[0].req or v[0].req)
+        if not y.req:
+            return y
 
         def bwd():
             do = y.g
             if do is None:
                 return
+            do = _bf(do)
             if not do.is_contiguous():
                 do = do.contiguous()
             bufs: Dict[int, torch.Tensor] = {}
@@ -323,7 +378,7 @@ class Tape:
             def gview(src, L):
                 var, c0 = src
                 return bufs[id(var)][:, c0:c0 + Cd].unflatten(0, (B, L)).unflatten(-1, (H, D))
-            T.attention_bwd(qv, kv, vv, o, do.view(B, Lq, H, D), dq=gview(q, Lq), dk=gview(k, Lk), dv=gview(v, Lk))
+            T.attention_bwd(qv, kv, vv, o, do.view(B, Lq, H, D), causal=causal, dq=gview(q, Lq), dk=gview(k, Lk), dv=gview(v, Lk))
             done = set()
             for var, _ in (q, k, v):
                 if id(var) not in done:
@@ -339,8 +394,8 @@ class Tape:
         def bwd():
             if y.g is None or not x.req:
                 return
-            if x.g is None or not x.own:
-                full = torch.zeros(x.v.shape, dtype=x.v.dtype, device=x.v.device)
+            if x.g is None or not x.own or x.g.dtype != F32:
+                full = torch.zeros(x.v.shape, dtype=F32, device=x.v.device)
                 if x.g is not None:
                     T.affine(x.g, out=full)
                 x.g, x.own = full, True
@@ -423,8 +478,10 @@ class DinoTrain:
 
     D, DEPTH, HEADS, PATCH, KPAD = 384, 12, 6, 14, 592
 
-    def __init__(self, P: ParamStore, prefix: str, device, img_size: int = 224):
-        self.P, self.p = P, prefix
+    def __init__(self, prefix: str, device, img_size: int = 224, mean=RESNET_MEAN, std=RESNET_STD, channels: int = 3):
+        """mean / std: input normalisation fused into the im2col kernel; channels = 1: a depth map replicated to 3 channels
+        (navdp_backbone.py:274-279). Parameters are looked up on the tape (trainable or frozen store)."""
+        self.p, self.mean, self.std, self.channels = prefix, mean, std, channels
         g = img_size // self.PATCH
         self.L = g * g
         # the interpolation is linear in pos_embed: recover its sparse matrix once by resampling an identity basis on the host
@@ -450,14 +507,16 @@ class DinoTrain:
         return idx.to(device), coef.to(device)
 
     def forward(self, tape: Tape, frames: torch.Tensor) -> Var:
-        """frames [n, 224, 224, 3] in 0..1 -> Var [n * 256, 384] bf16 patch tokens after the final LayerNorm (cls dropped)."""
-        P, p, D, L = self.P, self.p, self.D, self.L
+        """frames [n, 224, 224, C] -> Var [n * 256, 384] bf16 patch tokens after the final LayerNorm (cls dropped)."""
+        P, p, D, L = tape.P, self.p, self.D, self.L
         n = frames.shape[0]
         dev = frames.device
         Tt = L + 1
+        assert frames.shape[-1] == self.channels
         patches = torch.empty(n * L, self.KPAD, dtype=BF, device=dev)
-        ops.patchify(frames.contiguous(), patches, RESNET_MEAN, RESNET_STD, self.PATCH)
+        ops.patchify(frames.contiguous(), patches, self.mean, self.std, self.PATCH)
         wname = p + "patch_embed.proj.weight"
+        train = P.trains(wname)
         wpad = torch.zeros(D, self.KPAD, dtype=BF, device=dev)
         wpad[:, :588] = P.w16(wname).view(D, 588)
         pos_src = P.w32(p + "pos_embed").view(-1, D)                                   # [1370, 384]
@@ -465,7 +524,7 @@ class DinoTrain:
         x = torch.empty(n, Tt, D, dtype=F32, device=dev)
         ops.linear(patches.view(n, L, self.KPAD), wpad, bias=P.w32(p + "patch_embed.proj.bias"), residual=pos, out=x[:, 1:, :], batched=True)
         x[:, 0, :] = P.w32(p + "cls_token").view(1, D) + pos_src[:1]
-        xv = x_embed = Var(x.view(n * Tt, D))
+        xv = x_embed = Var(x.view(n * Tt, D), req=train)
 
         def bwd_embed():
             dx = x_embed.g
@@ -482,7 +541,8 @@ class DinoTrain:
             gpos[:1] += dpos_all[:1]
             P.grad(p + "cls_token").view(1, D).add_(dpos_all[:1])
             T.sparse_rows(dpos_all[1:].contiguous(), self.bwd_idx, self.bwd_coef, out=gpos[1:], accumulate=True)
-        tape.nodes.append(bwd_embed)
+        if train:
+            tape.nodes.append(bwd_embed)
 
         for i in range(self.DEPTH):
             b = f"{p}blocks.{i}"
@@ -497,7 +557,7 @@ class DinoTrain:
             xv = tape.col_scale(y, b + ".ls2.gamma", base=xv)
         out = tape.norm(xv, p + "norm.weight", p + "norm.bias", 1e-6)
         # drop the cls token
-        tok = Var(out.v.view(n, Tt, D)[:, 1:, :].reshape(n * L, D))
+        tok = Var(out.v.view(n, Tt, D)[:, 1:, :].reshape(n * L, D), req=out.req)
 
         def bwd_drop():
             if tok.g is None:
@@ -510,16 +570,17 @@ class DinoTrain:
 
 
 # ---------------------------------------------------------------------------------------------------------------- nn.Transformer layers
-def _mha(tape: Tape, xq: Var, xkv: Var, p: str, B: int, Lq: int, Lk: int, H: int, d: int, residual: Optional[Var] = None) -> Var:
+def _mha(tape: Tape, xq: Var, xkv: Var, p: str, B: int, Lq: int, Lk: int, H: int, d: int, residual: Optional[Var] = None,
+         causal: bool = False) -> Var:
     """nn.MultiheadAttention(batch_first=True): packed in_proj, SDPA, out_proj (+ the residual of the surrounding layer, fp32 sum)."""
     w, b = p + ".in_proj_weight", p + ".in_proj_bias"
     if xq is xkv:
         qkv = tape.linear(xq, w, b)
-        att = tape.attention((qkv, 0), (qkv, d), (qkv, 2 * d), B, Lq, Lk, H, d // H)
+        att = tape.attention((qkv, 0), (qkv, d), (qkv, 2 * d), B, Lq, Lk, H, d // H, causal=causal)
     else:
         qp = tape.linear(xq, w, b, rows=(0, d))
         kvp = tape.linear(xkv, w, b, rows=(d, 3 * d))
-        att = tape.attention((qp, 0), (kvp, 0), (kvp, d), B, Lq, Lk, H, d // H)
+        att = tape.attention((qp, 0), (kvp, 0), (kvp, d), B, Lq, Lk, H, d // H, causal=causal)
     return tape.linear(att, p + ".out_proj.weight", p + ".out_proj.bias", residual=residual, out_dtype=F32 if residual is not None else None)
 
 
@@ -616,7 +677,7 @@ class NextDiTSftHead:
         self.P = ParamStore(keep, device)
         self.device = device
         self.n_query = n_query
-        self.dino = DinoTrain(self.P, "rgb_model.", device)
+        self.dino = DinoTrain("rgb_model.", device)
         self.pos = sinusoidal_positions(32, 384, device)
 
     def loss_and_grads(self, hidden_q: torch.Tensor, traj_images: torch.Tensor, traj_poses: torch.Tensor, video_frame_num: torch.Tensor,
@@ -680,6 +741,142 @@ class NextDiTSftHead:
             T.colsum(pred.v, dout[:, nn_], out=gw[nn_], x2_bcast=True, accumulate=True)
         T.colsum(dout, out=P.grad("action_decoder.bias"), accumulate=True)
         pred.g = T.small_linear(dout, P.w32("action_decoder.weight"), out_dtype=BF, w_transposed=True)
+        tape.backward()
+        dh = hq.g if hq.g is not None else torch.zeros_like(hq.v)
+        return loss, dh.view(B, nq, -1)
+
+
+# ---------------------------------------------------------------------------------------------------------------- NavDP head (navdp_async)
+def decoder_layer_prenorm(tape: Tape, x: Var, mem: Var, p: str, B: int, Lq: int, Lm: int, H: int, d: int, causal: bool) -> Var:
+    """nn.TransformerDecoderLayer(batch_first=True, norm_first=True, activation='gelu'), causal tgt_mask, no memory mask, dropout off;
+    x is the fp32 residual stream."""
+    h = tape.norm(x, p + ".norm1.weight", p + ".norm1.bias", 1e-5)
+    x = _mha(tape, h, h, p + ".self_attn", B, Lq, Lq, H, d, residual=x, causal=causal)
+    h = tape.norm(x, p + ".norm2.weight", p + ".norm2.bias", 1e-5)
+    x = _mha(tape, h, mem, p + ".multihead_attn", B, Lq, Lm, H, d, residual=x)
+    h = tape.norm(x, p + ".norm3.weight", p + ".norm3.bias", 1e-5)
+    return tape.linear(tape.act(tape.linear(h, p + ".linear1.weight", p + ".linear1.bias"), "gelu_erf"), p + ".linear2.weight", p + ".linear2.bias",
+                       residual=x, out_dtype=F32)
+
+
+def ddpm_alphas_cumprod(num_train_timesteps: int) -> torch.Tensor:
+    """diffusers DDPMScheduler(beta_schedule='squaredcos_cap_v2'): betas_for_alpha_bar (cosine, max_beta 0.999) -> cumprod(1 - beta), fp32."""
+    def alpha_bar(t):
+        return math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2
+    betas = [min(1 - alpha_bar((i + 1) / num_train_timesteps) / alpha_bar(i / num_train_timesteps), 0.999) for i in range(num_train_timesteps)]
+    return torch.cumprod(1.0 - torch.tensor(betas, dtype=F32), dim=0)
+
+
+def sinusoidal_pos_emb(x: torch.Tensor, dim: int) -> torch.Tensor:
+    """SinusoidalPosEmb (navdp_backbone.py:9-21)."""
+    half = dim // 2
+    e = torch.exp(torch.arange(half, dtype=F32, device=x.device) * -(math.log(10000) / (half - 1)))
+    e = x[:, None].float() * e[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+IMAGENET_MEAN_BF16 = (0.484375, 0.45703125, 0.40625)          # DAT_RGBD_Patch_Backbone keeps its constants in bf16 (navdp_backbone.py:119-127)
+IMAGENET_STD_BF16 = (0.2294921875, 0.2236328125, 0.224609375)
+
+
+class NavDPSftHead:
+    """Loss + gradients of the navdp_async branch of InternVLAN1ForCausalLM.forward(labels=...) (internvla_n1.py:287-303) =
+    NavDP_Policy_DPT_CriticSum_DAT.forward_vlm_traj (internvla_n1/navdp.py:291-312): epsilon-prediction MSE of the 16-layer causal
+    decoder, trained with everything in `navdp.*` except the RGB DINOv2 (internvla_n1_trainer.py:118-121)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device, cfg: dict, n_query: int = 4, extra_trainable: Sequence[str] = ()):
+        frozen = {k: v for k, v in sd.items() if "rgb_model" in k and not k.endswith("mask_token")}
+        keep = {k: v for k, v in sd.items() if k not in frozen and not k.endswith("mask_token") and (k in extra_trainable or not k.startswith(("model.", "visual.", "lm_head")))}
+        self.P = ParamStore(keep, device)
+        self.F = ParamStore(frozen, device, trainable=False)
+        self.device, self.cfg, self.n_query = device, cfg, n_query
+        self.rgb = DinoTrain("rgbd_encoder.rgb_model.", device, mean=IMAGENET_MEAN_BF16, std=IMAGENET_STD_BF16)
+        self.depth = DinoTrain("rgbd_encoder.depth_model.", device, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), channels=1)
+        self.acp = ddpm_alphas_cumprod(cfg["num_train_timesteps"]).to(device)
+
+    def loss_and_grads(self, hidden_q: torch.Tensor, traj_images: torch.Tensor, traj_depths: torch.Tensor, traj_poses: torch.Tensor,
+                       video_frame_num: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor, loss_scale: float = 1.0):
+        """hidden_q bf16 [B, n_query, 3584]; traj_images [B, T, 224, 224, 3] in 0..1; traj_depths [B, T, 224, 224] metres; traj_poses f32
+        [B, T, P, 3]; noise f32 [B*T, P, 3]; timesteps int [B*T] in [0, num_train_timesteps) (the reference's sample_noise draws).
+        Gradients are ACCUMULATED into the store; returns (loss f32 [1], d loss / d hidden_q bf16 [B, n_query, 3584])."""
+        P, dev, nq, cfg = self.P, self.device, self.n_query, self.cfg
+        D, H, M = cfg["token_dim"], cfg["heads"], cfg["memory_size"]
+        B, Tn = traj_images.shape[:2]
+        N, Ta = B * Tn, traj_poses.shape[2]
+        tape = Tape(P, self.F)
+        hq = Var(hidden_q.reshape(B * nq, -1).to(BF).contiguous())
+        # ---- goal token: vlm_embed_mlp + 1-query compressor
+        h = tape.repeat_seq(hq, B, nq, Tn)
+        h = tape.act(tape.linear(h, "vlm_embed_mlp.0.weight", "vlm_embed_mlp.0.bias"), "relu")
+        h = tape.act(tape.linear(h, "vlm_embed_mlp.2.weight", "vlm_embed_mlp.2.bias"), "relu")
+        h = tape.linear(h, "vlm_embed_mlp.4.weight", "vlm_embed_mlp.4.bias")
+        h = tape.add_table(h, "goal_compressor.token_positional_encoding.position_embedding.weight", nq)
+        gq = Var((P.w32("goal_compressor.target_embedding.weight") + P.w32("goal_compressor.query_positional_encoding.position_embedding.weight")[:1])
+                 .to(BF).expand(N, D).contiguous())
+
+        def bwd_gq():
+            if gq.g is not None:
+                g = gq.g.float().sum(0, keepdim=True)
+                P.grad("goal_compressor.target_embedding.weight").add_(g)
+                P.grad("goal_compressor.query_positional_encoding.position_embedding.weight")[:1].add_(g)
+        tape.nodes.append(bwd_gq)
+        goal = _mha(tape, gq, h, "goal_compressor.cross_attention", N, 1, nq, H, D)                      # [N, D]
+        # ---- RGB-D memory tokens (goal frame = frame 0 of the sample; every distinct frame is encoded once)
+        rgb = self.rgb.forward(tape, traj_images.reshape(N, *traj_images.shape[2:]).to(dev))           # frozen: no backward
+        dep = self.depth.forward(tape, traj_depths.reshape(N, *traj_depths.shape[2:4], 1).to(dev).float())
+        tok = tape.cat_tokens([(tape.pair_goal_current(rgb, B, Tn, 256), 512), (tape.pair_goal_current(dep, B, Tn, 256), 512)], N)
+        tok = tape.add_table(tok, "rgbd_encoder.former_pe.weight", 2 * M * 256)
+        fq = Var(P.w16("rgbd_encoder.former_query.weight").unsqueeze(0).expand(N, -1, -1).reshape(N * M * 16, 384))
+
+        def bwd_fq():
+            if fq.g is not None:
+                P.grad("rgbd_encoder.former_query.weight").add_(fq.g.float().view(N, -1).sum(0).view(M * 16, 384))
+        tape.nodes.append(bwd_fq)
+        q = fq
+        for i in range(2):
+            q = decoder_layer(tape, q, tok, f"rgbd_encoder.former_net.layers.{i}", N, M * 16, 2 * M * 256, 8, 384)
+        rgbd = tape.linear(q, "rgbd_encoder.project_layer.weight", "rgbd_encoder.project_layer.bias")   # [N * M*16, D]
+        # ---- condition and noisy actions (sample_noise, navdp.py:163-175)
+        ts = timesteps.to(dev).long()
+        te = Var(sinusoidal_pos_emb(ts, D).to(BF), req=False)
+        Lc = 2 + M * 16
+        cond = tape.add_table(tape.cat_tokens([(te, 1), (goal, 1), (rgbd, M * 16)], N), "cond_pos_embed", Lc)
+        x = traj_poses.reshape(N, Ta, 3).to(device=dev, dtype=F32)
+        noise = noise.to(device=dev, dtype=F32).view(N, Ta, 3)
+        a = self.acp[ts].view(N, 1, 1)
+        noisy = (a.sqrt() * x + (1 - a).sqrt() * noise).reshape(N * Ta, 3).contiguous()
+        x0 = Var(T.small_linear(noisy, P.w32("input_embed.weight"), P.w32("input_embed.bias")))
+
+        def bwd_embed():
+            dy = x0.g
+            if dy is None:
+                return
+            gw = P.grad("input_embed.weight")
+            for kk in range(3):
+                T.colsum(dy, noisy[:, kk], out=gw[:, kk], x2_bcast=True, out_cs=3, accumulate=True)
+            T.colsum(dy, out=P.grad("input_embed.bias"), accumulate=True)
+        tape.nodes.append(bwd_embed)
+        y = tape.add_table(x0, "out_pos_embed", Ta)
+        taps = getattr(self, "taps", None)
+        if taps is not None:
+            taps.append(("cond", cond.v.float().clone()))
+            taps.append(("x0", y.v.float().clone()))
+        for i in range(cfg["temporal_depth"]):
+            y = decoder_layer_prenorm(tape, y, cond, f"decoder.layers.{i}", N, Ta, Lc, H, D, causal=True)
+            if taps is not None:
+                taps.append((f"layer{i}", y.v.float().clone()))
+        pred = tape.norm(y, "layernorm.weight", "layernorm.bias", 1e-5)
+        out = T.small_linear(pred.v, P.w32("action_head.weight"), P.w32("action_head.bias"))           # f32 [N*Ta, 3]
+        self.last_prediction = out
+        if taps is not None:
+            taps.append(("lnout", pred.v.float().clone()))
+        mask = (torch.arange(Tn, device=dev)[None, :] < video_frame_num.to(dev)[:, None]).to(F32).reshape(N).contiguous()
+        loss, dout = T.mse_masked(out, noise.reshape(N * Ta, 3).contiguous(), mask, Ta, loss_scale=loss_scale)
+        gw = P.grad("action_head.weight")
+        for nn_ in range(3):
+            T.colsum(pred.v, dout[:, nn_], out=gw[nn_], x2_bcast=True, accumulate=True)
+        T.colsum(dout, out=P.grad("action_head.bias"), accumulate=True)
+        pred.g = T.small_linear(dout, P.w32("action_head.weight"), out_dtype=BF, w_transposed=True)
         tape.backward()
         dh = hq.g if hq.g is not None else torch.zeros_like(hq.v)
         return loss, dh.view(B, nq, -1)

@@ -43,3 +43,40 @@ def nextdit_sft_loss(sd, hidden_q, traj_images, traj_poses, video_frame_num, noi
     loss = F.mse_loss(pred.float(), target.float(), reduction="none")
     mask = loss_mask.flatten(0, 1)[:, None, None]
     return (loss * mask).sum() / mask.sum() / (loss.shape[1] * loss.shape[2])                      # :283-286
+
+
+def navdp_sft_loss(sd, hidden_q, traj_images, traj_depths, traj_poses, video_frame_num, noise, timesteps, cfg):
+    """navdp_async branch (internvla_n1.py:287-303) = NavDP_Policy_DPT_CriticSum_DAT.forward_vlm_traj (internvla_n1/navdp.py:291-312) with
+    sample_noise's draws (:163-175) as arguments: noise [B*T, P, 3], timesteps long [B*T] in [0, num_train_timesteps).
+    hidden_q [B, n_query, 3584]; traj_images [B, T, 224, 224, 3] in 0..1; traj_depths [B, T, 224, 224] metres; traj_poses [B, T, P, 3]."""
+    from . import navdp as o_n
+    from .nn_ref import causal_mask, layer_norm, sinusoidal_pos_emb
+    from .schedulers import DDPMScheduler
+
+    B, Tn = traj_images.shape[:2]
+    ths = hidden_q.unsqueeze(1).repeat(1, Tn, 1, 1).flatten(0, 1)
+    loss_mask = torch.arange(Tn).expand(B, Tn) < video_frame_num.unsqueeze(1)
+    cur, cur_d = traj_images.flatten(0, 1), traj_depths.flatten(0, 1)
+    goal = traj_images[:, 0:1].repeat(1, Tn, 1, 1, 1).flatten(0, 1)
+    goal_d = traj_depths[:, 0:1].repeat(1, Tn, 1, 1).flatten(0, 1)
+    images_dp = torch.stack([goal, cur], dim=1)
+    depths_dp = torch.stack([goal_d, cur_d], dim=1).unsqueeze(-1)
+    h = ths.float()
+    h = F.relu(linear(h, sd, "vlm_embed_mlp.0"))
+    h = F.relu(linear(h, sd, "vlm_embed_mlp.2"))
+    h = linear(h, sd, "vlm_embed_mlp.4")
+    vlm_embed = o_n.token_compressor(h, sd)                                                        # [N, 1, D]
+    actions = traj_poses.flatten(0, 1).float()
+    sch = DDPMScheduler(num_train_timesteps=cfg["num_train_timesteps"])
+    noisy = sch.add_noise(actions, noise, timesteps)
+    time_embeds = sinusoidal_pos_emb(timesteps, cfg["token_dim"]).unsqueeze(1)
+    a = linear(noisy, sd, "input_embed")
+    rgbd = o_n.dat_rgbd_backbone(images_dp, depths_dp, sd)
+    cond = torch.cat([time_embeds, vlm_embed, rgbd], dim=1)
+    cond = cond + sd["cond_pos_embed"][:, : cond.shape[1]]
+    x = a + sd["out_pos_embed"][:, : cfg["predict_size"], :]
+    x = o_n._decoder(x, cond, sd, cfg["temporal_depth"], cfg["heads"], tgt_mask=causal_mask(x.shape[1]))
+    pred = linear(layer_norm(x, sd, "layernorm", 1e-5), sd, "action_head")
+    loss = (pred - noise).square()
+    mask = loss_mask.flatten(0, 1)[:, None, None]
+    return (loss * mask).sum() / mask.sum() / (loss.shape[1] * loss.shape[2])
