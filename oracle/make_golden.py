@@ -524,7 +524,80 @@ def gold_sft(B=1, T=2):
                 oracle_max_abs_diff=worst)
 
 
-UNITS = {"sft": gold_sft, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+def gold_sft_navdp(B=1, T=2):
+    """SFT loss of the navdp_async branch (internvla_n1.py:287-303) through the reference's own NavDP_Policy_DPT_CriticSum_DAT.forward_vlm_traj
+    (internvla_n1/navdp.py:291-312) under autograd, dropout off; sample_noise's random draws (:163-175) are replaced by seeded inputs fed
+    through the module's own time_emb / noise_scheduler.add_noise / input_embed."""
+    from . import sft as o_sft
+
+    torch_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        n1 = R.n1_navdp_module()
+        cfg = W.N1_NAVDP_CFG
+        m = n1.NavDP_Policy_DPT_CriticSum_DAT(memory_size=cfg["memory_size"], navdp_version=0.1, input_dtype="fp32")
+    finally:
+        torch.load = torch_load
+    sd = W.n1_navdp_state_dict(seed=7)
+    m = _load_strict(m, sd, allow_missing_prefixes=("point_encoder.", "critic_head.", "pg_embed_mlp.", "pg_pred_mlp.", "decoder_layer."),
+                     skip_buffers=("goal_compressor.positional_encoding.pe",))
+    m.rgbd_encoder.input_dtype = torch.float32
+    m.rgbd_encoder.preprocess_mean = m.rgbd_encoder.preprocess_mean.float()
+    m.rgbd_encoder.preprocess_std = m.rgbd_encoder.preprocess_std.float()
+    m.tgt_mask = m.tgt_mask.float()
+    g = torch.Generator().manual_seed(7)
+    hidden_q = torch.randn(B, 4, 3584, generator=g).requires_grad_(True)
+    traj_images = torch.rand(B, T, 224, 224, 3, generator=g)
+    traj_depths = torch.rand(B, T, 224, 224, generator=g) * 5.0
+    traj_poses = torch.randn(B, T, 32, 3, generator=g)
+    video_frame_num = torch.tensor([T] * (B - 1) + [max(1, T - 1)])
+    noise = torch.randn(B * T, 32, 3, generator=g)
+    timesteps = torch.randint(0, cfg["num_train_timesteps"], (B * T,), generator=g)
+
+    def sample_noise(action):
+        time_embeds = m.time_emb(timesteps).unsqueeze(1).float()
+        noisy_action = m.noise_scheduler.add_noise(action, noise, timesteps)
+        return noise, time_embeds, m.input_embed(noisy_action)
+    m.sample_noise = sample_noise
+    traj_hidden_states = hidden_q.unsqueeze(1).repeat(1, traj_poses.size(1), 1, 1).flatten(0, 1)
+    loss_mask = torch.arange(traj_images.size(1)).expand(traj_images.size(0), traj_images.size(1)) < video_frame_num.unsqueeze(1)
+    cur_images, cur_depths = traj_images.flatten(0, 1), traj_depths.flatten(0, 1)
+    pix_goal_images = traj_images[:, 0:1].repeat(1, traj_images.size(1), 1, 1, 1).flatten(0, 1)
+    pix_goal_depths = traj_depths[:, 0:1].repeat(1, traj_depths.size(1), 1, 1).flatten(0, 1)
+    images_dp = torch.stack([pix_goal_images, cur_images], dim=1)
+    depths_dp = torch.stack([pix_goal_depths, cur_depths], dim=1).unsqueeze(-1)
+    pred_pg, nz = m.forward_vlm_traj(traj_hidden_states, images_dp, depths_dp, tensor_label_actions=traj_poses)
+    pg_action_loss = (pred_pg - nz).square()
+    mask = loss_mask.flatten(0, 1)[:, None, None]
+    loss = (pg_action_loss * mask).sum() / mask.sum() / (pg_action_loss.shape[1] * pg_action_loss.shape[2])
+    loss.backward()
+    ref_grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+    sd_o = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    hq_o = hidden_q.detach().clone().requires_grad_(True)
+    loss_o = o_sft.navdp_sft_loss(sd_o, hq_o, traj_images, traj_depths, traj_poses, video_frame_num, noise, timesteps, cfg)
+    loss_o.backward()
+    worst = abs(loss_o.item() - loss.item())
+    gscale = max(x.abs().max().item() for x in ref_grads.values())
+    samples = {}
+    for k, gr in ref_grads.items():
+        assert k in sd_o and sd_o[k].grad is not None, f"reference parameter {k} has a gradient, the oracle's has none"
+        scale = gr.abs().max().item()
+        rel_k = 0.0 if scale < 1e-6 * gscale else (gr - sd_o[k].grad).abs().max().item() / scale
+        if rel_k > 1e-3:
+            print(f"  [sft_navdp] {k}: rel {rel_k:.3e} scale {scale:.3e}")
+        worst = max(worst, rel_k)
+        flat = gr.flatten()
+        pick = torch.linspace(0, flat.numel() - 1, min(32, flat.numel())).long()
+        samples[k] = dict(norm=gr.norm().item(), idx=pick, val=flat[pick].clone())
+    worst = max(worst, ((hidden_q.grad - hq_o.grad).abs().max() / hidden_q.grad.abs().max()).item())
+    return dict(B=B, T=T, weights_seed=7, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples,
+                inputs=dict(hidden_q=hidden_q.detach(), traj_images=traj_images, traj_depths=traj_depths, traj_poses=traj_poses,
+                            video_frame_num=video_frame_num, noise=noise, timesteps=timesteps),
+                oracle_max_abs_diff=worst)
+
+
+UNITS = {"sft_navdp": gold_sft_navdp, "sft": gold_sft, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
 
 
 def main():

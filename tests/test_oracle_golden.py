@@ -192,3 +192,28 @@ def test_flow_match_scheduler_default_state():
     s = FlowMatchEulerDiscreteScheduler()
     assert s.timesteps.shape == (1000,) and s.timesteps[0].item() == 1000.0 and s.timesteps[-1].item() == 1.0
     assert torch.allclose(s.sigmas, s.timesteps / 1000.0)
+
+
+def test_navdp_sft_loss_and_gradients_match_reference_autograd():
+    """navdp_async SFT branch: autograd of oracle/sft.navdp_sft_loss vs the fixture made by back-propagating through the reference's own
+    NavDP_Policy_DPT_CriticSum_DAT.forward_vlm_traj (oracle/make_golden.py gold_sft_navdp)."""
+    from oracle import sft as o_sft
+
+    gold = _load("sft_navdp")
+    sd = {k: v.float().clone().requires_grad_(True) for k, v in W.n1_navdp_state_dict(seed=gold["weights_seed"]).items()}
+    inp = gold["inputs"]
+    hq = inp["hidden_q"].clone().requires_grad_(True)
+    loss = o_sft.navdp_sft_loss(sd, hq, inp["traj_images"], inp["traj_depths"], inp["traj_poses"], inp["video_frame_num"], inp["noise"],
+                                inp["timesteps"], W.N1_NAVDP_CFG)
+    loss.backward()
+    assert abs(loss.item() - gold["loss"]) < 1e-5 * abs(gold["loss"])
+    assert ((hq.grad - gold["d_hidden"]).abs().max() / gold["d_hidden"].abs().max()).item() < 1e-4
+    gscale = max(g["norm"] for g in gold["grads"].values())
+    for k, g in gold["grads"].items():
+        mine = sd[k].grad
+        assert mine is not None, k
+        if g["norm"] < 1e-6 * gscale:
+            assert mine.norm().item() < 1e-5 * gscale, k
+            continue
+        assert abs(mine.norm().item() - g["norm"]) < 1e-4 * g["norm"], k
+        assert (mine.flatten()[g["idx"]] - g["val"]).abs().max().item() < 1e-4 * max(g["val"].abs().max().item(), g["norm"] / mine.numel() ** 0.5), k
