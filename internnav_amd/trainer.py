@@ -21,7 +21,7 @@ import torch
 
 from . import train_ops as T
 from .qwen_vl import QwenVLEngine
-from .sft import NextDiTSftHead
+from .sft import NavDPSftHead, NextDiTSftHead
 from .sft_llm import LatentQueryGrad
 
 LQ = "latent_queries"
@@ -50,12 +50,22 @@ def shard_bounds(numel: int, world: int, rank: int, align: int = 1024):
 class InternVLAN1SftTrainer:
     def __init__(self, engine: QwenVLEngine, s1_state_dict: Dict[str, torch.Tensor], device, total_steps: int = 1000, lr: float = 1e-4,
                  min_lr: float = 1e-5, warmup_ratio: float = 0.003, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
-                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False):
+                 betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False, system1: str = "nextdit_async",
+                 s1_cfg: Optional[dict] = None):
+        """system1: 'nextdit_async' (flow-matching loss on the NextDiT head) or 'navdp_async' (epsilon loss on the NavDP head; `s1_cfg` =
+        its hyper-parameters, synthetic.N1_NAVDP_CFG; the batch then also carries `traj_depths` [B, T, 224, 224] in metres)."""
         self.engine, self.device = engine, torch.device(device)
         nq, H = engine.latent_q.shape
         sd = dict(s1_state_dict)
         sd[LQ] = sd.get(LQ, engine.latent_q.float().view(1, nq, H).cpu())
-        self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,))
+        self.system1 = system1
+        if system1 == "nextdit_async":
+            self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,))
+        elif system1 == "navdp_async":
+            assert s1_cfg is not None, "navdp_async needs the NavDP hyper-parameters (s1_cfg)"
+            self.head = NavDPSftHead(sd, device, s1_cfg, n_query=nq, extra_trainable=(LQ,))
+        else:
+            raise NotImplementedError(f"SFT for system1={system1!r}: only the *_async heads of the released checkpoints are trained here")
         self.P = self.head.P
         self.lq = LatentQueryGrad(engine)
         self.total_steps, self.lr, self.min_lr = total_steps, lr, min_lr
@@ -86,11 +96,17 @@ class InternVLAN1SftTrainer:
         state = e.prefill(prefix, pv, batch["image_grid_thw"], seq_lens=t_s_pos)
         hq = self.lq.forward(state)
         Tn = batch["traj_images"].shape[1]
-        if noise is None:            # internvla_n1.py:261-264 (the reference draws u on the CPU generator)
+        if noise is None:            # internvla_n1.py:261-264 / navdp.py:163-175 (the reference draws inside forward)
             noise = torch.randn(B * Tn, *batch["traj_poses"].shape[2:], device=dev)
-        if t_index is None:
-            t_index = (torch.rand(B * Tn) * 1000).long()
-        loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index)
+        if self.system1 == "nextdit_async":
+            if t_index is None:
+                t_index = (torch.rand(B * Tn) * 1000).long()
+            loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index)
+        else:
+            if t_index is None:
+                t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,))
+            loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_depths"].to(dev), batch["traj_poses"],
+                                                batch["video_frame_num"], noise, t_index)
         self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
         return loss
 

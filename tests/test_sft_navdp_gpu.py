@@ -64,7 +64,7 @@ def test_navdp_sft_loss_and_gradients(built_lib):
         e, y = _rel(got, ref), _rel(g16[k], ref)
         errs.append(e)
         yards.append(y)
-        if e > 3e-2:
+        if e > max(3e-2, 1.25 * y):
             bad.append((k, e, y))
     print(f"{len(errs)} parameter gradients: engine mean {sum(errs) / len(errs):.3e}, bf16 PyTorch mean {sum(yards) / len(yards):.3e}")
     # Unlike the NextDiT branch (engine 0.7x of the bf16-PyTorch error) this 16-layer decoder on random weights has nearly sample-independent

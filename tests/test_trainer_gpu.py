@@ -80,3 +80,27 @@ def test_training_step_matches_chained_oracles(built_lib):
     l2 = tr.training_step(batch, noise, t_index)
     assert torch.isfinite(l2).all() and not torch.equal(before, eng.latent_q) and float(tr.P.g32.abs().max()) == 0.0
     assert tr.step_idx == 2 and tr.grad_norm.item() > 0
+
+
+def test_navdp_async_training_step_runs(built_lib):
+    """the other System-1 type of the reference's forward(labels=...) (internvla_n1.py:287-303) through the same trainer."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+    from internnav_amd.trainer import LQ, InternVLAN1SftTrainer
+
+    cfg = W.QWEN_TEST_CFG
+    B, T = 2, 2
+    sd_q = W.qwen_state_dict(seed=11, cfg=cfg)
+    sd_s = {k: v.float() for k, v in S.materialize(S.n1_navdp_spec(), 3).items()}
+    batch, noise, _, inp = _batch(cfg, B, T)
+    batch["traj_depths"] = torch.rand(B, T, 224, 224) * 5.0
+    eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+    tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100, system1="navdp_async", s1_cfg=S.N1_NAVDP_CFG)
+    tr.step_idx = 5
+    l0 = tr.forward_backward(batch, noise, torch.tensor([3, 7, 11, 19]))
+    assert torch.isfinite(l0).all() and float(tr.P.grad(LQ).abs().max()) > 0
+    assert not any("rgb_model" in k for k in tr.P.index)                 # the RGB DINOv2 stays frozen (internvla_n1_trainer.py:119-120)
+    before = eng.latent_q.clone()
+    tr.reduce_gradients()
+    tr.optimizer_step()
+    assert not torch.equal(before, eng.latent_q) and float(tr.P.g32.abs().max()) == 0.0

@@ -4,10 +4,11 @@ R=$PWD
 TAG=${1:-r02}
 mkdir -p $R/gpurun_out
 rm -f $R/gpurun_out/qwen_full_drift.txt
-timeout 1200 python -m pytest tests -q -m gpu > $R/gpurun_out/${TAG}_pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -q -m gpu > $R/gpurun_out/${TAG}_pytest_gpu.log 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/${TAG}_smoke.log 2>&1
 timeout 900 python bench.py > $R/gpurun_out/${TAG}_bench_n1_dual_b64.log 2>&1
 timeout 600 python bench.py --workload navdp_s1 > $R/gpurun_out/${TAG}_bench_navdp_s1_b64.log 2>&1
+timeout 600 python bench_sft.py > $R/gpurun_out/${TAG}_bench_sft.log 2>&1
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/kt.log 2>&1
 python $R/tools/rocprof_summary.py $R/gpurun_out/kt/kt_results.db 45 > $R/gpurun_out/${TAG}_n1_dual_b64_kernel_stats.txt 2>&1
@@ -17,6 +18,9 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_$w -o kt -- pyt
 python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/kt_$w/*.db | head -1) 40 > $R/gpurun_out/${TAG}_${w}_3calls_kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/kt_$w
 done
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_sft -o kt -- python $R/bench_sft.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/kt_sft.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/kt_sft/*.db | head -1) 40 > $R/gpurun_out/${TAG}_sft_kernel_stats.txt 2>&1
+rm -rf $R/gpurun_out/kt_sft
 # HBM-side traffic of one System-2 call (separate FETCH_SIZE / WRITE_SIZE passes, guides/MI355X_MICROARCH.md HBM section)
 timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pf -o f -- python $R/tools/profile_phases.py s2 1 > $R/gpurun_out/pf.log 2>&1
 timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pw -o w -- python $R/tools/profile_phases.py s2 1 > $R/gpurun_out/pw.log 2>&1
