@@ -232,6 +232,9 @@ def _attn_ref(q, k, v, do, scale, causal, k_len=None):
     (2, 100, 100, 4, 4, 64, True),
     (2, 4, 333, 28, 4, 128, True),      # LLM latent-query rows, GQA
     (1, 70, 200, 8, 2, 128, True),
+    (4, 32, 32, 8, 8, 48, True),        # NavDP decoder self-attention (head dim 48 padded to 64, causal)
+    (4, 32, 34, 8, 8, 48, False),       # NavDP decoder cross-attention
+    (4, 1, 4, 8, 8, 48, False),         # goal compressor: one query over the 4 latent tokens
     (2, 4, 2100, 28, 4, 128, True),     # long cached prefix: the dQ pass splits the keys over workgroups (f32 atomics)
 ])
 def test_attention_bwd(dev, B, Lq, Lk, H, Hkv, D, causal):
