@@ -212,7 +212,7 @@ def main():
             "data": "synthetic (seeded random weights at the true shapes, synthetic prompts / frames / trajectories)",
             "config": {"workload": f"sft_nextdit_async_b{info['B']}x{info['T']}", "micro_batch_per_gpu": info["B"], "subgoals_per_sample": info["T"],
                        "s2_prompt": f"{info['F']} frames x 784 patches + text, S={info['S']} + 4 <traj> tokens", "parallelism": f"dp{world}" + ("-zero2" if a.zero2 else ""),
-                       "trainable_parameters": int(sum(int(np.prod(s)) for _, s in tr.P.index.values())), "optimizer": "fused AdamW + clip 1.0, cosine_with_min_lr",
+                       "trainable_parameters": int(sum(int(np.prod(s)) for _, s in tr.P.index.values())), "optimizer": "fused AdamW + clip 1.0, cosine_with_min_lr", "dropout": 0.1,
                        "launch": "eager", "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": dom["launches"],

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 1
+#define INA_ABI_VERSION 2
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0
@@ -108,7 +108,12 @@ typedef struct ina_attn_args {
     const float* head_gate; /* f32 [H] or NULL: O *= tanh(gate[h]) */
     const int32_t* k_len;   /* int32 [B / kv_bdiv] or NULL: valid keys per K/V batch (dense mode; Lk is then the maximum) */
     int32_t accumulate;     /* 1: O += result */
-    int32_t _pad;
+    /* training only - attention-probability dropout of nn.MultiheadAttention(dropout=p) in train mode (dense layouts, no decode path):
+     * P[b,h,q,k] is kept iff ina_hash(drop_seed, ((b*H + h)*Lq + q)*Lk + k) >= drop_thresh and scaled by drop_scale = 1 / (1 - p);
+     * drop_thresh = p * 2^32, 0 = off. The backward kernel regenerates the same mask from the same numbers. */
+    uint32_t drop_seed;
+    uint32_t drop_thresh;
+    float drop_scale;
 } ina_attn_args;
 int ina_attention_bf16(const ina_attn_args* args, void* stream);
 
@@ -454,6 +459,8 @@ int ina_ddim_step(const ina_ddim_step_args* args, void* stream);
 #define INA_EW_ACT_BWD 2    /* Y = B * act'(A)            (A = pre-activation, B = dy) */
 #define INA_EW_GLU_FWD 3    /* Y = silu(A) * B */
 #define INA_EW_GLU_BWD 4    /* Y = D * B * silu'(A), Y2 = D * silu(A)   (D = dy) */
+#define INA_EW_DROPOUT 5    /* Y = A * keep / (1 - p): keep iff ina_hash(drop_seed, r * C + c) >= drop_thresh (nn.Dropout, train mode; the same
+                             * call on dy is its backward) */
 typedef struct ina_ew_args {
     const void* A; const void* B; const void* D; const void* S;
     void* Y; void* Y2;
@@ -462,6 +469,8 @@ typedef struct ina_ew_args {
     int32_t a_dt, b_dt, d_dt, s_dt, y_dt, y2_dt;
     int32_t lda, ldb, ldd, lds, ldy, ldy2;
     int32_t s_div, s_f, tab_mod, act, accumulate; /* accumulate: Y += */
+    uint32_t drop_seed, drop_thresh;
+    float drop_scale;
 } ina_ew_args;
 int ina_ew(const ina_ew_args* args, void* stream);
 

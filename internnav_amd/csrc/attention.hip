@@ -26,7 +26,7 @@ __device__ __forceinline__ int vt_pos(int kv_local) {
     return (sub << 5) + ((x >> 2) << 3) + (x & 3) + (t << 2);
 }
 
-template <int DP, int DV, int NW, int KVB>
+template <int DP, int DV, int NW, int KVB, bool DROP = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
     constexpr int NT = NW * 64;
     constexpr int KS_LD = DP + 8;
@@ -164,6 +164,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc_o[i][r] *= alpha;
 
+        if constexpr (DROP) {   // training: attention-probability dropout (the row sum above stays un-dropped, as in nn.MultiheadAttention)
+            const uint64_t row = ((uint64_t)((size_t)b * p.H + h) * p.Lq + q_abs) * p.Lk;
+#pragma unroll
+            for (int t = 0; t < NST; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s[t][r] = ina_hash(p.drop_seed, row + kv0 + t * 16 + g * 4 + r) >= p.drop_thresh ? s[t][r] * p.drop_scale : 0.f;
+        }
         // ---- O^T += V^T . P^T
 #pragma unroll
         for (int sb = 0; sb < NSB; ++sb) {
@@ -391,7 +399,7 @@ int launch_decode(const AttnArgs& p, hipStream_t stream) {
 template <int DP, int DV>
 int launch_d(const AttnArgs& p, hipStream_t stream) {
     // decode shape: few query tokens against a long dense KV (GQA-packed split-KV path)
-    if (!p.cu_q && !p.cu_k && p.kv_bdiv == 1 && p.kv_start == 0 && !p.accumulate && !p.head_gate && p.Lk >= 256 &&
+    if (!p.cu_q && !p.cu_k && p.kv_bdiv == 1 && p.kv_start == 0 && !p.accumulate && !p.head_gate && !p.drop_thresh && p.Lk >= 256 &&
         (p.H / p.Hkv) * p.Lq <= 48 && p.Lq <= 8 && DV <= 128)
         return launch_decode<DP, DV>(p, stream);
     // short query sequences: fewer waves per workgroup; short key sequences: 32-key blocks
@@ -404,6 +412,21 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
     const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)(p.Lk - p.kv_start);
     InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
                       2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)(p.B / p.kv_bdiv) * p.Hkv * p.Lk), stream);
+    if (p.drop_thresh) {   // training-only variant (d <= 64 heads of the nn.Transformer layers)
+        if constexpr (DP <= 64) {
+#define INA_ATTN_LAUNCH_DROP(NW_, KVB_) \
+    hipLaunchKernelGGL((attn_fwd_kernel<DP, DV, NW_, KVB_, true>), grid, dim3(NW_ * 64), 0, stream, p)
+            if (nw == 1) { if (small_k) INA_ATTN_LAUNCH_DROP(1, 32); else INA_ATTN_LAUNCH_DROP(1, 64); }
+            else if (nw == 2) { if (small_k) INA_ATTN_LAUNCH_DROP(2, 32); else INA_ATTN_LAUNCH_DROP(2, 64); }
+            else { if (small_k) INA_ATTN_LAUNCH_DROP(4, 32); else INA_ATTN_LAUNCH_DROP(4, 64); }
+#undef INA_ATTN_LAUNCH_DROP
+            INA_HIP_CHECK(hipGetLastError());
+            return 0;
+        } else {
+            ina_set_error("attention: dropout is built for head dims <= 64 only");
+            return -2;
+        }
+    }
 #define INA_ATTN_LAUNCH(NW_, KVB_) \
     hipLaunchKernelGGL((attn_fwd_kernel<DP, DV, NW_, KVB_>), grid, dim3(NW_ * 64), 0, stream, p)
     if (nw == 1) { if (small_k) INA_ATTN_LAUNCH(1, 32); else INA_ATTN_LAUNCH(1, 64); }

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
                     const int kv = kv0 + t * 16 + g * 4 + r;
                     const bool ok = kv < len_k && (!p.causal || kv <= q_abs + causal_shift);
                     const float pr = ok ? exp2f(s[t][r] * sc - lse2) : 0.f;
-                    s[t][r] = pr * (dp[t][r] - dl) * p.scale;   // dS
+                    float dpm = dp[t][r];
+                    if (p.drop_thresh)   // dropout on P: dL/dP = mask / (1 - p) * (dO . v)
+                        dpm = ina_hash(p.drop_seed, ((uint64_t)((size_t)b * p.H + h) * p.Lq + q_abs) * p.Lk + kv) >= p.drop_thresh ? dpm * p.drop_scale : 0.f;
+                    s[t][r] = pr * (dpm - dl) * p.scale;   // dS
                 }
             }
 #pragma unroll
@@ -281,8 +284,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
                     const int ql = t * 16 + g * 4 + r, q = q0 + ql;
                     const bool ok = live && q < len_q && (!p.causal || k_abs <= q + causal_shift);
                     const float pr = ok ? exp2f(s[t][r] * sc - st[ql]) : 0.f;
-                    dp[t][r] = pr * (dp[t][r] - st[CB + ql]) * p.scale;   // dS
-                    s[t][r] = pr;                                          // P
+                    float m = 1.f;
+                    if (p.drop_thresh) m = ina_hash(p.drop_seed, ((uint64_t)((size_t)b * p.H + h) * p.Lq + q) * p.Lk + k_abs) >= p.drop_thresh ? p.drop_scale : 0.f;
+                    dp[t][r] = pr * (dp[t][r] * m - st[CB + ql]) * p.scale;   // dS
+                    s[t][r] = pr * m;                                          // dropped P (what multiplied V in the forward pass)
                 }
             }
 #pragma unroll
@@ -353,6 +358,7 @@ int ina_launch_attention_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     INA_REQUIRE(p.Q && p.K && p.V && p.O && a.dO && a.lse && a.delta, "attention_bwd: null tensor");
     INA_REQUIRE(!p.cu_q && !p.cu_k, "attention_bwd: packed (varlen) sequences are not supported");
     INA_REQUIRE(!p.head_gate && p.kv_start == 0 && !p.accumulate, "attention_bwd: head_gate / kv_start / accumulate are forward-only");
+    INA_REQUIRE(!p.drop_thresh || a.nsplit <= 1, "attention_bwd: dropout with key splits is not built");
     INA_REQUIRE(p.D % 8 == 0 && p.D <= 128, "attention_bwd: head dim %d unsupported (multiple of 8, <= 128)", p.D);
     INA_REQUIRE(p.H % p.Hkv == 0, "attention_bwd: H %d not a multiple of Hkv %d", p.H, p.Hkv);
     INA_REQUIRE(a.kv_row0 >= -1 && a.kv_row0 <= p.Lk, "attention_bwd: kv_row0 %d out of range (-1 = the last Lq keys of every sequence)", a.kv_row0);

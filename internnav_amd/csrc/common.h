@@ -46,6 +46,16 @@ __device__ __forceinline__ float ina_act(float v, int act) {
     }
 }
 
+// counter-based dropout mask (training kernels): murmur3 finaliser over (seed, 64-bit element index); keep iff hash >= p * 2^32
+__device__ __forceinline__ uint32_t ina_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t ina_hash(uint32_t seed, uint64_t idx) {
+    const uint32_t h = ina_fmix32(seed ^ (uint32_t)idx);
+    return ina_fmix32(h + 0x9E3779B9u * (uint32_t)(idx >> 32) + 0x7F4A7C15u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
                 y2 = dy * ina_silu(av);
                 break;
             }
+            case INA_EW_DROPOUT:
+                y = ina_hash(p.drop_seed, (uint64_t)r * p.C + c) >= p.drop_thresh ? ldf(p.A, p.a_dt, (size_t)r * p.lda + c) * p.drop_scale : 0.f;
+                break;
             default: break;
         }
         if (p.accumulate) y += ldf(p.Y, p.y_dt, (size_t)r * p.ldy + c);
@@ -128,6 +131,10 @@ __global__ __launch_bounds__(256) void ew_vec_kernel(EwArgs p) {
                 for (int j = 0; j < 4; ++j) { y[j] = dy[j] * bv[j] * act_grad(av[j], INA_ACT_SILU); y2[j] = dy[j] * ina_silu(av[j]); }
                 break;
             }
+            case INA_EW_DROPOUT:
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = ina_hash(p.drop_seed, (uint64_t)r * p.C + c + j) >= p.drop_thresh ? av[j] * p.drop_scale : 0.f;
+                break;
             default: break;
         }
         if (p.accumulate) y += ld4(p.Y, p.y_dt, (size_t)r * p.ldy + c);
@@ -505,8 +512,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmNnArgs p, int rows_per
 
 int ina_launch_ew(const EwArgs& p, hipStream_t stream) {
     INA_REQUIRE(p.rows > 0 && p.C > 0 && p.A && p.Y, "ew: empty problem or null tensor");
-    INA_REQUIRE(p.op >= INA_EW_AFFINE && p.op <= INA_EW_GLU_BWD, "ew: unknown op %d", p.op);
-    INA_REQUIRE(p.op == INA_EW_AFFINE || p.op == INA_EW_ACT_FWD || p.B, "ew: op %d needs the second input", p.op);
+    INA_REQUIRE(p.op >= INA_EW_AFFINE && p.op <= INA_EW_DROPOUT, "ew: unknown op %d", p.op);
+    INA_REQUIRE(p.op == INA_EW_AFFINE || p.op == INA_EW_ACT_FWD || p.op == INA_EW_DROPOUT || p.B, "ew: op %d needs the second input", p.op);
     INA_REQUIRE(p.op != INA_EW_GLU_BWD || (p.D && p.Y2), "ew: glu backward needs dy and the second output");
     INA_REQUIRE(!p.S || p.s_div > 0, "ew: s_div must be positive");
     INA_REQUIRE(!p.tab || p.tab_mod > 0, "ew: tab_mod must be positive");

@@ -97,7 +97,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
               kv_start: int = 0, kv_bdiv: int = 1, cu_q: Optional[torch.Tensor] = None,
               cu_k: Optional[torch.Tensor] = None, max_q: int = 0, max_k: int = 0,
               head_gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-              accumulate: bool = False, k_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+              accumulate: bool = False, k_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     """softmax(q k^T * scale [+ masks]) v.
 
     Dense: q [B, Lq, H, D], k/v [Bk, Lk, Hkv, D] (arbitrary strides, last dim contiguous; Bk = B / kv_bdiv).
@@ -141,8 +141,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
         assert k_len.dtype == torch.int32 and k_len.is_contiguous() and cu_q is None
         a.k_len = k_len.data_ptr()
     a.accumulate = 1 if accumulate else 0
+    if drop_p > 0.0:       # training only: attention-probability dropout, mask = counter hash of (seed, element index)
+        assert cu_q is None, "dropout: dense layouts only"
+        a.drop_seed, a.drop_thresh, a.drop_scale = drop_params(drop_p, drop_seed)
     _lib.check(_lib.lib().ina_attention_bf16(C.byref(a), _stream()), "attention_bf16")
     return out
+
+
+def drop_params(p: float, seed: int):
+    """(seed, threshold, scale) of the counter-based dropout mask: keep iff hash(seed, index) >= p * 2^32, kept values scaled by 1 / (1 - p)."""
+    assert 0.0 < p < 1.0
+    return seed & 0xFFFFFFFF, max(1, min(0xFFFFFFFF, int(p * 4294967296.0))), 1.0 / (1.0 - p)
 
 
 def _rowmap(m) -> _lib.RowMap:

@@ -14,7 +14,7 @@ from . import _lib
 from .ops import ACT as _ACT, _DT, _stream
 
 ACT = dict(_ACT, tanh=6)
-EW_AFFINE, EW_ACT_FWD, EW_ACT_BWD, EW_GLU_FWD, EW_GLU_BWD = range(5)
+EW_AFFINE, EW_ACT_FWD, EW_ACT_BWD, EW_GLU_FWD, EW_GLU_BWD, EW_DROPOUT = range(6)
 SCALE_F = {None: 0, "id": 0, "one_plus": 1, "tanh": 2}
 
 
@@ -23,7 +23,7 @@ def _2d(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _ew(op, A, B=None, D=None, S=None, s_div=1, s_f=0, tab=None, act=0, out=None, out2=None, out_dtype=None, accumulate=False):
+def _ew(op, A, B=None, D=None, S=None, s_div=1, s_f=0, tab=None, act=0, out=None, out2=None, out_dtype=None, accumulate=False, drop=None):
     A = _2d(A)
     rows, Cd = A.shape
     if out is None:
@@ -54,6 +54,8 @@ def _ew(op, A, B=None, D=None, S=None, s_div=1, s_f=0, tab=None, act=0, out=None
         a.Y2, a.y2_dt, a.ldy2 = out2.data_ptr(), _DT[out2.dtype], out2.stride(0)
     a.act = act
     a.accumulate = 1 if accumulate else 0
+    if drop is not None:
+        a.drop_seed, a.drop_thresh, a.drop_scale = drop
     _lib.check(_lib.lib().ina_ew(C.byref(a), _stream()), "ew")
     return out
 
@@ -70,6 +72,14 @@ def act_fwd(x, act, out=None, out_dtype=None):
 def act_bwd(x, dy, act, out=None, out_dtype=None, accumulate=False):
     """out (+)= dy * act'(x)."""
     return _ew(EW_ACT_BWD, x, B=dy, act=ACT[act], out=out, out_dtype=out_dtype or dy.dtype, accumulate=accumulate)
+
+
+def dropout(x, p: float, seed: int, out=None, out_dtype=None):
+    """nn.Dropout in train mode with the library's counter-based mask (element index = r * C + c of the [rows, C] tensor); applying
+    it to dy with the same (p, seed) is the backward."""
+    from .ops import drop_params
+
+    return _ew(EW_DROPOUT, x, out=out, out_dtype=out_dtype, drop=drop_params(p, seed))
 
 
 def glu_fwd(a, b, out=None):
@@ -285,7 +295,7 @@ def gemm_nn(x, w, out=None, out_dtype=torch.float32, splits: Optional[int] = Non
 
 
 def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=1, dq=None, dk=None, dv=None, kv_row0=0, need_dkv=True,
-                  nsplit: Optional[int] = None):
+                  nsplit: Optional[int] = None, drop_p: float = 0.0, drop_seed: int = 0):
     """backward of ops.attention (dense): q/o/do [B, Lq, H, D], k/v [Bk, Lk, Hkv, D] (last dim contiguous, other strides free).
     Returns (dq [B,Lq,H,D], dk, dv [B, Lk - kv_row0, H, D]) - dk / dv are per QUERY head (sum GQA groups outside)."""
     assert q.dtype == k.dtype == v.dtype == o.dtype == do.dtype == torch.bfloat16
@@ -314,6 +324,11 @@ def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=
     a.dq_bs, a.dq_rs, a.dq_hs = dq.stride(0), dq.stride(1), dq.stride(2)
     stats = torch.empty(2, B, H, Lq, dtype=torch.float32, device=q.device)
     a.lse, a.delta = stats[0].data_ptr(), stats[1].data_ptr()
+    if drop_p > 0.0:
+        from .ops import drop_params
+
+        f.drop_seed, f.drop_thresh, f.drop_scale = drop_params(drop_p, drop_seed)
+        nsplit = 1
     if nsplit is None:      # few query rows against a long key axis: spread the keys over the chip
         nsplit = min(32, (Lk + 127) // 128) if (Lq <= 32 and Lk >= 512) else 1
     dq32 = None

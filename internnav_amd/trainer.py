@@ -51,19 +51,21 @@ class InternVLAN1SftTrainer:
     def __init__(self, engine: QwenVLEngine, s1_state_dict: Dict[str, torch.Tensor], device, total_steps: int = 1000, lr: float = 1e-4,
                  min_lr: float = 1e-5, warmup_ratio: float = 0.003, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False, system1: str = "nextdit_async",
-                 s1_cfg: Optional[dict] = None):
+                 s1_cfg: Optional[dict] = None, dropout: float = 0.1, seed: int = 0):
         """system1: 'nextdit_async' (flow-matching loss on the NextDiT head) or 'navdp_async' (epsilon loss on the NavDP head; `s1_cfg` =
         its hyper-parameters, synthetic.N1_NAVDP_CFG; the batch then also carries `traj_depths` [B, T, 224, 224] in metres)."""
         self.engine, self.device = engine, torch.device(device)
         nq, H = engine.latent_q.shape
         sd = dict(s1_state_dict)
         sd[LQ] = sd.get(LQ, engine.latent_q.float().view(1, nq, H).cpu())
-        self.system1 = system1
+        self.system1, self.seed = system1, seed
+        # dropout: the reference trains in module.train() mode, where MemoryEncoder / QFormer (nextdit) and former_net / decoder / drop
+        # (navdp) apply p = 0.1; masks come from a counter hash seeded per (seed, rank, micro-step)
         if system1 == "nextdit_async":
-            self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,))
+            self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,), dropout=dropout)
         elif system1 == "navdp_async":
             assert s1_cfg is not None, "navdp_async needs the NavDP hyper-parameters (s1_cfg)"
-            self.head = NavDPSftHead(sd, device, s1_cfg, n_query=nq, extra_trainable=(LQ,))
+            self.head = NavDPSftHead(sd, device, s1_cfg, n_query=nq, extra_trainable=(LQ,), dropout=dropout)
         else:
             raise NotImplementedError(f"SFT for system1={system1!r}: only the *_async heads of the released checkpoints are trained here")
         self.P = self.head.P
@@ -76,6 +78,7 @@ class InternVLAN1SftTrainer:
         self.rank = torch.distributed.get_rank(process_group) if self._dist() else 0
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.step_idx = 0
+        self.micro_idx = 0
 
     def _dist(self) -> bool:
         return torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -101,14 +104,19 @@ class InternVLAN1SftTrainer:
         if self.system1 == "nextdit_async":
             if t_index is None:
                 t_index = (torch.rand(B * Tn) * 1000).long()
-            loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index)
+            loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index,
+                                                seed=self._mask_seed())
         else:
             if t_index is None:
                 t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,))
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_depths"].to(dev), batch["traj_poses"],
-                                                batch["video_frame_num"], noise, t_index)
+                                                batch["video_frame_num"], noise, t_index, seed=self._mask_seed())
         self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
         return loss
+
+    def _mask_seed(self) -> int:
+        self.micro_idx += 1
+        return (self.seed * 2654435761 + self.rank * 97 + self.micro_idx) & 0x7FFFFFFF
 
     def reduce_gradients(self):
         """sum the flat gradient bucket over the data-parallel ranks (the 1 / world average is folded into the AdamW launch)."""

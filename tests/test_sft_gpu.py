@@ -108,3 +108,38 @@ def test_adamw_steps_follow_torch(case, dev):
             assert (head.P.w32(k) - p.detach()).abs().max().item() <= 5e-7 * max(1.0, p.detach().abs().max().item()), (step, k)   # fp32 rounding of the same update
         assert torch.equal(head.P.p16, head.P.p32.bfloat16())
     assert len(set(losses)) == 3, losses        # the bf16 working weights did move
+
+
+def test_dropout_training_mode(case, dev):
+    """train-mode dropout of MemoryEncoder / QFormer (p = 0.1 in the reference, internvla_n1_arch.py:77,105): counter-hash masks shared by the
+    forward and backward kernels. Same seed -> the same loss and gradients bit for bit; another seed -> another mask; p -> 0 recovers the
+    eval-mode step the oracle pins (the kernels' masks themselves are checked against a host replica in tests/test_train_ops_gpu.py)."""
+    from internnav_amd import sft as E
+
+    sd0, inp = case[0], case[1]
+    base_loss, base_grad = case[5].item(), case[4].P.g32.clone()
+
+    def run(p, seed):
+        head = E.NextDiTSftHead(sd0, dev, dropout=p)
+        loss, dh = head.loss_and_grads(inp["hidden_q"].to(dev), inp["traj_images"].to(dev), inp["traj_poses"], inp["video_frame_num"],
+                                       inp["noise"], inp["t_index"], seed=seed)
+        return loss.item(), head.P.g32.clone(), dh.clone()
+
+    l1, g1, d1 = run(0.1, 5)
+    l2, g2, d2 = run(0.1, 5)
+    l3, g3, _ = run(0.1, 6)
+    assert l1 == l2 and torch.equal(g1, g2) and torch.equal(d1, d2)
+    assert l3 != l1 and not torch.equal(g3, g1)
+    assert abs(l1 - base_loss) > 1e-4 and torch.isfinite(g1).all()
+    # every parameter tensor that gets a gradient without dropout still gets one
+    head0 = case[4]
+    for k in head0.P.index:
+        o, shape = head0.P.index[k]
+        n = 1
+        for d_ in shape:
+            n *= d_
+        if float(base_grad[o:o + n].abs().max()) > 0:
+            assert float(g1[o:o + n].abs().max()) > 0, k
+    l0, g0, _ = run(1e-7, 5)
+    assert abs(l0 - base_loss) < 2e-3 * abs(base_loss)
+    assert ((g0 - base_grad).norm() / base_grad.norm()).item() < 2e-2

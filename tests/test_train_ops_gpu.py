@@ -284,3 +284,65 @@ def test_attention_bwd_packed_views(dev):
     _, dq_ref, dk_ref, dv_ref = _attn_ref(q, k, v, do, D ** -0.5, False)
     for a, b in ((dq, dq_ref), (dk, dk_ref), (dv, dv_ref)):
         assert (a.float() - b).abs().max().item() < 2.5e-2 * b.abs().max().item()
+
+
+def _fmix32(h):
+    M = 0xFFFFFFFF
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M
+    return h ^ (h >> 16)
+
+
+def _keep_mask(seed, idx, p):
+    """host replica of ina_hash (csrc/common.h) on int64 tensors: keep iff hash(seed, idx) >= p * 2^32."""
+    M = 0xFFFFFFFF
+    lo, hi = idx & M, idx >> 32
+    h = _fmix32((seed ^ lo) & M)
+    h = _fmix32((h + 0x9E3779B9 * hi + 0x7F4A7C15) & M)
+    return h >= max(1, int(p * 4294967296.0))
+
+
+def test_dropout_mask_matches_host_replica(dev):
+    from internnav_amd import train_ops as T
+
+    g = torch.Generator(device="cpu").manual_seed(8)
+    rows, Cd, p, seed = 300, 384, 0.1, 12345
+    x = torch.randn(rows, Cd, generator=g).to(dev)
+    keep = _keep_mask(seed, torch.arange(rows * Cd, dtype=torch.int64, device=dev).view(rows, Cd), p)
+    y = T.dropout(x, p, seed)
+    assert torch.equal(y, torch.where(keep, x * (1.0 / (1.0 - p)), torch.zeros_like(x)))
+    assert abs(keep.float().mean().item() - 0.9) < 5e-3
+    yb = T.dropout(x.bfloat16()[:, 1:7], p, seed, out_dtype=torch.float32)          # scalar kernel, same indexing rule on the view
+    keep6 = _keep_mask(seed, torch.arange(rows * 6, dtype=torch.int64, device=dev).view(rows, 6), p)
+    assert torch.equal(yb, torch.where(keep6, x.bfloat16()[:, 1:7].float() * (1.0 / (1.0 - p)), torch.zeros(rows, 6, device=dev)))
+    assert not torch.equal(T.dropout(x, p, seed + 1), y)
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,D,causal", [(3, 257, 257, 6, 64, False), (2, 32, 512, 12, 64, False), (4, 32, 32, 8, 48, True), (4, 32, 34, 8, 48, False)])
+def test_attention_dropout_forward_backward(dev, B, Lq, Lk, H, D, causal):
+    """nn.MultiheadAttention(dropout=p) in train mode: the mask is regenerated identically by the forward and both backward passes; checked
+    against fp32 autograd with the host replica of the mask."""
+    from internnav_amd import ops
+    from internnav_amd import train_ops as T
+
+    g = torch.Generator(device="cpu").manual_seed(9)
+    p, seed = 0.1, 777
+    q, k, v, do = (torch.randn(B, L, H, D, generator=g).to(dev).bfloat16() for L in (Lq, Lk, Lk, Lq))
+    o = ops.attention(q, k, v, causal=causal, drop_p=p, drop_seed=seed)
+    idx = ((torch.arange(B, device=dev).view(B, 1, 1, 1) * H + torch.arange(H, device=dev).view(1, H, 1, 1)) * Lq
+           + torch.arange(Lq, device=dev).view(1, 1, Lq, 1)).to(torch.int64) * Lk + torch.arange(Lk, device=dev).view(1, 1, 1, Lk)
+    m = _keep_mask(seed, idx, p).float() / (1.0 - p)
+    qr, kr, vr = (t.float().detach().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * D ** -0.5
+    if causal:
+        s = s.masked_fill(~(torch.arange(Lk, device=dev)[None, :] <= torch.arange(Lq, device=dev)[:, None] + (Lk - Lq)), float("-inf"))
+    oref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1) * m, vr)
+    oref.backward(do.float())
+    assert _rel(o, oref.detach()) < 2e-2
+    assert not torch.allclose(o.float(), ops.attention(q, k, v, causal=causal).float(), atol=1e-2)
+    dq, dk, dv = T.attention_bwd(q, k, v, o, do, causal=causal, drop_p=p, drop_seed=seed)
+    for name, a, b in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (a.float() - b).abs()
+        assert err.max().item() < 2.5e-2 * b.abs().max().item() and err.mean().item() < 4e-3 * b.abs().mean().item() + 1e-6, name

@@ -59,7 +59,7 @@ def test_training_step_matches_chained_oracles(built_lib):
     sd_s = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
     batch, noise, t_index, inp = _batch(cfg, B, T)
     eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
-    tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100)
+    tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100, dropout=0.0)          # eval-mode gradients: what the oracle computes
     loss = tr.forward_backward(batch, noise, t_index)
     l32, glq32, g32 = _oracle(sd_q, sd_s, cfg, batch, noise, t_index, inp, False)
     l16, glq16, g16 = _oracle(sd_q, sd_s, cfg, batch, noise, t_index, inp, True)
