@@ -12,8 +12,6 @@ causal, only the query rows' own K / V receive gradients).
 """
 from __future__ import annotations
 
-from typing import List, Optional
-
 import numpy as np
 import torch
 
