@@ -73,3 +73,85 @@ def test_flat_bucket_all_reduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _cpu_adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, p_bf16=None, sumsq_parts=None, max_norm=0.0, grad_scale=1.0, norm_out=None, zero_grad=False):
+    """torch restatement of ina_adamw's contract (csrc/train.hip adamw_kernel) for the CPU-only plumbing test below - TEST CODE."""
+    total = float(sumsq_parts.sum().sqrt()) * grad_scale if sumsq_parts is not None else 0.0
+    clip = min(1.0, max_norm / (total + 1e-6)) if max_norm > 0 else 1.0
+    gg = g * (grad_scale * clip)
+    p.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    p.addcdiv_(m, v.sqrt() / (1 - beta2 ** step) ** 0.5 + eps, value=-lr / (1 - beta1 ** step))
+    if p_bf16 is not None:
+        p_bf16.copy_(p)
+    if norm_out is not None:
+        norm_out.fill_(total)
+    if zero_grad:
+        g.zero_()
+
+
+def _zero2_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from internnav_amd import train_ops as T
+    from internnav_amd.sft import ParamStore
+    from internnav_amd.trainer import InternVLAN1SftTrainer
+
+    T.adamw = _cpu_adamw                                                     # the GPU kernels are not under test here: the collectives are
+    T.sumsq_parts = lambda flat, width=1024: flat.view(-1, width).pow(2).sum(0)
+    results = []
+    for zero2 in (False, True):
+        g = torch.Generator().manual_seed(0)
+        # 3 blocks of 1024 after padding: with world 2 the shards are 2 + 1 blocks - the uneven case
+        P = ParamStore({"a": torch.randn(300, 7, generator=g), "b": torch.randn(500, generator=g), "latent_queries": torch.randn(1, 4, 16, generator=g)}, "cpu")
+        tr = object.__new__(InternVLAN1SftTrainer)
+        tr.P, tr.world, tr.rank, tr.pg, tr.zero2, tr.device = P, world, rank, None, zero2, torch.device("cpu")
+        tr.total_steps, tr.lr, tr.min_lr, tr.warmup_steps, tr.wd, tr.max_norm, tr.betas, tr.eps = 100, 1e-2, 1e-3, 0, 0.01, 1.0, (0.9, 0.999), 1e-8
+        tr.grad_norm, tr.step_idx = torch.zeros(1), 0
+
+        class _E:
+            latent_q = torch.zeros(4, 16, dtype=torch.bfloat16)
+        tr.engine = _E()
+        used = 300 * 7 + 4 + 500 + 4 + 64          # entries incl. alignment gaps (gaps get gradient 0 like in a real step)
+        for step in range(3):
+            gg = torch.Generator().manual_seed(100 * step + rank)
+            P.g32.zero_()
+            for k in P.index:
+                P.grad(k).copy_(torch.randn(P.grad(k).shape, generator=gg) * (5.0 if step == 1 else 0.05))
+            tr.reduce_gradients()
+            tr.optimizer_step()
+        results.append((P.p32.clone(), P.p16.clone(), tr.grad_norm.item(), tr.engine.latent_q.clone(), float(P.g32.abs().max())))
+    (p_ar, p16_ar, n_ar, lq_ar, g_ar), (p_z2, p16_z2, n_z2, lq_z2, g_z2) = results
+    q.put((rank, p_ar[:64].tolist(), float((p_ar - p_z2).abs().max()), bool(torch.equal(p16_ar, p16_z2)), n_ar, n_z2, bool(torch.equal(lq_ar, lq_z2)), g_ar, g_z2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_equals_all_reduce_world2_gloo():
+    """reduce-scatter -> sharded clip + update -> all-gather of master and working weights lands on the all-reduce (replicated update) result,
+    identical on both ranks; uneven shards (3 blocks over 2 ranks). The update arithmetic is a torch stand-in for the HIP kernel
+    (tests/test_train_ops_gpu.py::test_adamw_matches_torch covers the kernel itself)."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert len(res) == 2
+    for rank, head, diff, same16, n_ar, n_z2, same_lq, g_ar, g_z2 in res:
+        assert head == res[0][1]
+        assert diff <= 1e-7 and same16 and same_lq
+        assert abs(n_ar - n_z2) <= 1e-5 * n_ar and abs(n_ar - res[0][4]) <= 1e-6 * n_ar
+        assert g_ar == 0.0 and g_z2 == 0.0
