@@ -158,6 +158,25 @@ class InternVLAN1SftTrainer:
         self.step_idx += 1
         return lr
 
+    # ---------------------------------------------------------------------------------------------------------------- checkpoints
+    def state_dict(self, prefix: str = "model.") -> Dict[str, torch.Tensor]:
+        """trained tensors (fp32 master copies) under the names they have in an InternVLA-N1 checkpoint: the System-1 modules and
+        `latent_queries` are attributes of `InternVLAN1Model`, i.e. `model.<name>` (navdp_async: `model.navdp.<name>`)."""
+        p1 = prefix + ("navdp." if self.system1 == "navdp_async" else "")
+        return {(prefix + k if k == LQ else p1 + k): v for k, v in self.P.state_dict().items()}
+
+    def save_checkpoint(self, path: str):
+        """resume point: master weights, Adam moments, optimiser / schedule / mask counters (torch.save; every rank holds the same state)."""
+        torch.save(dict(store=self.P.checkpoint(), step_idx=self.step_idx, micro_idx=self.micro_idx, system1=self.system1), path)
+
+    def load_checkpoint(self, path: str):
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+        if ck["system1"] != self.system1:
+            raise ValueError(f"checkpoint of a {ck['system1']} head, trainer built for {self.system1}")
+        self.P.load_checkpoint(ck["store"])
+        self.step_idx, self.micro_idx = int(ck["step_idx"]), int(ck["micro_idx"])
+        self.engine.latent_q.copy_(self.P.w16(LQ).view(self.engine.latent_q.shape))
+
     def training_step(self, batch: dict, noise=None, t_index=None) -> torch.Tensor:
         loss = self.forward_backward(batch, noise, t_index)
         self.reduce_gradients()

@@ -41,3 +41,46 @@ def test_frozen_store_has_no_optimizer_state():
     names = _Params(P, F)
     assert names.trains("head.w") and not names.trains("rgb_model.w")
     assert names.w32("rgb_model.w").data_ptr() == F.p32.data_ptr() and names.grad("head.w").data_ptr() == P.g32.data_ptr()
+
+
+def test_checkpoint_resume_roundtrip(tmp_path):
+    """trainer.save_checkpoint / load_checkpoint: master weights, Adam moments and the optimiser / schedule / mask counters survive, the
+    engine's latent queries follow, and a mismatching trainable set is refused."""
+    import pytest
+
+    from internnav_amd.sft import ParamStore
+    from internnav_amd.trainer import LQ, InternVLAN1SftTrainer
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        P = ParamStore({"traj_dit.w": torch.randn(16, 8, generator=g), "cond_projector.0.bias": torch.randn(24, generator=g),
+                        LQ: torch.randn(1, 4, 32, generator=g)}, "cpu")
+        tr = object.__new__(InternVLAN1SftTrainer)
+        tr.P, tr.system1, tr.step_idx, tr.micro_idx = P, "nextdit_async", 0, 0
+
+        class _E:
+            latent_q = torch.zeros(4, 32, dtype=torch.bfloat16)
+        tr.engine = _E()
+        return tr
+
+    a = make(1)
+    a.P.m.normal_()
+    a.P.v.uniform_()
+    a.P.step_count, a.step_idx, a.micro_idx = 7, 7, 21
+    f = tmp_path / "ck.pt"
+    a.save_checkpoint(str(f))
+    b = make(2)
+    b.load_checkpoint(str(f))
+    for k in a.P.index:
+        assert torch.equal(a.P.w32(k), b.P.w32(k)) and torch.equal(a.P._view(a.P.m, k), b.P._view(b.P.m, k)) and torch.equal(a.P._view(a.P.v, k), b.P._view(b.P.v, k))
+    assert torch.equal(b.P.p16, b.P.p32.bfloat16()) and (b.P.step_count, b.step_idx, b.micro_idx) == (7, 7, 21)
+    assert torch.equal(b.engine.latent_q, a.P.w16(LQ).view(4, 32))
+    sd = a.state_dict()
+    assert set(sd) == {"model.traj_dit.w", "model.cond_projector.0.bias", "model.latent_queries"}
+    b.system1 = "navdp_async"
+    with pytest.raises(ValueError):
+        b.load_checkpoint(str(f))
+    c = make(3)
+    c.P = ParamStore({"other": torch.zeros(8)}, "cpu")
+    with pytest.raises(KeyError):
+        c.load_checkpoint(str(f))
