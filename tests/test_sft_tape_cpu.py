@@ -1,0 +1,84 @@
+"""CPU: the WIRING of the SFT tape (internnav_amd/sft.py) with torch stand-ins for the HIP kernel wrappers (tests/_cpu_kernels.py): every
+forward op and every backward closure of the NextDiT and NavDP loss graphs, against torch autograd of the fp32 oracle. The kernels themselves
+and the real step are tested on the GPU (tests/test_train_ops_gpu.py, tests/test_sft_gpu.py, tests/test_sft_navdp_gpu.py)."""
+import pytest
+import torch
+
+from tests import _cpu_kernels as K
+
+
+def _rel(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def _check(head, ref_grads, skip=(), tol=4e-2):
+    scale = max(g.norm().item() for g in ref_grads.values())
+    worst = ("", 0.0)
+    n = 0
+    for k, ref in ref_grads.items():
+        if any(s in k for s in skip):
+            continue
+        assert k in head.P.index, k
+        got = head.P.grad(k).view_as(ref)
+        if ref.norm().item() < 1e-6 * scale:
+            assert got.norm().item() < 1e-4 * scale, k
+            continue
+        e = _rel(got, ref)
+        n += 1
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < tol, worst          # bf16 activations between the stand-in ops, like the engine
+    return n
+
+
+def test_nextdit_tape_wiring(monkeypatch):
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+    from oracle import sft as O
+
+    K.install(monkeypatch)
+    sd0 = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
+    g = torch.Generator().manual_seed(0)
+    B, T = 1, 2
+    inp = dict(hq=torch.randn(B, 4, 3584, generator=g).bfloat16().float(), img=torch.rand(B, T, 224, 224, 3, generator=g),
+               poses=torch.randn(B, T, 32, 3, generator=g), vfn=torch.tensor([T]), noise=torch.randn(B * T, 32, 3, generator=g),
+               ti=torch.randint(0, 1000, (B * T,), generator=g))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    hq = inp["hq"].clone().requires_grad_(True)
+    loss = O.nextdit_sft_loss(sd, hq, inp["img"], inp["poses"], inp["vfn"], inp["noise"], inp["ti"])
+    loss.backward()
+    head = E.NextDiTSftHead(sd0, "cpu")
+    l2, dh = head.loss_and_grads(inp["hq"], inp["img"], inp["poses"], inp["vfn"], inp["noise"], inp["ti"])
+    assert abs(l2.item() - loss.item()) < 1e-2 * abs(loss.item())
+    assert _rel(dh.float().view_as(hq.grad), hq.grad) < 4e-2
+    assert _check(head, {k: v.grad for k, v in sd.items() if v.grad is not None}) > 550
+    # one fused optimiser step through the store moves every tensor that had a gradient and resets the gradients
+    before = head.P.p32.clone()
+    head.P.adamw_step(1e-3)
+    assert float(head.P.g32.abs().max()) == 0.0 and float((head.P.p32 - before).abs().max()) > 0 and torch.equal(head.P.p16, head.P.p32.bfloat16())
+
+
+def test_navdp_tape_wiring(monkeypatch):
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+    from oracle import sft as O
+
+    K.install(monkeypatch)
+    cfg = dict(S.N1_NAVDP_CFG, temporal_depth=2)         # two of the 16 decoder layers: the wiring is the same, the CPU time is not
+    spec = {k: v for k, v in S.n1_navdp_spec().items() if not k.startswith("decoder.layers.") or int(k.split(".")[2]) < 2}
+    sd0 = {k: v.float() for k, v in S.materialize(spec, 3).items()}
+    g = torch.Generator().manual_seed(1)
+    B, T = 1, 2
+    inp = dict(hq=torch.randn(B, 4, 3584, generator=g).bfloat16().float(), img=torch.rand(B, T, 224, 224, 3, generator=g),
+               dep=torch.rand(B, T, 224, 224, generator=g) * 5.0, poses=torch.randn(B, T, 32, 3, generator=g), vfn=torch.tensor([T]),
+               noise=torch.randn(B * T, 32, 3, generator=g), ts=torch.randint(0, 20, (B * T,), generator=g))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    hq = inp["hq"].clone().requires_grad_(True)
+    loss = O.navdp_sft_loss(sd, hq, inp["img"], inp["dep"], inp["poses"], inp["vfn"], inp["noise"], inp["ts"], cfg)
+    loss.backward()
+    head = E.NavDPSftHead(sd0, "cpu", cfg)
+    l2, dh = head.loss_and_grads(inp["hq"], inp["img"], inp["dep"], inp["poses"], inp["vfn"], inp["noise"], inp["ts"])
+    assert abs(l2.item() - loss.item()) < 1e-2 * abs(loss.item())
+    assert _rel(dh.float().view_as(hq.grad), hq.grad) < 8e-2     # bf16 PyTorch itself shows 3-5 % here (three ReLU / bf16 layers from 3584 to 384)
+    assert not any("rgb_model" in k for k in head.P.index) and any("rgb_model" in k for k in head.F.index)
+    assert _check(head, {k: v.grad for k, v in sd.items() if v.grad is not None}, skip=("rgb_model",), tol=8e-2) > 150
