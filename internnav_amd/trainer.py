@@ -80,6 +80,37 @@ class InternVLAN1SftTrainer:
         self.step_idx = 0
         self.micro_idx = 0
 
+    @classmethod
+    def from_pretrained(cls, path, device="cuda:0", max_seqs: int = 2, max_seq_len: int = 4096, max_patches: int = 2 * 10 * 784, **kw):
+        """trainer on an InternVLA-N1 checkpoint directory (HF safetensors shards + config.json, the layout `from_pretrained` of the
+        reference reads, internvla_n1_trainer.py:141-160): the frozen Qwen2.5-VL goes to the engine, the System-1 modules under `model.`
+        (`model.navdp.` for navdp_async) and `model.latent_queries` become the trainable store. Capacity arguments size the engine's
+        buffers (per-device batch, longest prompt incl. the <traj> tokens, patches of one batch)."""
+        import json
+        from pathlib import Path
+
+        from . import synthetic
+        from .policy import _ShardedCheckpoint, qwen_cfg_from_hf
+
+        p = Path(path)
+        files = sorted(p.glob("*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {p}: InternVLA-N1 checkpoints are HF safetensors shards")
+        cfgj = json.loads((p / "config.json").read_text()) if (p / "config.json").exists() else {}
+        qcfg = qwen_cfg_from_hf(cfgj)
+        system1 = cfgj.get("system1", "nextdit_async")
+        weights = _ShardedCheckpoint(files)
+        engine = QwenVLEngine(weights, qcfg, device, max_seqs=max_seqs, max_seq_len=max_seq_len, max_patches=max_patches)
+        frozen = set(synthetic.qwen_spec(qcfg))                          # visual.*, model.layers.*, embed / norm / lm_head, latent_queries
+        pre = "model.navdp." if "navdp" in system1 else "model."
+        sd = {k[len(pre):]: weights[k] for k in weights.keys() if k.startswith(pre) and k not in frozen}
+        if not sd:
+            raise KeyError(f"checkpoint {p} holds no System-1 parameters under '{pre}'")
+        sd[LQ] = weights["model.latent_queries"]
+        if "navdp" in system1:
+            kw.setdefault("s1_cfg", synthetic.N1_NAVDP_CFG)
+        return cls(engine, sd, device, system1=system1, **kw)
+
     def _dist(self) -> bool:
         return torch.distributed.is_available() and torch.distributed.is_initialized()
 

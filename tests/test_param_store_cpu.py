@@ -84,3 +84,32 @@ def test_checkpoint_resume_roundtrip(tmp_path):
     c.P = ParamStore({"other": torch.zeros(8)}, "cpu")
     with pytest.raises(KeyError):
         c.load_checkpoint(str(f))
+
+
+def test_trainer_from_pretrained_checkpoint_layout(tmp_path, monkeypatch):
+    """InternVLAN1SftTrainer.from_pretrained on an on-disk checkpoint in the reference's layout: the Qwen2.5-VL keys go to the (here stubbed)
+    engine, every System-1 tensor + latent_queries lands in the trainable store with the checkpoint's values, and state_dict() maps the
+    names back. (The engine itself needs the GPU; its checkpoint loading is covered by tests/test_agent_gpu.py.)"""
+    from internnav_amd import synthetic as S
+    from internnav_amd import trainer as TR
+
+    cfg = dict(S.QWEN_TEST_CFG, v_depth=1, v_fullatt=(0,), t_layers=1, vocab=64, image_token_id=50, traj_token_id=51, vision_start_id=52,
+               vision_end_id=53, eos_token_id=54)
+    sd_disk = S.write_checkpoint(tmp_path / "ck", cfg, "nextdit_async", seed=5, shards=3)
+
+    class _Engine:
+        def __init__(self, weights, qcfg, device, max_seqs, max_seq_len, max_patches):
+            assert qcfg["t_layers"] == 1 and qcfg["vocab"] == 64 and "model.layers.0.self_attn.q_proj.weight" in weights
+            self.latent_q = weights["model.latent_queries"].reshape(-1, qcfg["t_hidden"]).to(torch.bfloat16)
+            self.args = (max_seqs, max_seq_len, max_patches)
+
+    monkeypatch.setattr(TR, "QwenVLEngine", _Engine)
+    tr = TR.InternVLAN1SftTrainer.from_pretrained(tmp_path / "ck", device="cpu", max_seqs=2, max_seq_len=256, max_patches=1568, total_steps=10, dropout=0.0)
+    assert tr.engine.args == (2, 256, 1568) and tr.system1 == "nextdit_async"
+    s1_keys = {k for k in sd_disk if k.startswith("model.") and k[6:].startswith(("action_", "traj_dit", "cond_projector", "memory_encoder", "rgb_resampler", "rgb_model"))
+               and not k.endswith("mask_token")}
+    got = tr.state_dict()
+    assert set(got) == s1_keys | {"model.latent_queries"}
+    for k in got:
+        assert torch.equal(got[k], sd_disk[k].float().view_as(got[k])), k
+    assert not any(k.startswith(("layers.", "embed_tokens", "norm.")) for k in tr.P.index)        # nothing of the frozen LLM is trainable
