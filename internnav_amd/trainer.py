@@ -115,8 +115,10 @@ class InternVLAN1SftTrainer:
         return torch.distributed.is_available() and torch.distributed.is_initialized()
 
     # ---------------------------------------------------------------------------------------------------------------- one step
-    def forward_backward(self, batch: dict, noise: Optional[torch.Tensor] = None, t_index: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """loss of the micro-batch; gradients are accumulated into the flat store (call several times for gradient accumulation)."""
+    def forward_backward(self, batch: dict, noise: Optional[torch.Tensor] = None, t_index: Optional[torch.Tensor] = None,
+                         loss_scale: float = 1.0) -> torch.Tensor:
+        """loss of the micro-batch; gradients are accumulated into the flat store. Gradient accumulation over k micro-batches = k calls with
+        loss_scale = 1 / k (HF Trainer divides the loss by gradient_accumulation_steps before backward) and one optimizer_step()."""
         e, dev = self.engine, self.device
         ids = batch["input_ids"]
         t_s_pos = np.asarray(batch["t_s_pos"], dtype=np.int64)
@@ -136,12 +138,12 @@ class InternVLAN1SftTrainer:
             if t_index is None:
                 t_index = (torch.rand(B * Tn) * 1000).long()
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index,
-                                                seed=self._mask_seed())
+                                                loss_scale=loss_scale, seed=self._mask_seed())
         else:
             if t_index is None:
                 t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,))
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_depths"].to(dev), batch["traj_poses"],
-                                                batch["video_frame_num"], noise, t_index, seed=self._mask_seed())
+                                                batch["video_frame_num"], noise, t_index, loss_scale=loss_scale, seed=self._mask_seed())
         self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
         return loss
 

@@ -52,6 +52,13 @@ def test_nextdit_tape_wiring(monkeypatch):
     assert abs(l2.item() - loss.item()) < 1e-2 * abs(loss.item())
     assert _rel(dh.float().view_as(hq.grad), hq.grad) < 4e-2
     assert _check(head, {k: v.grad for k, v in sd.items() if v.grad is not None}) > 550
+    # gradient accumulation: two half-weighted passes over the same micro-batch add up to the full gradient (HF Trainer's loss / k)
+    full = head.P.g32.clone()
+    head.P.zero_grad()
+    for _ in range(2):
+        l_half, dh_half = head.loss_and_grads(inp["hq"], inp["img"], inp["poses"], inp["vfn"], inp["noise"], inp["ti"], loss_scale=0.5)
+    assert abs(l_half.item() - l2.item()) < 1e-6 and _rel(dh_half.float(), 0.5 * dh.float()) < 2e-2      # the reported loss is unscaled
+    assert _rel(head.P.g32, full) < 1e-2
     # one fused optimiser step through the store moves every tensor that had a gradient and resets the gradients
     before = head.P.p32.clone()
     head.P.adamw_step(1e-3)
