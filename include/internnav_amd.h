@@ -416,7 +416,7 @@ int ina_dit_attention(const ina_dit_attn_args* args, void* stream);
  *      The Conv1d / ConvTranspose1d themselves run on ina_gemm_bf16 over overlapping row windows (implicit GEMM); these three entry
  *      points are what remains: gn_mish = GroupNorm -> Mish [-> FiLM] [-> + residual] of a Conv1dBlock / ConditionalResidualBlock1D,
  *      pad_rows = zero the pad rows after a strided convolution (+ optional bias on the valid rows), ddim_step = DDIMScheduler.step
- *      (diffusers, eta 0, epsilon prediction, clip_sample) on the fp32 sample + refresh of the bf16 network input. */
+ *      (diffusers, eta 0, epsilon prediction, clip_sample, use_clipped_model_output 0|1) on the fp32 sample + refresh of the bf16 network input. */
 typedef struct ina_gn_mish_args {
     const void* X;          /* bf16 (f32 when x_f32) conv output, row (b, t) at b * in_seq_stride + t, row stride ldx */
     void* Y;                /* bf16 padded output [seqs, T + 2 pad, C], row stride ldy (pad rows are zeroed) */
@@ -443,7 +443,9 @@ typedef struct ina_ddim_step_args {
     void* Xin;              /* bf16 padded network input [seqs, T + 2 pad, ldx], channels [0, D) refreshed */
     int32_t seqs, T, D, pad, lde, ldx;
     float inv_sqrt_a, sqrt_b, sqrt_ap, sqrt_bp, clip;   /* 1/sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev), clip range (0 = off) */
-    int32_t _pad;
+    int32_t use_clipped_model_output;   /* diffusers DDIMScheduler.step(use_clipped_model_output=): 0 (the default, what
+                                           diffusion_unet_lowdim_policy.py:87-91 runs: step(model_output, t, trajectory, **{})) keeps the
+                                           network's eps in the direction term; 1 re-derives eps from the clipped x0 */
 } ina_ddim_step_args;
 int ina_ddim_step(const ina_ddim_step_args* args, void* stream);
 

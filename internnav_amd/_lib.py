@@ -176,7 +176,7 @@ class PadRowsArgs(C.Structure):
 
 class DdimStepArgs(C.Structure):
     _fields_ = [("eps", c_void_p), ("sample", c_void_p), ("Xin", c_void_p)] + [(n, c_int32) for n in ("seqs", "T", "D", "pad", "lde", "ldx")] + \
-               [(n, c_float) for n in ("inv_sqrt_a", "sqrt_b", "sqrt_ap", "sqrt_bp", "clip")] + [("_pad", c_int32)]
+               [(n, c_float) for n in ("inv_sqrt_a", "sqrt_b", "sqrt_ap", "sqrt_bp", "clip")] + [("use_clipped_model_output", c_int32)]
 
 
 class ResizeU8Args(C.Structure):

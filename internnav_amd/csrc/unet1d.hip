@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(PadRowsArgs p) {
     }
 }
 
-// DDIM step (eta = 0, epsilon prediction, clip_sample): x0 = clip((x - sqrt(1-a_t) eps) / sqrt(a_t)); eps' = (x - sqrt(a_t) x0) / sqrt(1-a_t)
-// when clipping is on; x <- sqrt(a_prev) x0 + sqrt(1-a_prev) eps'. Updates the fp32 sample in place and refreshes the bf16 network input.
+// DDIM step (eta = 0, epsilon prediction, clip_sample): x0 = clip((x - sqrt(1-a_t) eps) / sqrt(a_t)); the direction term uses the network's
+// eps as diffusers' DDIMScheduler.step does by default, or eps' = (x - sqrt(a_t) x0) / sqrt(1-a_t) re-derived from the clipped x0 when
+// use_clipped_model_output is set; x <- sqrt(a_prev) x0 + sqrt(1-a_prev) eps. Updates the fp32 sample in place and refreshes the bf16 network input.
 __global__ __launch_bounds__(256) void ddim_step_kernel(DdimStepArgs p) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // (sequence, t)
     if (i >= p.seqs * p.T) return;
@@ -137,10 +138,8 @@ __global__ __launch_bounds__(256) void ddim_step_kernel(DdimStepArgs p) {
         const float xv = x[d];
         float ev = e[d];
         float x0 = (xv - p.sqrt_b * ev) * p.inv_sqrt_a;
-        if (p.clip > 0.f) {
-            x0 = fminf(fmaxf(x0, -p.clip), p.clip);
-            ev = (xv - x0 / p.inv_sqrt_a) / p.sqrt_b;
-        }
+        if (p.clip > 0.f) x0 = fminf(fmaxf(x0, -p.clip), p.clip);
+        if (p.use_clipped_model_output) ev = (xv - x0 / p.inv_sqrt_a) / p.sqrt_b;
         const float nx = p.sqrt_ap * x0 + p.sqrt_bp * ev;
         x[d] = nx;
         xin[d] = (bf16)nx;

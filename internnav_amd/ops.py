@@ -571,11 +571,14 @@ def pad_rows(x: torch.Tensor, seqs: int, T: int, pad: int, bias: Optional[torch.
     return x
 
 
-def ddim_step(eps: torch.Tensor, sample: torch.Tensor, xin: torch.Tensor, seqs: int, T: int, D: int, pad: int, coefs, clip: float = 1.0):
-    """DDIMScheduler.step (eta 0) on the fp32 sample [seqs * T, D]; eps f32 in padded row indexing; xin bf16 padded network input."""
+def ddim_step(eps: torch.Tensor, sample: torch.Tensor, xin: torch.Tensor, seqs: int, T: int, D: int, pad: int, coefs, clip: float = 1.0,
+              use_clipped_model_output: bool = False):
+    """DDIMScheduler.step (eta 0) on the fp32 sample [seqs * T, D]; eps f32 in padded row indexing; xin bf16 padded network input.
+    use_clipped_model_output as diffusers' step() argument (default False: the direction term keeps the network's eps)."""
     assert eps.dtype == torch.float32 and sample.dtype == torch.float32 and sample.is_contiguous() and xin.dtype == torch.bfloat16
     a = _lib.DdimStepArgs()
     a.eps, a.sample, a.Xin, a.seqs, a.T, a.D, a.pad, a.lde, a.ldx = eps.data_ptr(), sample.data_ptr(), xin.data_ptr(), seqs, T, D, pad, eps.stride(0), xin.stride(0)
     a.inv_sqrt_a, a.sqrt_b, a.sqrt_ap, a.sqrt_bp, a.clip = [float(c) for c in coefs] + [float(clip)]
+    a.use_clipped_model_output = int(bool(use_clipped_model_output))
     _lib.check(_lib.lib().ina_ddim_step(C.byref(a), _stream()), "ddim_step")
     return sample

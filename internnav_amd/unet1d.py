@@ -233,8 +233,10 @@ class UNet1DHead:
         ops.linear(P[0][1][:rows], self.out_w, bias=self.out_b, out=self.eps[:rows])
 
     # ------------------------------------------------------------------------------------------------ sampler
-    def sample_traj(self, global_cond: torch.Tensor, x_init: torch.Tensor) -> torch.Tensor:
-        """global_cond bf16|f32 [B, G]; x_init f32 [B, S, T, D] (the initial noise) -> f32 [B, S, T, D] after the DDIM steps."""
+    def sample_traj(self, global_cond: torch.Tensor, x_init: torch.Tensor, use_clipped_model_output: bool = False) -> torch.Tensor:
+        """global_cond bf16|f32 [B, G]; x_init f32 [B, S, T, D] (the initial noise) -> f32 [B, S, T, D] after the DDIM steps.
+        `use_clipped_model_output` is the keyword diffusers' DDIMScheduler.step takes; the vendored policy passes none
+        (diffusion_unet_lowdim_policy.py:87-91: `step(model_output, t, trajectory, generator=generator, **kwargs)`), i.e. False."""
         B = global_cond.shape[0]
         assert B <= self.b_max and tuple(x_init.shape) == (B, self.S, self.T, self.D)
         nseq = B * self.S
@@ -246,7 +248,8 @@ class UNet1DHead:
         xin3[:, self.pads[0]: self.pads[0] + self.T, : self.D].copy_(x_init.reshape(nseq, self.T, self.D))     # data movement: noise into the padded input
         for i, t in enumerate(self.sched["timesteps"]):
             self._forward(nseq, i)
-            ops.ddim_step(self.eps, self.sample, self.xin, nseq, self.T, self.D, self.pads[0], self.sched["coefs"][i], clip=1.0)
+            ops.ddim_step(self.eps, self.sample, self.xin, nseq, self.T, self.D, self.pads[0], self.sched["coefs"][i], clip=1.0,
+                          use_clipped_model_output=use_clipped_model_output)
         return self.sample[: nseq * self.T].view(B, self.S, self.T, self.D)
 
 

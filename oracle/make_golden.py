@@ -302,17 +302,28 @@ def gold_unet1d(B=2):
     inp = W.unet1d_inputs(B, seed=4, cfg=cfg)
     S, T, D = cfg["sample_num"], cfg["predict_size"], cfg["input_dim"]
     g = inp["global_cond"].repeat_interleave(S, dim=0)
-    x = inp["x_init"].reshape(B * S, T, D).clone()
+    x0 = inp["x_init"].reshape(B * S, T, D).clone()
     sch = DDIMScheduler(num_train_timesteps=cfg["num_train_timesteps"])
     sch.set_timesteps(cfg["num_inference_steps"])
+    out, d, n_clipped = {}, 0.0, 0
     with torch.no_grad():
-        eps0 = net(x, int(sch.timesteps[0]), global_cond=g)
-        for t in sch.timesteps.tolist():
-            x = sch.step(net(x, t, global_cond=g), t, x).prev_sample
-        mine = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"])
+        eps0 = net(x0, int(sch.timesteps[0]), global_cond=g)
+        # the loop of diffusion_unet_lowdim_policy.py:77-91 with its **kwargs empty (the shipped behaviour: use_clipped_model_output absent
+        # = False) and, as a second fixture, with use_clipped_model_output=True
+        for flag in (False, True):
+            x = x0.clone()
+            for t in sch.timesteps.tolist():
+                r = sch.step(net(x, t, global_cond=g), t, x, **({"use_clipped_model_output": True} if flag else {}))
+                n_clipped += int((r.pred_original_sample.abs() >= 1.0).sum()) if not flag else 0
+                x = r.prev_sample
+            out[flag] = x.reshape(B, S, T, D).clone()
+            mine = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"], use_clipped_model_output=flag)
+            d = max(d, (out[flag] - mine).abs().max().item())
         mine_eps = o_u.unet_forward(sd, inp["x_init"].reshape(B * S, T, D), int(sch.timesteps[0]), g)
-    d = max((x.reshape(B, S, T, D) - mine).abs().max().item(), (eps0 - mine_eps).abs().max().item())
-    return dict(seed=4, B=B, eps0=eps0.reshape(B, S, T, D).clone(), samples=x.reshape(B, S, T, D).clone(), timesteps=sch.timesteps.clone(), oracle_max_abs_diff=d)
+    d = max(d, (eps0 - mine_eps).abs().max().item())
+    assert n_clipped > 0 and (out[False] - out[True]).abs().max().item() > 1e-3, "the fixture must exercise the clip (the two step variants differ only there)"
+    return dict(seed=4, B=B, eps0=eps0.reshape(B, S, T, D).clone(), samples=out[False], samples_use_clipped_model_output=out[True],
+                clipped_x0_elements=n_clipped, timesteps=sch.timesteps.clone(), oracle_max_abs_diff=d)
 
 
 def gold_vln_utils():

@@ -119,23 +119,30 @@ class FlowMatchEulerDiscreteScheduler:
 class DDIMScheduler(DDPMScheduler):
     """DDIM (Song et al. 2021), diffusers semantics as configured by the vendored diffusion_policy
     (config/train_diffusion_unet_ddim_lowdim_workspace.yaml:38-49): squaredcos_cap_v2 betas, epsilon prediction, clip_sample,
-    set_alpha_to_one=True, steps_offset=0, timestep_spacing 'leading', eta = 0 (deterministic: no noise term).  "parity unpinned"."""
+    set_alpha_to_one=True, steps_offset=0, timestep_spacing 'leading', eta = 0 (deterministic: no noise term).  "parity unpinned".
+
+    `step(..., use_clipped_model_output=False)` is diffusers' signature and default: the vendored policy calls
+    `self.noise_scheduler.step(model_output, t, trajectory, generator=generator, **kwargs)` with empty kwargs
+    (diffusion_policy/policy/diffusion_unet_lowdim_policy.py:87-91) and the config sets no such flag, so the direction term keeps
+    the NETWORK's epsilon even when x0 was clipped; only `True` re-derives epsilon from the clipped x0 (DDIMScheduler.step, "5./6.")."""
 
     def coefficients(self, t: int):
         """(1/sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev)): x0 = clip((x - sqrt(1-abar_t) eps) / sqrt(abar_t));
-        eps' = (x - sqrt(abar_t) x0) / sqrt(1-abar_t) (re-derived from the clipped x0); x_prev = sqrt(abar_prev) x0 + sqrt(1-abar_prev) eps'."""
+        x_prev = sqrt(abar_prev) x0 + sqrt(1-abar_prev) eps, with eps the model output (default) or, under use_clipped_model_output,
+        eps' = (x - sqrt(abar_t) x0) / sqrt(1-abar_t) re-derived from the clipped x0."""
         n_inf = self.num_inference_steps or self.config.num_train_timesteps
         prev_t = t - self.config.num_train_timesteps // n_inf
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one          # set_alpha_to_one
         return float(1.0 / a_t.sqrt()), float((1 - a_t).sqrt()), float(a_prev.sqrt()), float((1 - a_prev).sqrt())
 
-    def step(self, model_output, timestep, sample, eta: float = 0.0, **_):
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False, **_):
         assert eta == 0.0
         inv_sqrt_a, sqrt_b, sqrt_ap, sqrt_bp = self.coefficients(int(timestep))
         x0 = (sample - sqrt_b * model_output) * inv_sqrt_a
         eps = model_output
         if self.config.clip_sample:
             x0 = x0.clamp(-self.config.clip_sample_range, self.config.clip_sample_range)
+        if use_clipped_model_output:
             eps = (sample - x0 / inv_sqrt_a) / sqrt_b
         return SimpleNamespace(prev_sample=sqrt_ap * x0 + sqrt_bp * eps, pred_original_sample=x0)

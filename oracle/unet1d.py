@@ -75,8 +75,9 @@ def unet_forward(sd, sample, timestep, global_cond, n_levels=3):
     return x.transpose(1, 2)
 
 
-def ddim_sample(sd, global_cond, x_init, num_train_timesteps=100, num_inference_steps=10):
-    """global_cond [B, G] (one per env), x_init [B, S, T, D] -> [B, S, T, D]: every env's S samples share its condition."""
+def ddim_sample(sd, global_cond, x_init, num_train_timesteps=100, num_inference_steps=10, use_clipped_model_output=False):
+    """global_cond [B, G] (one per env), x_init [B, S, T, D] -> [B, S, T, D]: every env's S samples share its condition.
+    The loop of diffusion_unet_lowdim_policy.py:77-91 (conditional_sample); use_clipped_model_output is one of its **kwargs (default: absent)."""
     B, S, T, D = x_init.shape
     sch = DDIMScheduler(num_train_timesteps=num_train_timesteps)
     sch.set_timesteps(num_inference_steps)
@@ -84,5 +85,5 @@ def ddim_sample(sd, global_cond, x_init, num_train_timesteps=100, num_inference_
     g = global_cond.float().repeat_interleave(S, dim=0)
     for t in sch.timesteps.tolist():
         eps = unet_forward(sd, x, t, g)
-        x = sch.step(eps, t, x).prev_sample
+        x = sch.step(eps, t, x, use_clipped_model_output=use_clipped_model_output).prev_sample
     return x.reshape(B, S, T, D)

@@ -136,9 +136,12 @@ def test_unet1d_matches_vendored_reference():
     with torch.no_grad():
         eps = o_u.unet_forward(sd, inp["x_init"].reshape(B * S, T, D), int(gold["timesteps"][0]), inp["global_cond"].repeat_interleave(S, dim=0))
         out = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"])
+        out_c = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"], use_clipped_model_output=True)
     assert (eps.reshape(B, S, T, D) - gold["eps0"]).abs().max().item() < 1e-4
     assert (out - gold["samples"]).abs().max().item() < 1e-4
-    assert float(out.abs().max()) <= 1.0 + 1e-6       # clip_sample
+    assert (out_c - gold["samples_use_clipped_model_output"]).abs().max().item() < 1e-4
+    assert gold["clipped_x0_elements"] > 0 and (gold["samples"] - gold["samples_use_clipped_model_output"]).abs().max().item() > 1e-3   # the clip is exercised
+    assert float(out.abs().max()) <= 1.0 + 1e-6       # clip_sample: the last step (alpha_prev = 1) returns the clipped x0
 
 
 def test_ddim_scheduler_known_properties():
@@ -157,6 +160,15 @@ def test_ddim_scheduler_known_properties():
         assert torch.allclose(prev, sch.add_noise(x0, eps, torch.tensor(t - 10)), atol=1e-5)
     xt = sch.add_noise(x0, eps, torch.tensor(0))
     assert torch.allclose(sch.step(eps, 0, xt).prev_sample, x0, atol=1e-5)     # set_alpha_to_one: the last step returns x0
+    # diffusers' default (use_clipped_model_output=False, what diffusion_unet_lowdim_policy.py:87-91 runs): when the clip is active the
+    # direction term keeps the model's eps; True re-derives it from the clipped x0. Both written out from DDIMScheduler.step's formulas.
+    big = 3.0 * torch.randn(4, 8, 3, generator=g)
+    a_t, a_p = sch.alphas_cumprod[40], sch.alphas_cumprod[30]
+    x0c = ((big - (1 - a_t).sqrt() * eps) / a_t.sqrt()).clamp(-1, 1)
+    assert (x0c.abs() == 1).any()
+    assert torch.allclose(sch.step(eps, 40, big).prev_sample, a_p.sqrt() * x0c + (1 - a_p).sqrt() * eps, atol=1e-5)
+    eps_c = (big - a_t.sqrt() * x0c) / (1 - a_t).sqrt()
+    assert torch.allclose(sch.step(eps, 40, big, use_clipped_model_output=True).prev_sample, a_p.sqrt() * x0c + (1 - a_p).sqrt() * eps_c, atol=1e-5)
 
 
 def test_sft_loss_and_gradients_match_reference_autograd():

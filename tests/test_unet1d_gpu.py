@@ -51,6 +51,12 @@ def test_unet1d_ddim_vs_vendored_reference_fixture(built_lib):
     print(f"unet1d ddim samples: mean|err| {d.mean():.3e} max|err| {d.max():.3e} (range [-1, 1])")
     assert d.mean().item() < 2e-3 and d.max().item() < 1e-1     # clip_sample: a sample near +-1 can flip sides of the clip within bf16 noise
     assert eng.sched["timesteps"] == gold["timesteps"].tolist()
+    # the other value of diffusers' step(use_clipped_model_output=) has its own fixture
+    out_c = eng.sample_traj(inp["global_cond"].to(DEV), inp["x_init"].to(DEV), use_clipped_model_output=True).float().cpu()
+    dc = (out_c - gold["samples_use_clipped_model_output"]).abs()
+    print(f"unet1d ddim samples (use_clipped_model_output): mean|err| {dc.mean():.3e} max|err| {dc.max():.3e}")
+    assert dc.mean().item() < 2e-3 and dc.max().item() < 1e-1
+    assert (out - out_c).abs().max().item() > 1e-2           # the fixture clips: the two variants are different trajectories
     # first noise prediction alone (the network without the sampler)
     nseq = B * eng.S
     eng.sample[: nseq * eng.T].copy_(inp["x_init"].reshape(-1, 3).to(DEV))
