@@ -10,6 +10,14 @@ HTTP AgentServer requires). Differences, all behind that contract:
   * an S2 failure of an env (any exception out of its s2_step, e.g. an unparsable pixel goal) resets that env's policy and retries
     ONCE with look_down=False, then falls back to STOP ([0]) - the reference's handler (:168-189). Configuration / engine errors
     (`CapacityError`, `EngineError`) are NOT policy failures: they propagate to the caller instead of ending episodes silently.
+    A failure of a whole batched generate() is first re-run env by env, so only envs that fail on their own are reset.
+Pinned by execution: tests/test_agent_trace.py replays tests/golden/agent_trace.json - 8 scripted scenarios run through the reference's
+own InternVLAN1Agent.step + InternVLAN1Net (oracle/make_golden_agent.py) - and demands the same action every step and the same chat
+text / image bytes / System-1 inputs at every model call. Two documented divergences, both where the reference itself breaks:
+  * an answer with neither digits nor arrows: the reference's s2_step returns output_action=[] and its main thread raises IndexError
+    out of step() (:282); here it counts as an S2 failure (retry once, then STOP);
+  * both attempts of the FIRST System-2 call of an episode failing: the reference's main thread then waits forever (the STOP it
+    stores keeps idx = -1, so S2Output.validate() never turns true, :272-274); here the env STOPs.
 The per-env dual-system state machine (sync / partial_async cadence, look-down turn, action queue, dual_forward_step
 accounting) follows internvla_n1_agent.py:210-241 and :243-356 line by line.
 
@@ -31,6 +39,7 @@ from .policy import InternVLAN1ModelConfig, InternVLAN1Net, S1Output, S2Output
 from .runtime import CapacityError
 
 _FATAL = (CapacityError, EngineError, MemoryError, KeyboardInterrupt)
+_PENDING = object()      # marker for "this env's answer is a pixel goal, its latents come with the chunk's generate_latents call"
 
 
 class _EnvState:
@@ -201,8 +210,12 @@ class InternVLAN1Agent:
         for items_all in groups.values():
             model = items_all[0][0].policy.model
             cap = getattr(getattr(model, "qwen", None), "B_max", None) or len(items_all)
-            for c0 in range(0, len(items_all), cap):
-                items = items_all[c0:c0 + cap]
+            singles = []
+            chunks = [items_all[c0:c0 + cap] for c0 in range(0, len(items_all), cap)]
+            while chunks or singles:
+                if not chunks:
+                    chunks, singles = singles, []
+                items = chunks.pop(0)
                 try:
                     lens = [int(it[2]["input_ids"].shape[1]) for it in items]
                     ids = torch.zeros(len(items), max(lens), dtype=torch.long)
@@ -226,18 +239,19 @@ class InternVLAN1Agent:
                 except _FATAL:
                     raise
                 except Exception as ex:  # noqa: BLE001
-                    failed += [(e, o, ex) for e, o, _ in items]
+                    if len(items) > 1:
+                        # the reference's handler is per env (:156-189): one bad env must not wipe the episode history of the others
+                        # that happened to share its batch -> re-run this chunk's envs one at a time, only those that fail alone fail
+                        singles += [[it] for it in items]
+                    else:
+                        failed += [(e, o, ex) for e, o, _ in items]
                     continue
-                lat_cache = {}
-
-                def latents(seqs=seqs, pv=pv, grid=grid, lat_cache=lat_cache, extra=extra):
-                    if "v" not in lat_cache:
-                        lat_cache["v"] = model.generate_latents(seqs, pv, grid, **extra)
-                    return lat_cache["v"]
-
+                # pixel-goal rows get their latents from ONE generate_latents call over the chunk (reference: one call per env, only
+                # when the answer holds a pixel goal, internvla_n1_policy.py:183-192)
+                pending = []
                 for k, (e, o, inputs) in enumerate(items):
                     try:
-                        so = e.policy.finish_s2(inputs, seqs[k:k + 1], lambda k=k: latents()[k:k + 1])
+                        so = e.policy.finish_s2(inputs, seqs[k:k + 1], lambda: _PENDING)
                     except _FATAL:
                         raise
                     except Exception as ex:  # noqa: BLE001 - e.g. IndexError on a one-number pixel goal (internvla_n1_policy.py:187)
@@ -247,6 +261,12 @@ class InternVLAN1Agent:
                     so.rgb_memory, so.depth_memory = o["rgb"], o["depth"]
                     so.is_infering = False
                     e.s2_output = so
+                    if so.output_latent is _PENDING:
+                        pending.append((k, so))
+                if pending:
+                    lat = model.generate_latents(seqs, pv, grid, rows=[k for k, _ in pending], **extra)
+                    for j, (_, so) in enumerate(pending):
+                        so.output_latent = lat[j:j + 1]
         if not failed:
             return
         for e, o, ex in failed:

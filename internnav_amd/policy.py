@@ -291,10 +291,14 @@ class InternVLAN1ForCausalLM:
         call encoded; only filled when generate() was given `cached_image_embeds` (i.e. by callers that keep a frame cache)."""
         return getattr(self, "_fresh", {})
 
-    def generate_latents(self, output_ids, pixel_values, image_grid_thw, cached_image_embeds: Optional[list] = None):
+    def generate_latents(self, output_ids, pixel_values, image_grid_thw, cached_image_embeds: Optional[list] = None, rows=None):
         """[B, N_QUERY, 3584] hidden states of the latent trajectory queries (internvla_n1.py:320-347). When called right after
         generate() on its own output (the reference's only usage, internvla_n1_policy.py:191) the KV cache is reused: the queries
-        are placed behind each sequence's last kept token; otherwise the full prompt is re-run."""
+        are placed behind each sequence's last kept token; otherwise the full prompt is re-run.
+        rows (extension for the batched agent): the batch rows whose answer was a pixel goal - only their latents are returned
+        ([len(rows), N_QUERY, 3584]); the pass itself streams the weights once whatever the number of rows."""
+        if rows is not None:
+            return self.generate_latents(output_ids, pixel_values, image_grid_thw, cached_image_embeds)[torch.as_tensor(list(rows), dtype=torch.long, device=self.device)]
         g = getattr(self, "_gen", None)
         if g is not None and output_ids.shape[0] == g["tokens"].shape[0]:
             pl, lens, toks = g["prompt_lens"], g["lens"], g["tokens"]
@@ -575,7 +579,7 @@ class InternVLAN1Net:
         if re.search(r"\d", self.llm_output):
             coord = [int(c) for c in re.findall(r"\d+", self.llm_output)]
             out.output_pixel = np.array([int(coord[1]), int(coord[0])])   # a one-number answer raises IndexError like the reference (:187) -> the agent's retry path
-            out.output_latent = latents_fn()
+            out.output_latent = latents_fn()      # the batched agent passes a marker here and fills the latents of all pixel-goal rows in one call
         else:
             out.output_action = self.parse_actions(self.llm_output)
             if not out.output_action:

@@ -188,7 +188,7 @@ class _FakeModel:
     device = torch.device("cpu")
 
     def __init__(self, answers):
-        self.answers, self.batches, self.fail_b, self.masks, self.fail_next = answers, [], None, [], 0
+        self.answers, self.batches, self.fail_b, self.masks, self.fail_next, self.fail_text = answers, [], None, [], 0, None
 
     def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, **kw):
         from types import SimpleNamespace
@@ -196,7 +196,8 @@ class _FakeModel:
         B, S = input_ids.shape
         self.batches.append((B, S))
         self.masks.append(kw.get("attention_mask"))
-        if self.fail_b == B or self.fail_next > 0:
+        bad_row = self.fail_text is not None and any(self.fail_text in "".join(chr(int(v)) for v in row) for row in input_ids)
+        if self.fail_b == B or self.fail_next > 0 or bad_row:
             self.fail_next -= 1
             raise RuntimeError("injected S2 failure")
         ans = [self.answers.pop(0) for _ in range(B)]
@@ -209,8 +210,8 @@ class _FakeModel:
             seqs[b, lens[b]:lens[b] + len(a)] = torch.tensor([ord(c) for c in a])
         return SimpleNamespace(sequences=seqs)
 
-    def generate_latents(self, seqs, pv, grid):
-        return torch.zeros(seqs.shape[0], 4, 8)
+    def generate_latents(self, seqs, pv, grid, rows=None):
+        return torch.zeros(seqs.shape[0] if rows is None else len(rows), 4, 8)
 
     def generate_traj(self, traj_latents=None, images_dp=None, depths_dp=None):
         B = traj_latents.shape[0]
@@ -238,18 +239,32 @@ def test_agent_runs_ragged_s2_batches_retries_once_and_falls_back_to_stop():
     assert m is not None and m.sum(1).tolist() == sorted(m.sum(1).tolist()) and int(m.sum(1).max()) == model.batches[0][1] > int(m.sum(1).min())
     assert [o["action"] for o in out][:2] == [[1], [2]]
     assert out[2]["action"] == [1]          # pixel goal "12 34" -> latent -> System-1 -> forward
-    # one transient failure: the envs are reset and the retry (look_down=False) succeeds
+    # one transient failure of the batched call: its envs are re-run one at a time (a bad env must not wipe the history of the envs that
+    # shared its batch - the reference's handler is per env) and succeed without any reset
     for e in ag.envs:
         e.s2_output.output_action = e.s2_output.output_latent = e.s2_output.output_pixel = None
+    hist = [len(e.policy.rgb_list) for e in ag.envs]
     model.answers, model.fail_next = ["→", "→", "→"], 1
     out = ag.step(obs)
-    assert [o["action"] for o in out] == [[3], [3], [3]] and ag.s2_failures == 0 and len(model.batches) == 3
-    # a persistent failure: STOP for every env of the call, counted
+    assert [o["action"] for o in out] == [[3], [3], [3]] and ag.s2_failures == 0
+    assert model.batches[1:] == [(3, model.batches[1][1]), (1, model.batches[2][1]), (1, model.batches[3][1]), (1, model.batches[4][1])]
+    assert [len(e.policy.rgb_list) for e in ag.envs] == [h + 1 for h in hist]          # histories kept
+    # ONE env keeps failing (its single-env re-run fails too): only that env is reset, retried once without look-down and STOPped
     for e in ag.envs:
         e.s2_output.output_action = e.s2_output.output_latent = e.s2_output.output_pixel = None
-    model.answers, model.fail_b = ["→", "→", "→"], 3
+    hist = [len(e.policy.rgb_list) for e in ag.envs]
+    n0 = len(model.batches)
+    model.answers, model.fail_b, model.fail_text = ["←", "←"], 3, "wall"
     out = ag.step(obs)
-    assert [o["action"] for o in out] == [[0], [0], [0]] and ag.s2_failures == 3
+    assert [o["action"] for o in out] == [[2], [0], [2]] and ag.s2_failures == 1
+    assert [b for b, _ in model.batches[n0:]] == [3, 1, 1, 1, 1]                       # batch, three singles (one fails), its retry
+    assert [len(e.policy.rgb_list) for e in ag.envs] == [hist[0] + 1, 0, hist[2] + 1]  # only the failing env lost its history (reset twice)
+    # a persistent failure of every call: STOP for every env, counted
+    for e in ag.envs:
+        e.s2_output.output_action = e.s2_output.output_latent = e.s2_output.output_pixel = None
+    model.answers, model.fail_b, model.fail_text, model.fail_next = [], None, None, 10 ** 6
+    out = ag.step(obs)
+    assert [o["action"] for o in out] == [[0], [0], [0]] and ag.s2_failures == 4
 
 
 def test_bench_accounting_is_consistent():

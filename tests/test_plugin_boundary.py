@@ -81,9 +81,9 @@ class _ScriptedModel:
         out = torch.stack([torch.cat([o, torch.zeros(n - len(o), dtype=torch.long)]) for o in out])
         return SimpleNamespace(sequences=torch.cat([input_ids, out], 1))
 
-    def generate_latents(self, ids, pv, grid):
+    def generate_latents(self, ids, pv, grid, rows=None):
         self.calls.append(("latents", ids.shape[0]))
-        return torch.zeros(ids.shape[0], 4, 8)
+        return torch.zeros(ids.shape[0] if rows is None else len(rows), 4, 8)
 
     def generate_traj(self, traj_latents=None, images_dp=None, depths_dp=None):
         self.calls.append(("traj", traj_latents.shape[0], tuple(images_dp.shape)))

@@ -261,8 +261,8 @@ def test_agent_step_with_frame_preprocessor_end_to_end():
             toks = torch.tensor([[ord(c) for c in a] + [0] * (n - len(a)) for a in ans])
             return SimpleNamespace(sequences=torch.cat([input_ids, toks], 1))
 
-        def generate_latents(self, seqs, pv, grid):
-            return torch.zeros(seqs.shape[0], 4, 8)
+        def generate_latents(self, seqs, pv, grid, rows=None):
+            return torch.zeros(seqs.shape[0] if rows is None else len(rows), 4, 8)
 
         def generate_traj(self, traj_latents=None, images_dp=None, depths_dp=None):
             self.s1_inputs.append((images_dp.clone(), depths_dp.clone()))
