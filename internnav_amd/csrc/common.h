@@ -52,7 +52,9 @@ __device__ __forceinline__ uint32_t ina_fmix32(uint32_t h) {
     return h;
 }
 __device__ __forceinline__ uint32_t ina_hash(uint32_t seed, uint64_t idx) {
-    const uint32_t h = ina_fmix32(seed ^ (uint32_t)idx);
+    // the seed goes through its own finaliser round before it meets the index: with a plain seed ^ idx two seeds give the same field
+    // under an index permutation (hash(s1, i) == hash(s2, i ^ s1 ^ s2)), i.e. masks of different sites / steps would not be independent
+    const uint32_t h = ina_fmix32(ina_fmix32(seed) + 0x9E3779B9u * (uint32_t)idx);
     return ina_fmix32(h + 0x9E3779B9u * (uint32_t)(idx >> 32) + 0x7F4A7C15u);
 }
 

@@ -37,6 +37,13 @@ def cosine_with_min_lr(step: int, total_steps: int, warmup_steps: int, lr: float
     return lr * max(0.0, factor * (1 - rate) + rate)
 
 
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
 def shard_bounds(numel: int, world: int, rank: int, align: int = 1024):
     """[lo, hi) of rank's slice of a flat buffer whose length is a multiple of `align`: equal slices of whole `align` blocks, the last
     ranks may be shorter / empty (ZeRO-2 partition of the flat gradient / moment buffers)."""
@@ -79,6 +86,14 @@ class InternVLAN1SftTrainer:
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.step_idx = 0
         self.micro_idx = 0
+        if self.world > 1 and self.zero2:
+            # ZeRO-2 (the reference's deepspeed zero2.json, train_dual_system.sh): optimiser state lives on its owner rank only
+            self.P.shard_moments(*shard_bounds(self.P.numel, self.world, self.rank))
+        # the draws the reference makes inside forward (torch.randn / torch.rand, internvla_n1.py:261-264, navdp.py:163-175) come from
+        # trainer-owned generators, seeded per (seed, rank) and saved with the checkpoint: a resumed run continues the same streams
+        s = _splitmix64(_splitmix64(seed) ^ (self.rank + 1))
+        self.gen_dev = torch.Generator(device=self.device).manual_seed(s & 0x7FFFFFFFFFFFFFFF)
+        self.gen_cpu = torch.Generator().manual_seed((s >> 1) & 0x7FFFFFFFFFFFFFFF)
 
     @classmethod
     def from_pretrained(cls, path, device="cuda:0", max_seqs: int = 2, max_seq_len: int = 4096, max_patches: int = 2 * 10 * 784, **kw):
@@ -133,23 +148,24 @@ class InternVLAN1SftTrainer:
         hq = self.lq.forward(state)
         Tn = batch["traj_images"].shape[1]
         if noise is None:            # internvla_n1.py:261-264 / navdp.py:163-175 (the reference draws inside forward)
-            noise = torch.randn(B * Tn, *batch["traj_poses"].shape[2:], device=dev)
+            noise = torch.randn(B * Tn, *batch["traj_poses"].shape[2:], device=dev, generator=self.gen_dev)
         if self.system1 == "nextdit_async":
             if t_index is None:
-                t_index = (torch.rand(B * Tn) * 1000).long()
+                t_index = (torch.rand(B * Tn, generator=self.gen_cpu) * 1000).long()
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index,
                                                 loss_scale=loss_scale, seed=self._mask_seed())
         else:
             if t_index is None:
-                t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,))
+                t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,), generator=self.gen_cpu)
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_depths"].to(dev), batch["traj_poses"],
                                                 batch["video_frame_num"], noise, t_index, loss_scale=loss_scale, seed=self._mask_seed())
         self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
         return loss
 
     def _mask_seed(self) -> int:
+        """dropout-mask seed of this micro-step: (seed, rank, micro_idx) hashed together (a linear mix collides across ranks / steps)."""
         self.micro_idx += 1
-        return (self.seed * 2654435761 + self.rank * 97 + self.micro_idx) & 0x7FFFFFFF
+        return _splitmix64(_splitmix64(_splitmix64(self.seed) ^ (self.rank + 1)) ^ self.micro_idx) & 0x7FFFFFFF
 
     def reduce_gradients(self):
         """sum the flat gradient bucket over the data-parallel ranks (the 1 / world average is folded into the AdamW launch)."""
@@ -174,7 +190,7 @@ class InternVLAN1SftTrainer:
             torch.distributed.all_reduce(parts, group=self.pg)          # global gradient norm from the shards' partial sums
             P.step_count += 1
             if hi > lo:
-                T.adamw(P.p32[lo:hi], P.g32[lo:hi], P.m[lo:hi], P.v[lo:hi], lr, self.betas[0], self.betas[1], self.eps, self.wd, P.step_count,
+                T.adamw(P.p32[lo:hi], P.g32[lo:hi], P.m, P.v, lr, self.betas[0], self.betas[1], self.eps, self.wd, P.step_count,
                         p_bf16=P.p16[lo:hi], sumsq_parts=parts, max_norm=self.max_norm, grad_scale=1.0 / self.world, norm_out=self.grad_norm)
             P.g32.zero_()
             per = shard_bounds(P.numel, self.world, 0)[1]
@@ -193,14 +209,34 @@ class InternVLAN1SftTrainer:
 
     # ---------------------------------------------------------------------------------------------------------------- checkpoints
     def state_dict(self, prefix: str = "model.") -> Dict[str, torch.Tensor]:
-        """trained tensors (fp32 master copies) under the names they have in an InternVLA-N1 checkpoint: the System-1 modules and
-        `latent_queries` are attributes of `InternVLAN1Model`, i.e. `model.<name>` (navdp_async: `model.navdp.<name>`)."""
+        """TRAINED tensors only (fp32 master copies) under the names they have in an InternVLA-N1 checkpoint: the System-1 modules and
+        `latent_queries` are attributes of `InternVLAN1Model`, i.e. `model.<name>` (navdp_async: `model.navdp.<name>`). Frozen tensors
+        (the Qwen2.5-VL weights, navdp's rgb_model, DINOv2 mask_token) are not in it: an export merges this over the checkpoint it
+        started from."""
         p1 = prefix + ("navdp." if self.system1 == "navdp_async" else "")
         return {(prefix + k if k == LQ else p1 + k): v for k, v in self.P.state_dict().items()}
 
+    def _gather_flat(self, shard: torch.Tensor) -> torch.Tensor:
+        """all-gather of a ZeRO-2 shard into the full flat buffer (padded like the p32 / p16 all-gather of optimizer_step)."""
+        per = shard_bounds(self.P.numel, self.world, 0)[1]
+        mine = torch.zeros(per, dtype=shard.dtype, device=self.device)
+        mine[: shard.numel()].copy_(shard)
+        full = torch.empty(per * self.world, dtype=shard.dtype, device=self.device)
+        torch.distributed.all_gather_into_tensor(full, mine, group=self.pg)
+        return full[: self.P.numel]
+
+    def checkpoint(self) -> dict:
+        """resume point: master weights, Adam moments (ZeRO-2: all-gathered from their owner ranks - a COLLECTIVE, every rank calls it),
+        optimiser / schedule / mask counters and the state of this rank's noise / time-step generators. Weights, moments and counters
+        are the same on every rank; `rng` is per rank (each rank saves its own file, or rank 0's file + fresh streams elsewhere)."""
+        sharded = (self.P.m_lo, self.P.m_hi) != (0, self.P.numel)
+        return dict(store=self.P.checkpoint(self._gather_flat if sharded else None), step_idx=self.step_idx, micro_idx=self.micro_idx,
+                    system1=self.system1, rng=dict(rank=self.rank, dev=self.gen_dev.get_state().cpu(), cpu=self.gen_cpu.get_state()))
+
     def save_checkpoint(self, path: str):
-        """resume point: master weights, Adam moments, optimiser / schedule / mask counters (torch.save; every rank holds the same state)."""
-        torch.save(dict(store=self.P.checkpoint(), step_idx=self.step_idx, micro_idx=self.micro_idx, system1=self.system1), path)
+        """`checkpoint()` written with torch.save (collective under ZeRO-2: all ranks call it, each with its own path or only rank 0 writing
+        what it got back from `checkpoint()`)."""
+        torch.save(self.checkpoint(), path)
 
     def load_checkpoint(self, path: str):
         ck = torch.load(path, map_location="cpu", weights_only=True)
@@ -208,6 +244,9 @@ class InternVLAN1SftTrainer:
             raise ValueError(f"checkpoint of a {ck['system1']} head, trainer built for {self.system1}")
         self.P.load_checkpoint(ck["store"])
         self.step_idx, self.micro_idx = int(ck["step_idx"]), int(ck["micro_idx"])
+        if "rng" in ck and int(ck["rng"]["rank"]) == self.rank:          # another rank's file: keep this rank's own streams
+            self.gen_dev.set_state(ck["rng"]["dev"])
+            self.gen_cpu.set_state(ck["rng"]["cpu"])
         self.engine.latent_q.copy_(self.P.w16(LQ).view(self.engine.latent_q.shape))
 
     def training_step(self, batch: dict, noise=None, t_index=None) -> torch.Tensor:

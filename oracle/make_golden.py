@@ -438,6 +438,30 @@ def gold_preprocess():
                 oracle_max_abs_diff=float(max(diffs)))
 
 
+def _count_dropout_sites(module, fn):
+    """how many times a forward of `fn` in train() mode passes an ACTIVE dropout: calls of nn.Dropout modules with p > 0 and of
+    nn.MultiheadAttention modules built with dropout > 0 (attention-probability dropout). The SFT tape must draw one mask per site."""
+    import torch.nn as nn
+
+    counts = {"dropout": 0, "attention": 0}
+    hooks = []
+    for sub_m in module.modules():
+        if isinstance(sub_m, nn.Dropout) and sub_m.p > 0:
+            hooks.append(sub_m.register_forward_hook(lambda *_: counts.__setitem__("dropout", counts["dropout"] + 1)))
+        elif isinstance(sub_m, nn.MultiheadAttention) and sub_m.dropout > 0:
+            hooks.append(sub_m.register_forward_hook(lambda *_: counts.__setitem__("attention", counts["attention"] + 1)))
+    was = module.training
+    module.train()
+    try:
+        with torch.no_grad():
+            fn()
+    finally:
+        module.train(was)
+        for h in hooks:
+            h.remove()
+    return counts
+
+
 def gold_sft(B=1, T=2):
     """SFT loss of the nextdit_async branch (internvla_n1.py:222-286) through the reference's own System-1 modules under autograd
     (dropout off: .eval()), transcribed line by line; the noise / time-step draws of :261-264 are seeded inputs. Saves the loss, the
@@ -529,7 +553,9 @@ def gold_sft(B=1, T=2):
         samples[k] = dict(norm=gr.norm().item(), idx=pick, val=flat[pick].clone())
     worst = max(worst, ((hidden_q.grad - hq_o.grad).abs().max() / hidden_q.grad.abs().max()).item())
     no_grad = sorted(k for k, p in m.named_parameters() if p.grad is None)
-    return dict(B=B, T=T, seed=6, weights_seed=6, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples, params_without_grad=no_grad,
+    sites = _count_dropout_sites(m, lambda: m.traj_dit(x=action_features, timestep=timesteps, z_latents=torch.cat(
+        [m.rgb_resampler(torch.cat([images_dp_feat.flatten(1, 2), m.memory_encoder(images_dp_feat.flatten(1, 2))], dim=-1)), ths], dim=1)))
+    return dict(B=B, T=T, seed=6, weights_seed=6, dropout_sites=sites, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples, params_without_grad=no_grad,
                 inputs=dict(hidden_q=hidden_q.detach(), traj_images=traj_images, traj_poses=traj_poses, video_frame_num=video_frame_num,
                             noise=noise, t_index=indices),
                 oracle_max_abs_diff=worst)
@@ -602,7 +628,8 @@ def gold_sft_navdp(B=1, T=2):
         pick = torch.linspace(0, flat.numel() - 1, min(32, flat.numel())).long()
         samples[k] = dict(norm=gr.norm().item(), idx=pick, val=flat[pick].clone())
     worst = max(worst, ((hidden_q.grad - hq_o.grad).abs().max() / hidden_q.grad.abs().max()).item())
-    return dict(B=B, T=T, weights_seed=7, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples,
+    sites = _count_dropout_sites(m, lambda: m.forward_vlm_traj(traj_hidden_states, images_dp, depths_dp, tensor_label_actions=traj_poses))
+    return dict(B=B, T=T, weights_seed=7, dropout_sites=sites, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples,
                 inputs=dict(hidden_q=hidden_q.detach(), traj_images=traj_images, traj_depths=traj_depths, traj_poses=traj_poses,
                             video_frame_num=video_frame_num, noise=noise, timesteps=timesteps),
                 oracle_max_abs_diff=worst)

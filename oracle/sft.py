@@ -80,3 +80,64 @@ def navdp_sft_loss(sd, hidden_q, traj_images, traj_depths, traj_poses, video_fra
     loss = (pred - noise).square()
     mask = loss_mask.flatten(0, 1)[:, None, None]
     return (loss * mask).sum() / mask.sum() / (loss.shape[1] * loss.shape[2])
+
+
+# ----------------------------------------------------------------------------------------------------- latent queries through the frozen LLM
+class _LayerView:
+    """state-dict view that presents decoder layer `i` as layer 0 (so oracle.qwen_vl.decoder_stack can run ONE layer)."""
+
+    def __init__(self, sd, i, p="model."):
+        self.sd, self.i, self.p = sd, i, p
+
+    def __getitem__(self, k):
+        pre = f"{self.p}layers.0."
+        return self.sd[f"{self.p}layers.{self.i}." + k[len(pre):]] if k.startswith(pre) else self.sd[k]
+
+
+class LatentQueryOracle:
+    """d loss / d latent_queries through the frozen decoder at FULL depth without holding the whole autograd graph.
+
+    The reference appends N_QUERY TRAJ tokens, overwrites their embeddings with `latent_queries` and back-propagates through all S rows
+    of all layers (internvla_n1.py:166-172, 222-227; internvla_n1_trainer.py:116). With a causal mask no earlier row depends on
+    `latent_queries` and no later row exists, so the gradient flows through the N_QUERY rows only: `forward` runs the prefix once
+    without grad on a KV cache (oracle.qwen_vl.decoder_stack(cache=), HF use_cache semantics), then the query rows layer by layer;
+    `backward` differentiates one layer at a time (torch.autograd.grad on a re-run of that layer) - the same numbers as autograd over
+    the whole sequence (tests/test_oracle_golden.py checks that on the reduced configuration), at O(1 layer) memory.
+    input_ids [1, L]: one unpadded sequence WITHOUT the TRAJ tokens. tap(i, x): residual stream of the query rows after layer i."""
+
+    def __init__(self, sd, cfg, input_ids, pixel_values, grid_thw, tap=None):
+        from . import qwen_vl as o_q
+        from .nn_ref import rms_norm
+
+        assert input_ids.shape[0] == 1
+        self.sd, self.cfg, self.o_q, self.rms_norm = sd, cfg, o_q, rms_norm
+        nq, Ln = cfg["n_query"], cfg["t_layers"]
+        with torch.no_grad():
+            emb = o_q.vision_tower(pixel_values, grid_thw, sd, cfg) if pixel_values is not None else None
+            x = o_q.input_embeds(input_ids, emb, sd, cfg)
+            pos, _ = o_q.rope_index(input_ids, grid_thw, cfg["image_token_id"], cfg["vision_start_id"])
+            self.cache = [None] * Ln
+            o_q.decoder_stack(x, pos, sd, cfg, cache=self.cache)
+            pq = (pos[:, :, -1].max(0).values + 1)[None, :, None] + torch.arange(nq)[None, None, :]
+            self.pq = pq.expand(3, 1, nq)
+            self.xs = [sd["model.latent_queries"].reshape(1, nq, -1).float().clone()]
+            for i in range(Ln):
+                self.xs.append(self._layer(i, self.xs[-1]))
+                if tap is not None:
+                    tap(i, self.xs[-1])
+            self.hidden = rms_norm(self.xs[-1], sd["model.norm.weight"], 1e-6)      # [1, N_QUERY, H]
+
+    def _layer(self, i, x_in):
+        got = []
+        self.o_q.decoder_stack(x_in, self.pq, _LayerView(self.sd, i), dict(self.cfg, t_layers=1), tap=lambda _, y: got.append(y), cache=[self.cache[i]])
+        return got[0]
+
+    def backward(self, d_hidden):
+        """d loss / d hidden [1, N_QUERY, H] -> d loss / d latent_queries f32 [N_QUERY, H]."""
+        xf = self.xs[-1].detach().requires_grad_(True)
+        h = self.rms_norm(xf, self.sd["model.norm.weight"], 1e-6)
+        (g,) = torch.autograd.grad(h, xf, d_hidden.to(h.dtype))
+        for i in reversed(range(self.cfg["t_layers"])):
+            x_in = self.xs[i].detach().requires_grad_(True)
+            (g,) = torch.autograd.grad(self._layer(i, x_in), x_in, g.to(x_in.dtype))
+        return g[0].float()

@@ -229,3 +229,25 @@ def test_navdp_sft_loss_and_gradients_match_reference_autograd():
             continue
         assert abs(mine.norm().item() - g["norm"]) < 1e-4 * g["norm"], k
         assert (mine.flatten()[g["idx"]] - g["val"]).abs().max().item() < 1e-4 * max(g["val"].abs().max().item(), g["norm"] / mine.numel() ** 0.5), k
+
+
+def test_latent_query_oracle_cached_equals_whole_sequence_autograd():
+    """oracle/sft.LatentQueryOracle (prefix on a KV cache without grad, query rows differentiated one layer at a time - what
+    oracle/make_golden_sft_full.py runs at 28 layers) gives the gradient torch autograd computes over the WHOLE sequence, i.e. the
+    reference's computation (internvla_n1.py:166-172, 222-227 with every LLM weight frozen), on the reduced configuration."""
+    from oracle import qwen_vl as o_q
+    from oracle import sft as o_sft
+
+    cfg = W.QWEN_TEST_CFG
+    sd = {k: v.float() for k, v in W.qwen_state_dict(seed=11, cfg=cfg).items()}
+    inp = W.qwen_inputs(1, 1, seed=9, cfg=cfg)
+    G = torch.randn(1, cfg["n_query"], cfg["t_hidden"], generator=torch.Generator().manual_seed(5))
+    lq = sd["model.latent_queries"].clone().requires_grad_(True)
+    sd_w = dict(sd)
+    sd_w["model.latent_queries"] = lq
+    h = o_q.generate_latents(sd_w, cfg, inp["input_ids"], inp["pixel_values"], inp["grid_thw"])
+    (h * G).sum().backward()
+    orc = o_sft.LatentQueryOracle(sd, cfg, inp["input_ids"], inp["pixel_values"], inp["grid_thw"])
+    g = orc.backward(G)
+    assert ((orc.hidden - h.detach()).abs().max() / h.detach().abs().max()).item() < 1e-5
+    assert ((g - lq.grad.reshape(g.shape)).norm() / lq.grad.norm()).item() < 1e-5

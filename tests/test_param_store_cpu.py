@@ -57,6 +57,8 @@ def test_checkpoint_resume_roundtrip(tmp_path):
                         LQ: torch.randn(1, 4, 32, generator=g)}, "cpu")
         tr = object.__new__(InternVLAN1SftTrainer)
         tr.P, tr.system1, tr.step_idx, tr.micro_idx = P, "nextdit_async", 0, 0
+        tr.rank, tr.world, tr.device = 0, 1, torch.device("cpu")
+        tr.gen_dev, tr.gen_cpu = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed + 100)
 
         class _E:
             latent_q = torch.zeros(4, 32, dtype=torch.bfloat16)
@@ -75,6 +77,9 @@ def test_checkpoint_resume_roundtrip(tmp_path):
         assert torch.equal(a.P.w32(k), b.P.w32(k)) and torch.equal(a.P._view(a.P.m, k), b.P._view(b.P.m, k)) and torch.equal(a.P._view(a.P.v, k), b.P._view(b.P.v, k))
     assert torch.equal(b.P.p16, b.P.p32.bfloat16()) and (b.P.step_count, b.step_idx, b.micro_idx) == (7, 7, 21)
     assert torch.equal(b.engine.latent_q, a.P.w16(LQ).view(4, 32))
+    # the noise / time-step streams continue where the saved run stood (the global torch RNG was neither saved nor restored)
+    assert torch.equal(torch.randn(5, generator=a.gen_dev), torch.randn(5, generator=b.gen_dev))
+    assert torch.equal(torch.rand(5, generator=a.gen_cpu), torch.rand(5, generator=b.gen_cpu))
     sd = a.state_dict()
     assert set(sd) == {"model.traj_dit.w", "model.cond_projector.0.bias", "model.latent_queries"}
     b.system1 = "navdp_async"

@@ -89,3 +89,38 @@ def test_navdp_tape_wiring(monkeypatch):
     assert _rel(dh.float().view_as(hq.grad), hq.grad) < 8e-2     # bf16 PyTorch itself shows 3-5 % here (three ReLU / bf16 layers from 3584 to 384)
     assert not any("rgb_model" in k for k in head.P.index) and any("rgb_model" in k for k in head.F.index)
     assert _check(head, {k: v.grad for k, v in sd.items() if v.grad is not None}, skip=("rgb_model",), tol=8e-2) > 150
+
+
+def test_dropout_sites_match_the_reference_modules(monkeypatch):
+    """train mode: the tape draws one mask per ACTIVE dropout site of the reference's modules - nn.Dropout with p > 0 and
+    nn.MultiheadAttention built with dropout > 0 - counted by forward hooks on the reference modules in train() mode
+    (oracle/make_golden.py _count_dropout_sites -> tests/golden/sft.pt / sft_navdp.pt). ADVICE r2: TokenCompressor.cross_attention is an
+    nn.MultiheadAttention with the default dropout 0.0 (encoder/navdp_backbone.py:77) and must NOT get a mask."""
+    from pathlib import Path
+
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+
+    K.install(monkeypatch)
+    monkeypatch.setattr(K, "COUNT_ONLY", True)
+    gold = Path(__file__).resolve().parent / "golden"
+    ref_nd = torch.load(gold / "sft.pt", weights_only=True)["dropout_sites"]
+    ref_nv = torch.load(gold / "sft_navdp.pt", weights_only=True)["dropout_sites"]
+    g = torch.Generator().manual_seed(0)
+    B, T = 1, 1
+    hq, img = torch.randn(B, 4, 3584, generator=g), torch.rand(B, T, 224, 224, 3, generator=g)
+    poses, noise = torch.randn(B, T, 32, 3, generator=g), torch.randn(B * T, 32, 3, generator=g)
+    head = E.NextDiTSftHead({k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}, "cpu", dropout=0.1)
+    head.loss_and_grads(hq, img, poses, torch.tensor([T]), noise, torch.tensor([500]), seed=1)
+    assert head.last_dropout_sites == ref_nd == {"dropout": 21, "attention": 9}
+    depth = 2                                            # 2 of the 16 decoder layers (CPU time); each layer = 2 attention + 4 nn.Dropout sites
+    cfg = dict(S.N1_NAVDP_CFG, temporal_depth=depth)
+    spec = {k: v for k, v in S.n1_navdp_spec().items() if not k.startswith("decoder.layers.") or int(k.split(".")[2]) < depth}
+    head = E.NavDPSftHead({k: v.float() for k, v in S.materialize(spec, 3).items()}, "cpu", cfg, dropout=0.1)
+    head.loss_and_grads(hq, img, torch.rand(B, T, 224, 224, generator=g) * 5.0, poses, torch.tensor([T]), noise, torch.tensor([7]), seed=1)
+    skipped = S.N1_NAVDP_CFG["temporal_depth"] - depth
+    assert head.last_dropout_sites == {"dropout": ref_nv["dropout"] - 4 * skipped, "attention": ref_nv["attention"] - 2 * skipped}
+    # eval-mode gradients (what the parity tests compare) draw nothing
+    head = E.NextDiTSftHead({k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}, "cpu", dropout=0.0)
+    head.loss_and_grads(hq, img, poses, torch.tensor([T]), noise, torch.tensor([500]))
+    assert head.last_dropout_sites == {"dropout": 0, "attention": 0}

@@ -299,7 +299,7 @@ def _keep_mask(seed, idx, p):
     """host replica of ina_hash (csrc/common.h) on int64 tensors: keep iff hash(seed, idx) >= p * 2^32."""
     M = 0xFFFFFFFF
     lo, hi = idx & M, idx >> 32
-    h = _fmix32((seed ^ lo) & M)
+    h = _fmix32((_fmix32(torch.full_like(lo, seed)) + 0x9E3779B9 * lo) & M)
     h = _fmix32((h + 0x9E3779B9 * hi + 0x7F4A7C15) & M)
     return h >= max(1, int(p * 4294967296.0))
 

@@ -99,7 +99,7 @@ def _zero2_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from internnav_amd import train_ops as T
     from internnav_amd.sft import ParamStore
-    from internnav_amd.trainer import InternVLAN1SftTrainer
+    from internnav_amd.trainer import InternVLAN1SftTrainer, shard_bounds
 
     T.adamw = _cpu_adamw                                                     # the GPU kernels are not under test here: the collectives are
     T.sumsq_parts = lambda flat, width=1024: flat.view(-1, width).pow(2).sum(0)
@@ -112,6 +112,9 @@ def _zero2_worker(rank, world, port, q):
         tr.P, tr.world, tr.rank, tr.pg, tr.zero2, tr.device = P, world, rank, None, zero2, torch.device("cpu")
         tr.total_steps, tr.lr, tr.min_lr, tr.warmup_steps, tr.wd, tr.max_norm, tr.betas, tr.eps = 100, 1e-2, 1e-3, 0, 0.01, 1.0, (0.9, 0.999), 1e-8
         tr.grad_norm, tr.step_idx = torch.zeros(1), 0
+        if zero2:
+            P.shard_moments(*shard_bounds(P.numel, world, rank))            # what the constructor does under ZeRO-2
+            assert P.m.numel() == shard_bounds(P.numel, world, rank)[1] - shard_bounds(P.numel, world, rank)[0] < P.numel
 
         class _E:
             latent_q = torch.zeros(4, 16, dtype=torch.bfloat16)
@@ -155,3 +158,85 @@ def test_zero2_equals_all_reduce_world2_gloo():
         assert diff <= 1e-7 and same16 and same_lq
         assert abs(n_ar - n_z2) <= 1e-5 * n_ar and abs(n_ar - res[0][4]) <= 1e-6 * n_ar
         assert g_ar == 0.0 and g_z2 == 0.0
+
+
+def _zero2_ckpt_worker(rank, world, port, q, tmp):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from internnav_amd import train_ops as T
+    from internnav_amd.sft import ParamStore
+    from internnav_amd.trainer import InternVLAN1SftTrainer, shard_bounds
+
+    T.adamw = _cpu_adamw
+    T.sumsq_parts = lambda flat, width=1024: flat.view(-1, width).pow(2).sum(0)
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        P = ParamStore({"a": torch.randn(300, 7, generator=g), "b": torch.randn(500, generator=g), "latent_queries": torch.randn(1, 4, 16, generator=g)}, "cpu")
+        tr = object.__new__(InternVLAN1SftTrainer)
+        tr.P, tr.world, tr.rank, tr.pg, tr.zero2, tr.device, tr.system1 = P, world, rank, None, True, torch.device("cpu"), "nextdit_async"
+        tr.total_steps, tr.lr, tr.min_lr, tr.warmup_steps, tr.wd, tr.max_norm, tr.betas, tr.eps = 100, 1e-2, 1e-3, 0, 0.01, 1.0, (0.9, 0.999), 1e-8
+        tr.grad_norm, tr.step_idx, tr.micro_idx = torch.zeros(1), 0, 0
+        tr.gen_dev, tr.gen_cpu = torch.Generator().manual_seed(rank), torch.Generator().manual_seed(rank + 50)
+
+        class _E:
+            latent_q = torch.zeros(4, 16, dtype=torch.bfloat16)
+        tr.engine = _E()
+        P.shard_moments(*shard_bounds(P.numel, world, rank))
+        return tr
+
+    def step(tr, k):
+        gg = torch.Generator().manual_seed(100 * k + rank)
+        tr.P.g32.zero_()
+        for name in tr.P.index:
+            tr.P.grad(name).copy_(torch.randn(tr.P.grad(name).shape, generator=gg) * 0.05)
+        tr.reduce_gradients()
+        tr.optimizer_step()
+
+    a = make(0)                      # uninterrupted: 4 steps
+    for k in range(4):
+        step(a, k)
+    b = make(0)                      # 2 steps, checkpoint (collective), resume in a fresh trainer with other initial weights, 2 more steps
+    for k in range(2):
+        step(b, k)
+    path = os.path.join(tmp, f"ck_rank{rank}.pt")
+    b.save_checkpoint(path)
+    dist.barrier()                   # rank 1 reads rank 0's file below
+    ck = torch.load(path, weights_only=True)
+    lo1, hi1 = shard_bounds(b.P.numel, world, 1)
+    # the file of EVERY rank holds the moments of EVERY shard (rank 0's file used to lack rank 1's slice): compare with the owners' values
+    full_m = b._gather_flat(b.P.m)
+    owned_by_1 = float(full_m[lo1:hi1].abs().sum())
+    in_file = sum(float(ck["store"]["exp_avg"][k].abs().sum()) for k in b.P.index)
+    c = make(7)
+    c.load_checkpoint(os.path.join(tmp, "ck_rank0.pt") if rank == 1 else path)      # rank 1 resumes from RANK 0's file
+    for k in range(2, 4):
+        step(c, k)
+    q.put((rank, float((a.P.p32 - c.P.p32).abs().max()), bool(torch.equal(a.P.m, c.P.m) and torch.equal(a.P.v, c.P.v)), owned_by_1 > 0,
+           abs(in_file - float(full_m.abs().sum())) <= 1e-4 * in_file, c.step_idx, c.P.step_count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero2_checkpoint_resume_world2_gloo(tmp_path):
+    """under ZeRO-2 each rank updates the Adam moments of its own shard only. save_checkpoint all-gathers them, so any rank's
+    file is complete, and a run resumed from it (even from the OTHER rank's file) continues exactly like an uninterrupted run."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero2_ckpt_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert len(res) == 2
+    for rank, diff, same_moments, other_shard_nonzero, file_complete, step_idx, step_count in res:
+        assert diff == 0.0 and same_moments and other_shard_nonzero and file_complete and step_idx == 4 and step_count == 4
