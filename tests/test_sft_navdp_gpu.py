@@ -72,3 +72,67 @@ def test_navdp_sft_loss_and_gradients(built_lib):
     # prediction 1.24e-2 vs 8.3e-3, gradients 1.2e-2 vs 3.5e-3 relative (tools/sft_check_navdp*.py). Bound: 3 % per tensor, 1.5 % on average.
     assert not bad, bad[:10]
     assert sum(errs) / len(errs) <= 1.5e-2
+
+
+def test_navdp_sft_per_layer_drift_table(built_lib):
+    """Where the navdp_async branch sits against its yardstick, layer by layer: the residual stream of the 16-layer
+    decoder after every layer and its GRADIENT on the way back, engine vs fp32 oracle next to bf16-autocast PyTorch vs the same oracle.
+    Written to gpurun_out/sft_navdp_drift.txt. Asserted: the forward stream stays within 1.35x of the yardstick at every layer."""
+    import os
+    from pathlib import Path
+
+    import oracle.navdp as ON
+    import oracle.sft as O
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+
+    dev = torch.device("cuda:0")
+    cfg = S.N1_NAVDP_CFG
+    sd0 = {k: v.float() for k, v in S.materialize(S.n1_navdp_spec(), 3).items()}
+    inp = _inputs(2, 2)
+    rec = {}
+    orig = ON.decoder_layer
+
+    def tapped(x, mem, sd, p, *a, **k):
+        y = orig(x, mem, sd, p, *a, **k)
+        if p.startswith("decoder.layers."):
+            y.retain_grad()
+            rec[f"layer{p.split('.')[-1]}"] = y
+        return y
+
+    def run(autocast):
+        rec.clear()
+        ON.decoder_layer = tapped
+        try:
+            sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+            with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+                loss = O.navdp_sft_loss(sd, inp["hidden_q"].clone().requires_grad_(True), inp["traj_images"], inp["traj_depths"], inp["traj_poses"],
+                                        inp["video_frame_num"], inp["noise"], inp["timesteps"], cfg)
+            loss.backward()
+        finally:
+            ON.decoder_layer = orig
+        return {k: (v.detach().float().clone(), v.grad.float().clone()) for k, v in rec.items()}
+
+    r32, r16 = run(False), run(True)
+    head = E.NavDPSftHead(sd0, dev, cfg)
+    head.taps = []
+    head.loss_and_grads(inp["hidden_q"].to(dev), inp["traj_images"].to(dev), inp["traj_depths"].to(dev), inp["traj_poses"], inp["video_frame_num"],
+                        inp["noise"], inp["timesteps"])
+    fwd, bwd = dict(head.taps), dict(head.grad_taps)
+    lines = ["# navdp_async SFT: decoder residual stream per layer, engine vs fp32 oracle | bf16-autocast PyTorch vs fp32 oracle (relative L2)",
+             "# layer | forward: engine  autocast  ratio | gradient of the stream: engine  autocast  ratio"]
+    worst_f = 0.0
+    for i in range(cfg["temporal_depth"]):
+        n = f"layer{i}"
+        ef, yf = _rel(fwd[n].cpu().view_as(r32[n][0]), r32[n][0]), _rel(r16[n][0], r32[n][0])
+        eb, yb = _rel(bwd[n].cpu().view_as(r32[n][1]), r32[n][1]), _rel(r16[n][1], r32[n][1])
+        worst_f = max(worst_f, ef / yf)
+        lines.append(f"{n:8s} {ef:.3e} {yf:.3e} {ef / yf:5.2f} | {eb:.3e} {yb:.3e} {eb / yb:5.2f}")
+    out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out"
+    try:
+        out.mkdir(exist_ok=True)
+        (out / "sft_navdp_drift.txt").write_text("\n".join(lines) + "\n")
+    except OSError:
+        pass
+    print("\n".join(lines))
+    assert worst_f <= 1.35, worst_f
