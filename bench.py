@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=64, help="environments per GPU")
-    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1", "unet1d_s1"])
+    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1", "unet1d_s1", "sft"],
+                    help="n1_dual = the BASELINE metric's configuration (default); navdp_s1 = config #2; unet1d_s1 = the diffusion-policy UNet head; "
+                         "sft = config #5 (the SFT step, bench_sft.py: its own flags pass through)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--overlap-at", choices=["start", "decode"], default="decode",
@@ -63,7 +65,32 @@ def parse():
                          "sample of the reference) comes from the cache, 3 of the 4 frames are encoded; algorithmic FLOPs are accounted accordingly")
     ap.add_argument("--no-raw-frames", action="store_true",
                     help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
-    return ap.parse_args()
+    a, rest = ap.parse_known_args()
+    if rest and a.workload != "sft":
+        ap.error(f"unrecognized arguments: {' '.join(rest)}")
+    a.rest = rest
+    return a
+
+
+def calibration_gemm(dev, seconds: float = 0.5):
+    """sustained TF/s of THIS box on one fixed compute-bound launch (8192^3 bf16 through the library's own tiled GEMM), so the line tells
+    box-to-box clock / power spread (265-281 steps/s across round-2 boxes on unchanged code) apart from code changes."""
+    from internnav_amd import ops
+
+    x = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16) * 0.01
+    out = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.linear(x, w, out=out)
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            ops.linear(x, w, out=out)
+        torch.cuda.synchronize()
+        n += 10
+    dt = time.perf_counter() - t0
+    return {"gemm_8192_tflops": round(n * 2 * 8192 ** 3 / dt / 1e12, 1), "launches": n, "seconds": round(dt, 2)}
 
 
 # ------------------------------------------------------------------------------------------------------------ workloads
@@ -542,10 +569,18 @@ def pmc_traffic(workload):
 # ------------------------------------------------------------------------------------------------------------ driver
 def main():
     a = parse()
+    from internnav_amd.dist import maybe_self_spawn
+
+    maybe_self_spawn(str(Path(__file__).resolve()), a.gpus)      # `python bench.py --gpus N` without a launcher starts its own N ranks
+    if a.workload == "sft":                                       # config #5 in the same JSON shape (bench_sft.py)
+        import bench_sft
+
+        sys.argv = [str(ROOT / "bench_sft.py"), "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup)] + \
+                   (["--no-cpu-baseline"] if a.no_cpu_baseline else []) + a.rest
+        return bench_sft.main()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from internnav_amd import runtime
@@ -604,6 +639,7 @@ def main():
     value = world * wl.B * a.steps / dt
 
     if rank == 0:
+        calib = calibration_gemm(dev)
         # ---- roofline: one instrumented eager pass, HIP events around every launch on the launch stream
         runtime.prof_enable(True)
         extra = wl.instrumented()
@@ -640,7 +676,8 @@ def main():
             "metric": "policy steps/sec/node", "value": round(value, 2), "unit": "policy steps/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at the true shapes, synthetic camera frames / prompts)",
-            "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}",
+            "rccl_ranks": world,
+            "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}", "calibration": calib,
                             "launch": "eager" if a.no_graph else "hipGraph replay",
                             "schedule": (("S2 ViT+prefill, then S2 decode+latent queries || S1(non-S2 envs) on a side stream, then S1(S2 envs)"
                                           if getattr(wl, "overlap_at", "") == "decode" else

@@ -151,8 +151,10 @@ def cpu_baseline(info, qcfg):
 
 def main():
     a = parse()
+    from internnav_amd.dist import maybe_self_spawn
+
+    maybe_self_spawn(str(Path(__file__).resolve()), a.gpus)
     rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from internnav_amd import runtime
@@ -207,7 +209,7 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         step_tflops = fl["total"] * a.steps / dt / 1e12
         line = {
-            "metric": "SFT samples/sec/node", "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": "SFT samples/sec/node", "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "rccl_ranks": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded random weights at the true shapes, synthetic prompts / frames / trajectories)",
             "config": {"workload": f"sft_nextdit_async_b{info['B']}x{info['T']}", "micro_batch_per_gpu": info["B"], "subgoals_per_sample": info["T"],

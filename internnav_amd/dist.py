@@ -76,3 +76,35 @@ def pin_host_threads(local_rank: int, local_world: int) -> int:
         return len(cores)
     torch.set_num_threads(max(1, len(mine)))
     return len(mine)
+
+
+def self_spawn_command(script: str, argv: Sequence[str], n_ranks: int, port: int = 0) -> List[str]:
+    """the command that re-launches `script argv` as one process per GPU of this node: what `python bench.py --gpus N` runs when it was
+    started WITHOUT a launcher (no WORLD_SIZE in the environment). The reference's evaluation scripts do the same - they start one
+    process per GPU themselves (scripts/eval/bash/eval_dual_system.sh:4-12, internnav/utils/dist.py:193-243). Rendezvous on 127.0.0.1."""
+    import socket
+    import sys
+
+    if port <= 0:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script, *argv]
+
+
+def maybe_self_spawn(script: str, n_gpus: int) -> None:
+    """`python <script> --gpus N` with N > 1 and no launcher environment: re-exec through torch.distributed.run (one rank per GPU) and
+    exit with its return code. Under a launcher (WORLD_SIZE set) it only checks that the launcher and --gpus agree."""
+    import subprocess
+    import sys
+
+    world = os.environ.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return
+    if n_gpus <= 1:
+        return
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(self_spawn_command(script, sys.argv[1:], n_gpus), env=env))

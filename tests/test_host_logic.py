@@ -306,3 +306,32 @@ def test_pin_host_threads_partitions_the_cores():
         outs.append(eval(r.stdout.strip().split(" ", 1)[1]))
     if len(os.sched_getaffinity(0)) >= 2:
         assert not set(outs[0]) & set(outs[1]) and outs[0] and outs[1]
+
+
+def test_self_spawn_relaunches_one_process_per_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher must start its own N ranks (it used to die on an assert). The helper both
+    benches call re-execs through torch.distributed.run on 127.0.0.1; under a launcher it only cross-checks WORLD_SIZE."""
+    import subprocess
+    import sys
+
+    from internnav_amd.dist import maybe_self_spawn, self_spawn_command
+
+    cmd = self_spawn_command("bench.py", ["--gpus", "4", "--steps", "5"], 4, port=29999)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "5"]
+    script = tmp_path / "mini_bench.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {str(Path(__file__).resolve().parent.parent)!r})\n"
+        "from internnav_amd.dist import maybe_self_spawn\n"
+        "n = int(sys.argv[sys.argv.index('--gpus') + 1])\n"
+        "maybe_self_spawn(__file__, n)\n"
+        "print('RANK', os.environ.get('RANK', 'none'), 'of', os.environ.get('WORLD_SIZE', 'none'), flush=True)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(script), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert sorted(l for l in out.stdout.splitlines() if l.startswith("RANK")) == ["RANK 0 of 2", "RANK 1 of 2"]
+    out = subprocess.run([sys.executable, str(script), "--gpus", "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert out.stdout.strip() == "RANK none of none"                       # single GPU: no launcher involved
+    bad = subprocess.run([sys.executable, str(script), "--gpus", "4"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)

@@ -9,14 +9,21 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _device(rank, backend):
+    """one GPU per rank under RCCL; the gloo twin of these workers (tests/test_rccl_workers_gloo_cpu.py) runs the same code on the CPU."""
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        return torch.device("cuda", rank)
+    return torch.device("cpu")
+
+
+def _worker(rank, world, port, q, backend="nccl"):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     from internnav_amd import dist as D
 
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    r, _, w = D.init_distributed("nccl", device=dev)
+    dev = _device(rank, backend)
+    r, _, w = D.init_distributed(backend, device=dev)
     acts = (torch.arange(64 * 4, dtype=torch.int32, device=dev).view(64, 4) % 4) + 0 * r
     acts[:, 0] = r
     g = D.all_gather_actions(acts)
@@ -51,18 +58,23 @@ def test_action_all_gather_over_rccl():
         assert m == [float(v + 10 * k) for k in range(world) for v in range(3 + k)]
 
 
-def _sft_worker(rank, world, port, q):
+def _sft_worker(rank, world, port, q, backend="nccl"):
     """the SFT trainer's flat-bucket reduction + fused AdamW: ZeRO-2 (reduce-scatter, sharded update, all-gather) must land on exactly the
     all-reduce (replicated update) weights, and every rank must hold the same ones."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", device_id=dev)
+    dev = _device(rank, backend)
+    dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {"rank": rank, "world_size": world}))
     from internnav_amd.sft import ParamStore
-    from internnav_amd.trainer import InternVLAN1SftTrainer
+    from internnav_amd.trainer import InternVLAN1SftTrainer, shard_bounds
+
+    if backend != "nccl":            # CPU twin: torch stand-ins for the two HIP kernels of the optimiser (the collectives are under test)
+        from internnav_amd import train_ops as T
+        from tests import _cpu_kernels as K
+
+        T.adamw, T.sumsq_parts = K.adamw, K.sumsq_parts
 
     out = []
     for zero2 in (False, True):
@@ -72,6 +84,8 @@ def _sft_worker(rank, world, port, q):
         tr.P, tr.world, tr.rank, tr.pg, tr.zero2, tr.device = P, world, rank, None, zero2, dev
         tr.total_steps, tr.lr, tr.min_lr, tr.warmup_steps, tr.wd, tr.max_norm, tr.betas, tr.eps = 100, 1e-2, 1e-3, 0, 0.01, 1.0, (0.9, 0.999), 1e-8
         tr.grad_norm, tr.step_idx = torch.zeros(1, device=dev), 0
+        if zero2:
+            P.shard_moments(*shard_bounds(P.numel, world, rank))          # as the trainer's constructor does under ZeRO-2
 
         class _E:
             latent_q = torch.zeros(4, 64, dtype=torch.bfloat16, device=dev)
