@@ -1,0 +1,34 @@
+"""System-1 call (64 envs, eager and graph) with and without the fused row-norm GEMMs. Usage: python tools/bench_s1_variants.py"""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from internnav_amd import runtime, synthetic  # noqa: E402
+from internnav_amd.nextdit import NextDiTSystem1  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = synthetic.N1_NEXTDIT_CFG
+sd = synthetic.n1_nextdit_state_dict(seed=0)
+B = 64
+inp = synthetic.n1_nextdit_inputs(B, seed=0)
+lat, img, x0 = inp["traj_latents"].to(dev, torch.bfloat16), inp["images"].to(dev), inp["x_init"].to(dev)
+ref = None
+for name, kw in (("unfused", {}), ("fuse_rownorm", dict(fuse_rownorm=True)), ("fuse_ffn", dict(fuse_ffn=True))):
+    eng = NextDiTSystem1(sd, cfg, dev, max_envs=B, **kw)
+    out = eng.generate_traj(lat, img, x0).clone()
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = out
+    g = runtime.GraphedCall(lambda: eng.generate_traj(lat, img, x0), {})
+    g()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"{name:14s} S1 call over {B} envs (graph): {ms:7.2f} ms   max|diff| vs unfused {(out - ref).abs().max().item():.3e}", flush=True)
+    del eng, g
