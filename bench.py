@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--vit-cache", action="store_true",
                     help="n1_dual: per-frame ViT cache variant - the first history frame of every env (frame 0, present in every np.linspace history "
                          "sample of the reference) comes from the cache, 3 of the 4 frames are encoded; algorithmic FLOPs are accounted accordingly")
+    ap.add_argument("--prefix-kv", action="store_true",
+                    help="n1_dual: prefix-KV reuse variant - the K/V of system prompt + instruction + first history frame (296 of the 920 prompt "
+                         "tokens, identical between the System-2 calls of an episode) come from a per-env cache; the call encodes 3 of 4 frames and "
+                         "prefills 624 tokens per env. Exact (causal mask); algorithmic FLOPs are accounted accordingly. Reported next to the headline.")
     ap.add_argument("--no-raw-frames", action="store_true",
                     help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
     a, rest = ap.parse_known_args()
@@ -269,8 +273,11 @@ class N1Dual:
                      "s2": f"{self.N_IMG} frames x 784 patches + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
                      "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps", "s2_microbatches_per_10_steps": self.mb}
         self.vit_cache = bool(getattr(a, "vit_cache", False)) and self.raw
-        n_fresh = self.N_IMG - 1 if self.vit_cache else self.N_IMG
-        f2 = flops.s2_call_flops(self.S, [self.GRID] * n_fresh, self.N_DECODE, qcfg)     # a cached frame costs no vision-tower FLOPs
+        self.prefix_kv = bool(getattr(a, "prefix_kv", False)) and self.raw
+        assert not (self.vit_cache and self.prefix_kv), "--prefix-kv already covers frame 0 (its tokens are cached K/V): use one of the two"
+        self.prefix_len = (34 + self.N_INSTR + per // 4 + 2) if self.prefix_kv else 0     # template + instruction + <vs> frame 0 <ve>
+        n_fresh = self.N_IMG - 1 if (self.vit_cache or self.prefix_kv) else self.N_IMG
+        f2 = flops.s2_call_flops(self.S, [self.GRID] * n_fresh, self.N_DECODE, qcfg, prefix_len=self.prefix_len)   # cached frames / tokens cost no FLOPs
         f1 = flops.nextdit_s1_flops_per_env(scfg)
         self.f_alg = f1["total"] + f2["total"] / self.CADENCE
         self.f_parts = {"s1_per_env": f1["total"], "s2_per_call": f2["total"]}
@@ -286,10 +293,24 @@ class N1Dual:
                 emb, inv = q.vision(pv0, [self.GRID] * (hi - lo))
                 self.emb0[lo:hi].copy_(emb[torch.from_numpy(inv).to(dev).long()].view(hi - lo, per // 4, -1))
             self.desc["vit_cache"] = "frame 0 of every env from the per-frame ViT cache (3 of 4 frames encoded per System-2 call)"
+        if self.prefix_kv:
+            # prefix K/V of every env, computed once by a prefill of the prefix alone (they would have been left behind by the env's
+            # previous System-2 call): bf16 [B, layers, prefix_len, 1024] = 17 MB per env
+            pl = self.prefix_len
+            self.kv_prefix = torch.empty(B, qcfg["t_layers"], pl, q.kv_w, dtype=torch.bfloat16, device=dev)
+            for lo in range(0, B, mmax):
+                hi = min(B, lo + mmax)
+                pv0, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:hi, 0].contiguous())
+                q.prefill(ids[lo:hi, :pl].cpu(), pv0, torch.cat([self.grid[:1]] * (hi - lo)))
+                for k in range(hi - lo):
+                    self.kv_prefix[lo + k].copy_(q.export_prefix_kv(k, pl))
+            self.desc["prefix_kv"] = (f"K/V of the first {pl} prompt tokens (template + instruction + frame 0) of every env from the prefix cache: "
+                                      f"{self.S - pl} tokens prefilled and 3 of 4 frames encoded per System-2 call")
         for m in sorted(set(self.mb)):
             cache0 = torch.empty(m, per // 4, qcfg["t_hidden"], dtype=torch.bfloat16, device=dev) if self.vit_cache else None
             cached = [c for k in range(m) for c in ([cache0[k]] + [None] * (self.N_IMG - 1))] if self.vit_cache else None
-            P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True, cached_embeds=cached)
+            P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True, cached_embeds=cached,
+                       prefix_len=self.prefix_len)
             self.s2[m] = dict(P=P, cache0=cache0, pv=torch.empty(m * n_fresh * per, 1176, dtype=torch.bfloat16, device=dev),
                               toks=torch.zeros(m, self.N_DECODE, dtype=torch.int32, device=dev),
                               lat=torch.zeros(m, qcfg["n_query"], qcfg["t_hidden"], dtype=torch.bfloat16, device=dev), graph=None)
@@ -329,7 +350,11 @@ class N1Dual:
 
     def _ingest_s2(self, lo, m, dst):
         """System-2 images of envs [lo, lo + m): raw frames -> pixel_values of the micro-batch (or the round-1 resident tensor)."""
-        if self.vit_cache:
+        if self.prefix_kv:
+            self.model.qwen.import_prefix_kv_batch(self.kv_prefix[lo:lo + m])           # 28 strided device copies, inside the timed step
+            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, 1:].reshape(m * (self.N_IMG - 1), 480, 640, 3))
+            dst.copy_(pv)
+        elif self.vit_cache:
             self.s2[m]["cache0"].copy_(self.emb0[lo:lo + m])
             pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, 1:].reshape(m * (self.N_IMG - 1), 480, 640, 3))
             dst.copy_(pv)
@@ -419,7 +444,7 @@ class N1Dual:
             with torch.cuda.stream(self.side):
                 trajA = self.gA[nA]()
         # main stream: System-2 micro-batch, then System-1 for exactly those envs
-        s["P"]["ids"].copy_(self.ids[lo:lo + m].reshape(-1).to(torch.int32))
+        s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
         self._ingest_s2(lo, m, s["pv"])
         if late:
             self.gP[m]()
@@ -470,7 +495,7 @@ class N1Dual:
         m, lo = self.mb[j], int(self.mb_start[j])
         s = self.s2[m]
         # System-2 for the envs whose plan expires this step: gather their prompt / frames, run, scatter the latents back
-        s["P"]["ids"].copy_(self.ids[lo:lo + m].reshape(-1).to(torch.int32))
+        s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
         self._ingest_s2(lo, m, s["pv"])
         self._ingest_s1()
         s["graph"]() if s["graph"] else self._s2_call(m)

@@ -87,11 +87,12 @@ def llm_flops(new_tokens: int, ctx_start: int, cfg, lm_head_rows: int = 0) -> fl
     return cfg["t_layers"] * (lin + attn) + 2 * lm_head_rows * H * cfg["vocab"]
 
 
-def s2_call_flops(S: int, grids, n_decode: int, cfg) -> dict:
+def s2_call_flops(S: int, grids, n_decode: int, cfg, prefix_len: int = 0) -> dict:
     """one System-2 call per env (pixel-goal answer): ViT + prefill + n_decode greedy tokens + N_QUERY latent queries on the cache
-    (16.46 TFLOP for 4 frames, S = 920, n_dec = 8)."""
+    (16.46 TFLOP for 4 frames, S = 920, n_dec = 8). `grids` = the images the call ENCODES; prefix_len = prompt tokens
+    whose K/V come from the prefix cache (they cost no GEMM FLOPs; the other tokens still attend to them)."""
     vit = qwen_vit_flops(grids, cfg)
-    prefill = llm_flops(S, 0, cfg, lm_head_rows=1)
+    prefill = llm_flops(S - prefix_len, prefix_len, cfg, lm_head_rows=1)
     decode = sum(llm_flops(1, S + j, cfg, lm_head_rows=1) for j in range(max(n_decode - 1, 0)))
     lat = llm_flops(1 + cfg["n_query"], S + max(n_decode - 1, 0), cfg)
     return dict(vit=vit, prefill=prefill, decode=decode, latents=lat, total=vit + prefill + decode + lat)

@@ -296,27 +296,58 @@ class QwenVLEngine:
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)
-    def plan(self, input_ids, image_grid_thw, n_decode: int = 0, with_latents: bool = False, cached_embeds: Optional[list] = None) -> dict:
+    def plan(self, input_ids, image_grid_thw, n_decode: int = 0, with_latents: bool = False, cached_embeds: Optional[list] = None,
+             prefix_len: int = 0) -> dict:
         """Host-side plan of one S2 call for B equal-length prompts: embedding / scatter indices, vision plan, position ids and cache
         rows of the prefill, of every decode step and of the latent-query pass (fixed-length answers of n_decode tokens).
         cached_embeds: one entry per image (prompt order over the batch), None = run the vision tower on it, else its merged embeddings
         bf16 [h*w/4, H] in token order from an earlier call (per-frame ViT cache, SURVEY.md 8f-1: the tower attends per image, so a
-        frame's embeddings do not depend on what else is in the batch). pixel_values then holds the patches of the fresh images only."""
+        frame's embeddings do not depend on what else is in the batch). pixel_values then holds the patches of the fresh images only.
+        prefix_len (prefix-KV reuse, SURVEY.md 7 / DESIGN 8.5): the first prefix_len tokens of EVERY sequence are not run - their K/V of
+        all layers are already in the cache slots of this batch (`import_prefix_kv`, from an earlier call whose prompt started with the
+        same tokens: system prompt + instruction + first history frame between the System-2 calls of an episode). With a causal mask
+        the K/V of a token depend on the tokens before it only, so the suffix sees exactly what a full prefill would have cached.
+        Images whose tokens lie inside the prefix are not encoded (pixel_values holds the patches of the other images); the prefix
+        must end on an image boundary."""
         cfg, dev = self.cfg, self.device
         ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
         B, S = ids.shape
         if B > self.B_max or S > self.S_max:
             raise CapacityError(f"System-2 batch of {B} x {S} tokens exceeds the engine's max_seqs={self.B_max} / max_seq_len={self.S_max}")
+        assert 0 <= prefix_len < S, f"prefix_len={prefix_len} must leave at least one token of the {S}-token prompts to run"
         grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
-        flat = ids.reshape(-1)
-        P = dict(B=B, S=S, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None, cached=[], fresh_tokens=[])
+        grids_all = grids
+        Sr = S - prefix_len                                       # tokens per sequence this call runs
+        run = np.ascontiguousarray(ids[:, prefix_len:])
+        flat = run.reshape(-1)
+        P = dict(B=B, S=S, S_run=Sr, prefix_len=prefix_len, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None,
+                 cached=[], fresh_tokens=[])
         img_pos = np.nonzero(flat == cfg["image_token_id"])[0].astype(np.int32)
         if grids:
-            ntok = [t * h * w // 4 for t, h, w in grids]
+            ntok_all = [t * h * w // 4 for t, h, w in grids]
+            # images inside the prefix: their tokens are cached K/V, nothing of them is needed (neither pixels nor embeddings)
+            in_prefix, k = [], 0
+            for b in range(B):
+                ipos = np.nonzero(ids[b] == cfg["image_token_id"])[0]
+                cum = 0
+                while cum < ipos.size:
+                    assert k < len(grids), "image count of the prompts and image_grid_thw disagree"
+                    first, last = int(ipos[cum]), int(ipos[cum + ntok_all[k] - 1])
+                    assert last < prefix_len or first >= prefix_len, "the cached prefix must end on an image boundary"
+                    in_prefix.append(last < prefix_len)
+                    cum += ntok_all[k]
+                    k += 1
+            assert k == len(grids), "image count of the prompts and image_grid_thw disagree"
+            keep = [k for k, ins in enumerate(in_prefix) if not ins]
+            P["images_run"] = keep
+            cached_all = list(cached_embeds) if cached_embeds is not None else [None] * len(grids)
+            assert len(cached_all) == len(grids)
+            grids = [grids_all[k] for k in keep]
+            cached_embeds = [cached_all[k] for k in keep]
+            ntok = [ntok_all[k] for k in keep]
             assert img_pos.size == sum(ntok), f"Image features and image tokens do not match: tokens: {img_pos.size}, features {sum(ntok)}"
             off = np.concatenate([[0], np.cumsum(ntok)])
-            cached = list(cached_embeds) if cached_embeds is not None else [None] * len(grids)
-            assert len(cached) == len(grids)
+            cached = list(cached_embeds)
             fresh = [k for k, c in enumerate(cached) if c is None]
             if fresh:
                 vp = self.plan_vision([grids[k] for k in fresh])
@@ -324,7 +355,7 @@ class QwenVLEngine:
                 P["vision"], P["img_src"], P["img_dst"] = vp, torch.from_numpy(vp["inv"]).to(dev), torch.from_numpy(dst).to(dev)
                 o = 0
                 for k in fresh:
-                    P["fresh_tokens"].append((k, o, o + ntok[k]))      # rows of emb_tok that hold image k after run_prefill
+                    P["fresh_tokens"].append((keep[k], o, o + ntok[k]))      # rows of emb_tok that hold image keep[k] (index over ALL images) after run_prefill
                     o += ntok[k]
             for k, c in enumerate(cached):
                 if c is not None:
@@ -335,8 +366,8 @@ class QwenVLEngine:
             nq = self.latent_q.shape[0]
             P["traj_src"] = torch.from_numpy((np.arange(traj_pos.size) % nq).astype(np.int32)).to(dev)
             P["traj_dst"] = torch.from_numpy(traj_pos).to(dev)
-        pos3, _ = rope_index(ids, grids, cfg["image_token_id"], cfg["vision_start_id"])
-        P["prefill"] = self._phase(B, S, pos3, 0)
+        pos3, _ = rope_index(ids, grids_all, cfg["image_token_id"], cfg["vision_start_id"])
+        P["prefill"] = self._phase(B, Sr, pos3[:, :, prefix_len:], prefix_len)
         nxt = pos3[:, :, -1].max(axis=0) + 1                      # text position of the first generated token, per sequence
         P["next_pos"] = nxt
         P["decode"] = [self._phase(B, 1, (nxt + j)[None, :, None], S + j) for j in range(max(n_decode - 1, 0))]
@@ -369,7 +400,7 @@ class QwenVLEngine:
 
     def run_decode(self, P: dict, tokens_out: torch.Tensor):
         """n_decode greedy tokens: the first from the prompt's last position, then n_decode - 1 single-token passes."""
-        B, S, n = P["B"], P["S"], P["n_decode"]
+        B, S, n = P["B"], P["S_run"], P["n_decode"]               # rows of x: the tokens this call ran (all of them without a cached prefix)
         if n == 0:
             return
         self._last_logits(B, S, S - 1)
@@ -401,20 +432,42 @@ class QwenVLEngine:
         if latents_out is not None:
             self.run_latents(P, latents_out)
 
+    # ---- prefix-KV reuse: the K/V of a prompt prefix leave / re-enter the batch's cache slots (device copies, no arithmetic)
+    def export_prefix_kv(self, seq: int, n_tokens: int) -> torch.Tensor:
+        """K/V of the first n_tokens cached tokens of batch slot `seq`, all layers: bf16 [layers, n_tokens, 2 * kv_heads * head_dim]
+        (a copy: what a caller keeps per environment between the System-2 calls of an episode)."""
+        assert 0 <= seq < self.B_max and 0 < n_tokens <= self.S_max
+        return torch.stack([L["kv"].view(self.B_max, self.S_max, self.kv_w)[seq, :n_tokens] for L in self.layers])
+
+    def import_prefix_kv_batch(self, kv: torch.Tensor):
+        """kv bf16 [m, layers, n, kv_w]: the prefixes of m environments into batch slots 0 .. m-1 (one strided copy per layer)."""
+        m, nl, n, w = kv.shape
+        assert nl == len(self.layers) and w == self.kv_w and m <= self.B_max and n <= self.S_max and kv.dtype == torch.bfloat16
+        for li, L in enumerate(self.layers):
+            L["kv"].view(self.B_max, self.S_max, self.kv_w)[:m, :n].copy_(kv[:, li])
+
+    def import_prefix_kv(self, seq: int, kv: torch.Tensor):
+        """put an exported prefix back into batch slot `seq` (before plan(..., prefix_len=kv.shape[1]) / prefill(..., prefix_len=))."""
+        n = kv.shape[1]
+        assert kv.shape == (len(self.layers), n, self.kv_w) and kv.dtype == torch.bfloat16 and n <= self.S_max
+        for li, L in enumerate(self.layers):
+            L["kv"].view(self.B_max, self.S_max, self.kv_w)[seq, :n].copy_(kv[li])
+
     # ---- eager, stateful API (used by the policy layer: answers have data-dependent lengths)
     def prefill(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor], image_grid_thw, cached_embeds: Optional[list] = None,
-                seq_lens=None) -> dict:
+                seq_lens=None, prefix_len: int = 0) -> dict:
         """seq_lens [B] (optional): RAGGED batch - input_ids is right-padded to a common length S and sequence b has seq_lens[b] real
         tokens. Causal attention keeps every real position independent of the padding behind it, so the prefill runs on the padded
         rectangle; the first token is read at each sequence's own last position and the decode / latent passes append at per-sequence
         cache positions with per-sequence key lengths (the pad rows' K/V are never attended and get overwritten)."""
-        P = self.plan(input_ids, image_grid_thw, cached_embeds=cached_embeds)
+        P = self.plan(input_ids, image_grid_thw, cached_embeds=cached_embeds, prefix_len=prefix_len)
         self.run_prefill(P, pixel_values)
-        st = dict(B=P["B"], S=P["S"], next_pos=P["next_pos"].copy(), plan=P)
+        st = dict(B=P["B"], S=P["S"], S_run=P["S_run"], next_pos=P["next_pos"].copy(), plan=P)
         if seq_lens is not None:
             lens = np.asarray(seq_lens, dtype=np.int64)
             assert lens.shape == (P["B"],) and int(lens.max()) <= P["S"] and int(lens.min()) >= 1
             if bool((lens != P["S"]).any()):
+                assert int(lens.min()) > prefix_len, "every sequence must have tokens behind the cached prefix"
                 ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
                 grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
                 pos3, _ = rope_index(ids, grids, self.cfg["image_token_id"], self.cfg["vision_start_id"])
@@ -426,15 +479,16 @@ class QwenVLEngine:
         """n greedy steps after prefill (or after a previous decode); returns int32 [B, n] generated tokens (device). The last
         returned token is sampled but not yet run through the layers (its K/V are not cached)."""
         B, S = state["B"], state["S"]
+        Sr = state.get("S_run", S)                                # rows per sequence in x (prompt minus a cached prefix)
         out = torch.empty(B, n_steps, dtype=torch.int32, device=self.device)
         lens = state.get("lens")
         if "cur" not in state:
             if lens is None:
-                self._last_logits(B, S, S - 1)
+                self._last_logits(B, Sr, Sr - 1)
                 state["cur"] = S
             else:
-                rows = torch.from_numpy((np.arange(B) * S + lens - 1).astype(np.int32)).to(self.device)
-                self._last_logits(B, S, None, rows_idx=rows)
+                rows = torch.from_numpy((np.arange(B) * Sr + lens - (S - Sr) - 1).astype(np.int32)).to(self.device)
+                self._last_logits(B, Sr, None, rows_idx=rows)
                 state["cur"] = lens.copy()
         for j in range(n_steps):
             out[:, j].copy_(self.next_tok[:B])

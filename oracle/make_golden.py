@@ -322,7 +322,17 @@ def gold_unet1d(B=2):
         mine_eps = o_u.unet_forward(sd, inp["x_init"].reshape(B * S, T, D), int(sch.timesteps[0]), g)
     d = max(d, (eps0 - mine_eps).abs().max().item())
     assert n_clipped > 0 and (out[False] - out[True]).abs().max().item() > 1e-3, "the fixture must exercise the clip (the two step variants differ only there)"
+    # yardstick: the same loops under bf16 autocast (the precision the vendored policy runs in). With the default step the network's own
+    # eps stays in the update even where x0 was clipped, so the 10-step recursion is far more sensitive to rounding than the re-derived
+    # variant (which contracts onto the clip bounds): bf16 PyTorch is ~1e-2 from fp32 there, ~2e-3 with use_clipped_model_output=True
+    yard = {}
+    for flag in (False, True):
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            o16 = o_u.ddim_sample(sd, inp["global_cond"], inp["x_init"], cfg["num_train_timesteps"], cfg["num_inference_steps"], use_clipped_model_output=flag).float()
+        e = (o16 - out[flag]).abs()
+        yard[flag] = dict(mean=e.mean().item(), max=e.max().item())
     return dict(seed=4, B=B, eps0=eps0.reshape(B, S, T, D).clone(), samples=out[False], samples_use_clipped_model_output=out[True],
+                bf16_autocast_err=yard[False], bf16_autocast_err_use_clipped_model_output=yard[True],
                 clipped_x0_elements=n_clipped, timesteps=sch.timesteps.clone(), oracle_max_abs_diff=d)
 
 

@@ -48,14 +48,18 @@ def test_unet1d_ddim_vs_vendored_reference_fixture(built_lib):
     eng = UNet1DHead(sd, cfg, DEV, max_envs=B)
     out = eng.sample_traj(inp["global_cond"].to(DEV), inp["x_init"].to(DEV)).float().cpu()
     d = (out - gold["samples"]).abs()
-    print(f"unet1d ddim samples: mean|err| {d.mean():.3e} max|err| {d.max():.3e} (range [-1, 1])")
-    assert d.mean().item() < 2e-3 and d.max().item() < 1e-1     # clip_sample: a sample near +-1 can flip sides of the clip within bf16 noise
+    y = gold["bf16_autocast_err"]
+    print(f"unet1d ddim samples: mean|err| {d.mean():.3e} max|err| {d.max():.3e} (range [-1, 1]); bf16-autocast PyTorch vs fp32: mean {y['mean']:.3e} max {y['max']:.3e}")
+    # diffusers' default step keeps the network's eps where x0 was clipped: the recursion does not contract onto the clip bounds and bf16
+    # PyTorch itself sits at ~1.4e-2 from fp32 on this fixture. Bar: not further from fp32 than bf16 PyTorch is.
+    assert d.mean().item() <= y["mean"] and d.max().item() <= max(1.5 * y["max"], 1e-1)
     assert eng.sched["timesteps"] == gold["timesteps"].tolist()
     # the other value of diffusers' step(use_clipped_model_output=) has its own fixture
     out_c = eng.sample_traj(inp["global_cond"].to(DEV), inp["x_init"].to(DEV), use_clipped_model_output=True).float().cpu()
     dc = (out_c - gold["samples_use_clipped_model_output"]).abs()
-    print(f"unet1d ddim samples (use_clipped_model_output): mean|err| {dc.mean():.3e} max|err| {dc.max():.3e}")
-    assert dc.mean().item() < 2e-3 and dc.max().item() < 1e-1
+    yc = gold["bf16_autocast_err_use_clipped_model_output"]
+    print(f"unet1d ddim samples (use_clipped_model_output): mean|err| {dc.mean():.3e} max|err| {dc.max():.3e}; bf16-autocast PyTorch mean {yc['mean']:.3e}")
+    assert dc.mean().item() <= max(yc["mean"], 2e-3) and dc.max().item() <= max(1.5 * yc["max"], 1e-1)
     assert (out - out_c).abs().max().item() > 1e-2           # the fixture clips: the two variants are different trajectories
     # first noise prediction alone (the network without the sampler)
     nseq = B * eng.S
@@ -84,9 +88,11 @@ def test_unet1d_b64_vs_per_env_oracle_and_timing(built_lib):
     for b in (0, 63):
         with torch.no_grad():
             ref = o_u.ddim_sample(sd, inp["global_cond"][b:b + 1], inp["x_init"][b:b + 1], cfg["num_train_timesteps"], cfg["num_inference_steps"])
-        d = (out[b] - ref[0]).abs()
-        print(f"unet1d B=64 env {b}: mean|err| {d.mean():.3e} max|err| {d.max():.3e}")
-        assert d.mean().item() < 2e-3 and d.max().item() < 1e-1
+            with torch.autocast("cpu", dtype=torch.bfloat16):      # yardstick: the same env in bf16 PyTorch (see the fixture test above)
+                r16 = o_u.ddim_sample(sd, inp["global_cond"][b:b + 1], inp["x_init"][b:b + 1], cfg["num_train_timesteps"], cfg["num_inference_steps"]).float()
+        d, y = (out[b] - ref[0]).abs(), (r16[0] - ref[0]).abs()
+        print(f"unet1d B=64 env {b}: mean|err| {d.mean():.3e} max|err| {d.max():.3e}; bf16-autocast PyTorch mean {y.mean():.3e} max {y.max():.3e}")
+        assert d.mean().item() <= 1.25 * y.mean().item() and d.max().item() <= max(1.5 * y.max().item(), 1e-1)
     torch.cuda.synchronize()
     a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
