@@ -67,6 +67,8 @@ def parse():
                     help="n1_dual: prefix-KV reuse variant - the K/V of system prompt + instruction + first history frame (296 of the 920 prompt "
                          "tokens, identical between the System-2 calls of an episode) come from a per-env cache; the call encodes 3 of 4 frames and "
                          "prefills 624 tokens per env. Exact (causal mask); algorithmic FLOPs are accounted accordingly. Reported next to the headline.")
+    ap.add_argument("--fuse-rownorm", action="store_true",
+                    help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
     ap.add_argument("--no-raw-frames", action="store_true",
                     help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
     a, rest = ap.parse_known_args()
@@ -241,6 +243,8 @@ class N1Dual:
         weights = synthetic.LazyDeviceWeights(spec, dev, seed=0)
         self.model = InternVLAN1ForCausalLM(weights, qcfg, "nextdit_async", scfg, device=dev, max_envs=B, max_seq_len=1024,
                                             max_patches=mmax * self.N_IMG * per, max_s2_seqs=mmax)
+        if getattr(a, "fuse_rownorm", False):
+            self.model.s1.fuse_rownorm = True
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
         lim = qcfg["image_token_id"] - 16
         ids = torch.randint(0, lim, (B, self.S), device=dev, generator=g)
@@ -326,7 +330,7 @@ class N1Dual:
             from internnav_amd.nextdit import NextDiTSystem1
             from internnav_amd.policy import _Prefixed
 
-            self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax)
+            self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
             self.side = torch.cuda.Stream(device=dev)
             nA = B - min(self.mb)
             self.latA, self.imgA, self.xA = (torch.empty((nA,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
