@@ -42,18 +42,15 @@ __device__ __forceinline__ bf16x8 ln_apply8(bf16x8 x, float mean, float rstd, co
     return y;
 }
 
-template <int NH, int OCC>
-__global__ __launch_bounds__(NH * 64, OCC) void dit_attn_kernel(DitAttnArgs p) {
+template <int NH>
+__global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
     constexpr int HD = 64, D = NH * HD, VT_LD = 40;
     __shared__ float stats[3][32][2];
     __shared__ __attribute__((aligned(16))) bf16 Vt[NH][HD * VT_LD];
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
     const int g = lane >> 4, lq = lane & 15;
+    const int seq = blockIdx.x, env = seq / p.seq_per_env;
     const int T = p.T;
-    // sequence loop: a launch with fewer workgroups than sequences is persistent (every workgroup walks the sequences with stride gridDim.x)
-#pragma unroll 1
-    for (int seq = blockIdx.x; seq < p.nseq; seq += gridDim.x) {
-    const int env = seq / p.seq_per_env;
     const bf16* __restrict__ base = reinterpret_cast<const bf16*>(p.X) + (size_t)seq * T * p.ldx;
     // Rows / keys beyond T or Lz are read from a clamped (valid) row instead of being predicated: their scores are masked to -inf and
     // their outputs never stored, and no load needs an exec-mask branch.
@@ -75,7 +72,7 @@ __global__ __launch_bounds__(NH * 64, OCC) void dit_attn_kernel(DitAttnArgs p) {
     //      (segment, 16-token tile) unit; with X = its [16 tokens x D] slice, X . 1^T gives the row sums and diag(X . X^T) the row sums
     //      of squares (bf16 products are exact in fp32), 2 x D/32 MFMAs instead of ~500 VALU instructions per wave
     {
-        static_assert(NH == 6 && OCC >= 1, "one (segment, token tile) unit per wave: 3 segments x 2 tiles");
+        static_assert(NH == 6, "one (segment, token tile) unit per wave: 3 segments x 2 tiles");
         constexpr int NCH = D / 32;
         const int us = h >> 1, utt = h & 1, useg = us == 2 ? 3 : us;
         const int utok = utt * 16 + lq;
@@ -289,8 +286,6 @@ __global__ __launch_bounds__(NH * 64, OCC) void dit_attn_kernel(DitAttnArgs p) {
             }
         }
     }
-    if (seq + (int)gridDim.x < p.nseq) __syncthreads();    // stats / Vt are rewritten by the next sequence
-    }
 }
 
 // condition V [env][Lz rows][heads x 64] -> V2T[env][head][64 dims][64 key slots], slot = dit_vt_pos(key), zero beyond Lz
@@ -325,13 +320,7 @@ int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream) {
     if (p.nseq == 0) return 0;
     const double D = p.heads * 64.0, rows = (double)p.nseq * p.T;
     InaProfScope prof(INA_PROF_ATTN, 4.0 * rows * D * (p.T + p.Lz), 2.0 * rows * D * 5.0, stream);
-    // experiments (round 3): INA_DIT_PERSIST=<workgroups per CU> launches a persistent grid, INA_DIT_OCC=4 the 128-register build
-    static int persist = -1, occ = -1;
-    if (persist < 0) persist = getenv("INA_DIT_PERSIST") ? atoi(getenv("INA_DIT_PERSIST")) : 0;
-    if (occ < 0) occ = getenv("INA_DIT_OCC") ? atoi(getenv("INA_DIT_OCC")) : 3;
-    const int grid = (persist > 0 && p.nseq > 256 * persist) ? 256 * persist : p.nseq;
-    if (occ >= 4) hipLaunchKernelGGL((dit_attn_kernel<6, 4>), dim3(grid), dim3(6 * 64), 0, stream, p);
-    else hipLaunchKernelGGL((dit_attn_kernel<6, 3>), dim3(grid), dim3(6 * 64), 0, stream, p);
+    hipLaunchKernelGGL(dit_attn_kernel<6>, dim3(p.nseq), dim3(6 * 64), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

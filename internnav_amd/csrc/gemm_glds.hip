@@ -38,12 +38,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int total_tiles = tiles_m * tiles_n;
-    // tile loop: a launch with fewer workgroups than tiles is PERSISTENT (grid = resident slots, every workgroup walks the tile list
-    // with stride gridDim.x; gridDim.x is a multiple of 8, so a workgroup stays inside its XCD's contiguous chunk of the tile order)
-#pragma unroll 1
-    for (int bid = blockIdx.x; bid < total_tiles; bid += gridDim.x) {
-    const int id = xcd_remap(bid, total_tiles);
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     int tm, tn;
     if (p.group_m > 1) {
         // grouped order: GM row-tiles x all column-tiles per group, row index fastest -> the ~32 workgroups an XCD runs at a time
@@ -168,8 +163,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_glds_kernel(GemmArgs p)
         gemm_store_tile_staged<C::FM, C::FN, C::TM, C::TN, ALL>(p, acc, m0, n0, wm, wn, lane, scratch);
     } else {
         gemm_store_tile<C::FM, C::FN, C::TM, C::TN>(p, acc, m0, n0, wm, wn, lane);
-    }
-    if (bid + (int)gridDim.x < total_tiles) __syncthreads();   // the epilogue scratch becomes the next tile's stage buffers
     }
 }
 
@@ -443,18 +436,6 @@ int launch_glds(const GemmArgs& p, hipStream_t stream) {
         attr_done[staged] = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    // persistent launch (INA_GEMM_PERSIST=1, single-buffer kernels): as many workgroups as the chip holds at once, each walking the tile list
-    static int persist = -1, slots[2] = {0, 0};
-    if (persist < 0) persist = (getenv("INA_GEMM_PERSIST") && atoi(getenv("INA_GEMM_PERSIST")) > 0) ? atoi(getenv("INA_GEMM_PERSIST")) : 0;
-    int grid_x = tiles;
-    if (persist && NS == 1 && p.batch == 1) {
-        if (!slots[staged]) {
-            int per_cu = 0;
-            INA_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), C::NT, C::LDS_BYTES));
-            slots[staged] = 256 * (per_cu > 0 ? per_cu : 1);
-        }
-        if (tiles > slots[staged]) grid_x = slots[staged];
-    }
     GemmArgs q = p;
     // auto tile order: with many column tiles the ~32 workgroups an XCD runs concurrently would share one A panel and stream 32
     // different W panels; groups of 8 row-tiles cut the panels per 32 tiles from 33 to 12 (PMC: FETCH_SIZE of the gate/up GEMM,
@@ -463,7 +444,7 @@ int launch_glds(const GemmArgs& p, hipStream_t stream) {
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
                       (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
-    hipLaunchKernelGGL(kern, dim3(grid_x, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, q);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, q);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -326,21 +326,24 @@ class NavDPNet(_NavDPBase):
 
 
 class NavDPPolicyDAT(_NavDPBase):
-    """MI355X engine behind `NavDP_Policy_DPT_CriticSum_DAT.predict_pointgoal_action_async` (internvla_n1/navdp.py:197-253)."""
+    """MI355X engine behind `NavDP_Policy_DPT_CriticSum_DAT.predict_pointgoal_action_async` (internvla_n1/navdp.py:197-253) and, with
+    use_async=False, `predict_pointgoal_action` (:255-289: the 'navdp' System-1 type - condition = [time, mean of the embedded VLM tokens],
+    no RGB-D memory, no TokenCompressor)."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, n_query: int = 4):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, n_query: int = 4, use_async: bool = True):
         device = torch.device(device)
         self.cfg = cfg
         M = cfg["memory_size"]
-        self.M, self.nq_vlm = M, n_query
-        Lc = M * 16 + 2
+        self.M, self.nq_vlm, self.use_async = M, n_query, bool(use_async)
+        Lc = (M * 16 if self.use_async else 0) + 2
         self._init_denoiser(state_dict, device, cfg, max_envs, Lc)
         sd, p = state_dict, "rgbd_encoder."
         bf, f32 = torch.bfloat16, torch.float32
-        self.rgb = DinoV2Encoder(sd, p + "rgb_model.", device)
-        self.depth_vit = DinoV2Encoder(sd, p + "depth_model.", device)
-        self.vit_ws = VitWorkspace(max_envs * M, device)
-        self.former = _RGBDFormer(sd, p, device, M * 16, 2 * M * 256, max_envs, "former_query.weight", "former_pe.weight")
+        if self.use_async:
+            self.rgb = DinoV2Encoder(sd, p + "rgb_model.", device)
+            self.depth_vit = DinoV2Encoder(sd, p + "depth_model.", device)
+            self.vit_ws = VitWorkspace(max_envs * M, device)
+            self.former = _RGBDFormer(sd, p, device, M * 16, 2 * M * 256, max_envs, "former_query.weight", "former_pe.weight")
         self.cond_pos = sd["cond_pos_embed"][0].to(device=device, dtype=f32).contiguous()
         self.out_pos = sd["out_pos_embed"][0].to(device=device, dtype=f32).contiguous()
         self._set_time_tables(sd["cond_pos_embed"][0, 0])
@@ -349,6 +352,9 @@ class NavDPPolicyDAT(_NavDPBase):
         V = cfg["vlm_token_dim"]
         self.m0 = torch.empty(max_envs * n_query, V // 4, dtype=bf, device=device)
         self.m1 = torch.empty(max_envs * n_query, V // 8, dtype=bf, device=device)
+        if not self.use_async:
+            self.gc_tok = torch.empty(max_envs * n_query, self.D, dtype=bf, device=device)
+            return
         # TokenCompressor (navdp_backbone.py:60-99): 1 learned query, 8 heads
         g = "goal_compressor."
         self.tok_pe = sd[g + "token_positional_encoding.position_embedding.weight"][:n_query].to(device=device, dtype=f32).contiguous()
@@ -399,6 +405,24 @@ class NavDPPolicyDAT(_NavDPBase):
                    batched=True)
         sample = self._denoise(B, x_init, step_noise)
         return sample.view(B, self.S, self.T, 3)
+
+
+    def predict_pointgoal_action(self, vlm_tokens: torch.Tensor, x_init: torch.Tensor, step_noise: torch.Tensor) -> torch.Tensor:
+        """the non-async 'navdp' System-1 (internvla_n1/navdp.py:255-289): vlm_embed = mean over the tokens of vlm_embed_mlp(vlm_tokens),
+        condition = [time, vlm_embed] + cond_pos_embed[:2], num_train_timesteps DDPM steps. vlm_tokens bf16 [B, n_query, 3584]; x_init f32
+        [B,S,T,3]; step_noise f32 [K,B,S,T,3] -> f32 [B,S,T,3]. Every env of the batch gets its own condition (the reference keeps only
+        the first sample of a batch, :265-268 - it is only ever called with batch 1)."""
+        assert not self.use_async, "this engine was built for the async head: use predict_pointgoal_action_async"
+        B, nq = vlm_tokens.shape[0], self.nq_vlm
+        assert B <= self.b_max and vlm_tokens.shape[1] == nq
+        D, Lc = self.D, self.Lc
+        rows = B * nq
+        ops.linear(vlm_tokens.reshape(rows, -1), self.mlp[0][0], bias=self.mlp[0][1], act="relu", out=self.m0[:rows])
+        ops.linear(self.m0[:rows], self.mlp[1][0], bias=self.mlp[1][1], act="relu", out=self.m1[:rows])
+        ops.linear(self.m1[:rows], self.mlp[2][0], bias=self.mlp[2][1], out=self.gc_tok[:rows])
+        cond3 = self.cond[: B * Lc].view(B, Lc, D)
+        ops.pool_act(self.gc_tok[:rows], cond3[:, 1, :], T=nq, pos=self.cond_pos[1:2].contiguous())      # mean over tokens + cond_pos_embed[1]
+        return self._denoise(B, x_init, step_noise).view(B, self.S, self.T, 3)
 
 
 class NavDPModelConfig:

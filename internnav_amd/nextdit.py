@@ -43,7 +43,10 @@ def _interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 class NextDiTSystem1:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, fuse_rownorm: bool = False,
-                 fuse_ffn: bool = False):
+                 fuse_ffn: bool = False, use_async: bool = True):
+        """use_async: the 'async' System-1 types condition the DiT on [32 memory tokens of the two look-down frames | projected VLM latents]
+        (internvla_n1.py:364-381); without it ('nextdit': :382-383) the condition is the n_query projected latents alone - no DINOv2,
+        MemoryEncoder or QFormer weights are read."""
         dev = torch.device(device)
         bf, f32 = torch.bfloat16, torch.float32
         sd = state_dict
@@ -60,7 +63,8 @@ class NextDiTSystem1:
         D, L, S, T = cfg["dit_dim"], cfg["latent_dim"], cfg["sample_num"], cfg["predict_size"]
         self.D, self.L, self.S, self.T, self.nq = D, L, S, T, cfg["n_query"]
         self.Fr = cfg["memory_frames"]
-        self.Lz = 32 + self.nq
+        self.use_async = bool(use_async)
+        self.Lz = (32 if self.use_async else 0) + self.nq
         self.nl, self.nh = cfg["dit_layers"], cfg["dit_heads"]
 
         def w(k):
@@ -71,25 +75,27 @@ class NextDiTSystem1:
 
         # ---- condition path
         self.cp = [(w("cond_projector.0.weight"), f("cond_projector.0.bias")), (w("cond_projector.2.weight"), f("cond_projector.2.bias"))]
-        self.vit = DinoV2Encoder(sd, "rgb_model.", dev)
-        self.vit_ws = VitWorkspace(max_envs * self.Fr, dev)
         nm = self.Fr * 256
         self.nm = nm
-        self.mem_pos = sd["memory_encoder.memory_pos"][:nm].to(device=dev, dtype=f32).contiguous()
+        if self.use_async:
+            self.vit = DinoV2Encoder(sd, "rgb_model.", dev)
+            self.vit_ws = VitWorkspace(max_envs * self.Fr, dev)
+            self.mem_pos = sd["memory_encoder.memory_pos"][:nm].to(device=dev, dtype=f32).contiguous()
         self.me_layers = []
-        for i in range(3):
+        for i in range(3 if self.use_async else 0):
             p = f"memory_encoder.encoder.layers.{i}"
             self.me_layers.append(dict(sa_w=w(p + ".self_attn.in_proj_weight"), sa_b=f(p + ".self_attn.in_proj_bias"),
                                        sa_ow=w(p + ".self_attn.out_proj.weight"), sa_ob=f(p + ".self_attn.out_proj.bias"),
                                        l1w=w(p + ".linear1.weight"), l1b=f(p + ".linear1.bias"), l2w=w(p + ".linear2.weight"),
                                        l2b=f(p + ".linear2.bias"), n1=(f(p + ".norm1.weight"), f(p + ".norm1.bias")),
                                        n2=(f(p + ".norm2.weight"), f(p + ".norm2.bias"))))
-        self.me_ws = _SeqWorkspace(max_envs * nm, D, 2048, dev)
-        self.memcat = torch.empty(max_envs * nm, L, dtype=bf, device=dev)      # [feat | memory_feat] per token
-        self.q_layers = [_DecoderLayer(sd, f"rgb_resampler.decoder.layers.{i}", dev, L) for i in range(3)]
-        self.q_init = (sd["rgb_resampler.query_tokens"].float() + sd["rgb_resampler.query_pos"].float()).to(dev).contiguous()
-        self.q_ws = _SeqWorkspace(max_envs * 32, L, 2048, dev)
-        self.q_kv = torch.empty(max_envs * nm, 2 * L, dtype=bf, device=dev)
+        if self.use_async:
+            self.me_ws = _SeqWorkspace(max_envs * nm, D, 2048, dev)
+            self.memcat = torch.empty(max_envs * nm, L, dtype=bf, device=dev)      # [feat | memory_feat] per token
+            self.q_layers = [_DecoderLayer(sd, f"rgb_resampler.decoder.layers.{i}", dev, L) for i in range(3)]
+            self.q_init = (sd["rgb_resampler.query_tokens"].float() + sd["rgb_resampler.query_pos"].float()).to(dev).contiguous()
+            self.q_ws = _SeqWorkspace(max_envs * 32, L, 2048, dev)
+            self.q_kv = torch.empty(max_envs * nm, 2 * L, dtype=bf, device=dev)
         self.cp_h = torch.empty(max_envs * self.nq, L, dtype=bf, device=dev)
         self.z = torch.empty(max_envs * self.Lz, L, dtype=bf, device=dev)
         # ---- DiT
@@ -176,56 +182,82 @@ class NextDiTSystem1:
             # the last LayerNorm also lands in the right half of the [feat | memory_feat] buffer the QFormer attends to
             ops.norm(x, Lr["n2"][0], Lr["n2"][1], eps=1e-5, out=self.memcat[:rows, D:] if last else h, out32=None if last else x)
 
-    def encode_condition(self, B: int, traj_latents: torch.Tensor, images_dp: torch.Tensor):
-        """internvla_n1.py:364-381 -> z [B, 36, 768] and everything of the DiT that only depends on it."""
+    def _cond_set(self, null: bool = False) -> dict:
+        """buffers of everything the DiT derives from ONE set of condition tokens z: caption projection, pooled caption embedding, per-layer
+        cross-attention K|V (+ the transposed V image) and the adaLN modulation vectors. Set 0 = the real condition (buffers allocated in
+        __init__); the null set (all-zero tokens, the unconditional half of classifier-free guidance, internvla_n1.py:384-385) is created
+        on first use."""
+        if not null:
+            return dict(z=self.z, cap_h=self.cap_h, enc=self.enc, enc_n=self.enc_n, pool=self.pool, pool_n=self.pool_n, cap_emb=self.cap_emb,
+                        silu_temb=self.silu_temb, mod=self.mod, kv2=[Lr["kv2"] for Lr in self.layers], v2t=[Lr["v2t"] for Lr in self.layers])
+        if getattr(self, "_null", None) is None:
+            e = torch.empty_like
+            self._null = dict(z=torch.zeros_like(self.z), cap_h=e(self.cap_h), enc=e(self.enc), enc_n=e(self.enc_n), pool=e(self.pool),
+                              pool_n=e(self.pool_n), cap_emb=e(self.cap_emb), silu_temb=e(self.silu_temb), mod=e(self.mod),
+                              kv2=[e(Lr["kv2"]) for Lr in self.layers], v2t=[e(Lr["v2t"]) for Lr in self.layers])
+            self.x_u = torch.empty_like(self.x)                       # second residual stream + its prediction buffers (guidance != 1)
+            self.pred = [torch.empty_like(self.sample), torch.empty_like(self.sample)]
+        return self._null
+
+    def encode_condition(self, B: int, traj_latents: torch.Tensor, images_dp: torch.Tensor, cs: dict = None):
+        """internvla_n1.py:364-383 -> z [B, Lz, 768] (async: 32 memory tokens | n_query projected latents; otherwise the latents alone)
+        and everything of the DiT that only depends on it."""
         D, L, nq, nm, Lz = self.D, self.L, self.nq, self.nm, self.Lz
+        cs = cs or self._cond_set()
         z3 = self.z[: B * Lz].view(B, Lz, L)
         rows = B * nq
         ops.linear(traj_latents.reshape(rows, -1), self.cp[0][0], bias=self.cp[0][1], act="gelu_tanh", out=self.cp_h[:rows])
-        ops.linear(self.cp_h[:rows].view(B, nq, L), self.cp[1][0], bias=self.cp[1][1], out=z3[:, 32:, :], batched=True)
-        # DINOv2 on the look-down frames: tokens -> left half of memcat, tokens + memory_pos -> MemoryEncoder stream
-        mrows = B * nm
-        self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
-                         extra_outputs=[(self.me_ws.h[:mrows], self.me_ws.x[:mrows], None, self.mem_pos)])
-        self._memory_encoder(B)
-        # QFormer (internvla_n1_arch.py:97-118): 32 learned queries attend to [feat | memory_feat]
-        qrows = B * 32
-        ops.embed3(None, None, None, out=self.q_ws.x[:qrows], pos=self.q_init, rows=qrows)
-        ops.embed3(None, None, None, out=self.q_ws.h[:qrows], pos=self.q_init, rows=qrows)
-        for Lr in self.q_layers:
-            ops.linear(self.memcat[:mrows], Lr.ca_kvw, bias=Lr.ca_kvb, out=self.q_kv[:mrows])
-            decoder_layer_postnorm(Lr, self.q_ws, B, 32, self.q_kv[:mrows], B, nm, 12, "relu")
-        z3[:, :32, :].copy_(self.q_ws.h[:qrows].view(B, 32, L))  # data movement only: memory tokens into the condition buffer
-        # caption_projection, pooled caption embedding (nextdit_traj.py:340-341; all-ones mask -> plain mean)
+        ops.linear(self.cp_h[:rows].view(B, nq, L), self.cp[1][0], bias=self.cp[1][1], out=z3[:, Lz - nq:, :], batched=True)
+        if self.use_async:
+            # DINOv2 on the look-down frames: tokens -> left half of memcat, tokens + memory_pos -> MemoryEncoder stream
+            mrows = B * nm
+            self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                             extra_outputs=[(self.me_ws.h[:mrows], self.me_ws.x[:mrows], None, self.mem_pos)])
+            self._memory_encoder(B)
+            # QFormer (internvla_n1_arch.py:97-118): 32 learned queries attend to [feat | memory_feat]
+            qrows = B * 32
+            ops.embed3(None, None, None, out=self.q_ws.x[:qrows], pos=self.q_init, rows=qrows)
+            ops.embed3(None, None, None, out=self.q_ws.h[:qrows], pos=self.q_init, rows=qrows)
+            for Lr in self.q_layers:
+                ops.linear(self.memcat[:mrows], Lr.ca_kvw, bias=Lr.ca_kvb, out=self.q_kv[:mrows])
+                decoder_layer_postnorm(Lr, self.q_ws, B, 32, self.q_kv[:mrows], B, nm, 12, "relu")
+            z3[:, :32, :].copy_(self.q_ws.h[:qrows].view(B, 32, L))  # data movement only: memory tokens into the condition buffer
+        self._derive_condition(B, cs)
+
+    def _derive_condition(self, B: int, cs: dict):
+        """caption_projection, pooled caption embedding (nextdit_traj.py:340-341; all-ones mask -> plain mean) and the per-layer
+        cross-attention K/V (attn2.to_k/to_v on norm1_context(enc), norm_k across heads) of the condition tokens cs['z']."""
+        D, Lz = self.D, self.Lz
         zr = B * Lz
-        ops.linear(self.z[:zr], self.cap[0][0], bias=self.cap[0][1], act="gelu_tanh", out=self.cap_h[:zr])
-        ops.linear(self.cap_h[:zr], self.cap[1][0], bias=self.cap[1][1], out=self.enc[:zr])
-        ops.pool_act(self.enc[:zr], self.pool[:B], T=Lz)
-        ops.norm(self.pool[:B], self.ce_ln[0], self.ce_ln[1], eps=1e-5, out=self.pool_n[:B])
-        ops.linear(self.pool_n[:B], self.ce_w, bias=self.ce_b, out=self.cap_emb[:B])
-        # per-layer cross-attention K/V of the condition (attn2.to_k/to_v on norm1_context(enc), norm_k across heads)
-        for Lr in self.layers:
-            ops.norm(self.enc[:zr], Lr["ctx"], None, eps=1e-5, rms=True, out=self.enc_n[:zr])
-            kv = Lr["kv2"][:zr]
-            ops.linear(self.enc_n[:zr], Lr["wkv2"], out=kv)
+        ops.linear(cs["z"][:zr], self.cap[0][0], bias=self.cap[0][1], act="gelu_tanh", out=cs["cap_h"][:zr])
+        ops.linear(cs["cap_h"][:zr], self.cap[1][0], bias=self.cap[1][1], out=cs["enc"][:zr])
+        ops.pool_act(cs["enc"][:zr], cs["pool"][:B], T=Lz)
+        ops.norm(cs["pool"][:B], self.ce_ln[0], self.ce_ln[1], eps=1e-5, out=cs["pool_n"][:B])
+        ops.linear(cs["pool_n"][:B], self.ce_w, bias=self.ce_b, out=cs["cap_emb"][:B])
+        for l, Lr in enumerate(self.layers):
+            ops.norm(cs["enc"][:zr], Lr["ctx"], None, eps=1e-5, rms=True, out=cs["enc_n"][:zr])
+            kv = cs["kv2"][l][:zr]
+            ops.linear(cs["enc_n"][:zr], Lr["wkv2"], out=kv)
             kk = kv.view(zr * 2, D)
             ops.norm(kk, Lr["k2n"][0], Lr["k2n"][1], eps=1e-5, out=kk, rows=zr, in_map=(1, 2, 0), out_map=(1, 2, 0))
-            ops.dit_v2t(kv.view(B, Lz, 2, self.nh, D // self.nh), self.nh, Lr["v2t"])   # V image the fused attention stage consumes
+            ops.dit_v2t(kv.view(B, Lz, 2, self.nh, D // self.nh), self.nh, cs["v2t"][l])   # V image the fused attention stage consumes
 
     # ------------------------------------------------------------------------------------------------ DiT
-    def _dit_layer(self, l: int, B: int):
+    def _dit_layer(self, l: int, B: int, cs: dict = None, x_buf: torch.Tensor = None):
         Lr, D, S, T, Lz, nh = self.layers[l], self.D, self.S, self.T, self.Lz, self.nh
+        cs = cs or self._cond_set()
         rows, nseq, hd = B * S * T, B * S, D // self.nh
-        x, h, att, qkvq, proj, ff = self.x[:rows], self.h[:rows], self.att[:rows], self.qkvq[:rows], self.proj[:rows], self.ff[:rows]
-        m = self.mod[:B, l * 4 * D:(l + 1) * 4 * D]
+        x, h, att, qkvq, proj, ff = (self.x if x_buf is None else x_buf)[:rows], self.h[:rows], self.att[:rows], self.qkvq[:rows], self.proj[:rows], self.ff[:rows]
+        mod = cs["mod"]
+        m = mod[:B, l * 4 * D:(l + 1) * 4 * D]
         scale_msa, gate_msa, scale_mlp, gate_mlp = m[:, :D], m[:, D:2 * D], m[:, 2 * D:3 * D], m[:, 3 * D:]
         if l == 0:   # later blocks get their pre-norm from the previous block's ffn_norm2 launch (chained)
             ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
         ops.linear(h, Lr["wq"], out=qkvq)
         # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
         # env's condition rows (shared by its S samples): one launch, the projection row is read once
-        kv5 = Lr["kv2"][: B * Lz].view(B, Lz, 2, nh, hd)
-        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, Lr["v2t"], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5)
+        kv5 = cs["kv2"][l][: B * Lz].view(B, Lz, 2, nh, hd)
+        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5)
         if self.fuse_rownorm:
             # attn2.to_out as a row-block GEMM whose epilogue does x += tanh(gate) * norm2(.) and h = ffn_norm1(x) * (1 + scale_mlp)
             ops.gemm_rownorm(att, Lr["wo"], Lr["n2"], x, gate=gate_msa, h=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp, mod_div=S * T, eps=1e-5)
@@ -236,7 +268,7 @@ class NextDiTSystem1:
                      out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
         # linear_1/3 + SiLU gate, linear_2, then x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
         last = l + 1 >= self.nl
-        nxt = None if last else self.mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
+        nxt = None if last else mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
         if self.fuse_ffn:
             ops.dit_ffn(h, Lr["w13"], Lr["w2"], Lr["fn2"], x, gate=gate_mlp, h=None if last else h,
                         gamma2=None if last else self.layers[l + 1]["n1"], mod_scale2=nxt, mod_div=S * T, eps=1e-5)
@@ -253,24 +285,49 @@ class NextDiTSystem1:
                 ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x,
                          out2=h, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt)
 
-    def generate_traj(self, traj_latents: torch.Tensor, images_dp: torch.Tensor, x_init: torch.Tensor) -> torch.Tensor:
-        """traj_latents bf16 [B,n_query,3584]; images_dp bf16|f32 [B,2,224,224,3] in 0..1; x_init f32 [B,S,T,3] (the initial
-        noise the reference draws with randn_tensor)  ->  latents f32 [B,S,T,3] (x4-scaled waypoint increments)."""
+    def generate_traj(self, traj_latents: torch.Tensor, images_dp: torch.Tensor, x_init: torch.Tensor, guidance_scale: float = 1.0) -> torch.Tensor:
+        """traj_latents bf16 [B,n_query,3584]; images_dp bf16|f32 [B,2,224,224,3] in 0..1 (ignored without 'async'); x_init f32 [B,S,T,3]
+        (the initial noise the reference draws with randn_tensor)  ->  latents f32 [B,S,T,3] (x4-scaled waypoint increments).
+        guidance_scale: classifier-free guidance weight of internvla_n1.py:386-387,425-427 - noise = u + g (c - u) with u the prediction
+        under the all-zero condition. g == 1 returns c (the null half has zero weight and is not computed); g != 1 runs the DiT twice
+        per step (conditional and null condition set) and combines the two predictions in the Euler update."""
         B = traj_latents.shape[0]
         assert B <= self.b_max and traj_latents.dtype == torch.bfloat16
         D, S, T = self.D, self.S, self.T
         rows = B * S * T
-        self.encode_condition(B, traj_latents, images_dp)
+        cs = self._cond_set()
+        self.encode_condition(B, traj_latents, images_dp, cs)
+        cfg_on = float(guidance_scale) != 1.0
+        sets = [(cs, self.x)]
+        if cfg_on:
+            from . import train_ops as Tr
+
+            null = self._cond_set(null=True)
+            self._derive_condition(B, null)           # input independent (z = 0): constants of the weights, recomputed per call for simplicity
+            sets.append((null, self.x_u))
         sample = self.sample[:rows]
         sample.copy_(x_init.reshape(rows, 3))
         nmod = self.nl * 4 * D
+        if cfg_on:       # per-step weights of the two predictions: dt * g for the conditional, dt * (1 - g) for the null one  [steps, 2, 3]
+            dts = torch.from_numpy(self.sigmas[1:] - self.sigmas[:-1]).float()
+            g = float(guidance_scale)
+            coefs = torch.stack([dts * g, dts * (1.0 - g)], 1)[:, :, None].expand(-1, -1, 3).contiguous().to(self.device)
         for i in range(self.cfg["num_inference_steps"]):
-            ops.pool_act(self.cap_emb[:B], self.silu_temb[:B], T=1, pos=self.time_emb[i:i + 1], act="silu")
-            ops.linear(self.silu_temb[:B], self.mod_w, bias=self.mod_b, out=self.mod[:B])
-            ops.embed3(sample, self.ae_w, self.ae_b, out=self.x[:rows], pos=self.pos_tab)
-            for l in range(self.nl):
-                self._dit_layer(l, B)
             dt = float(self.sigmas[i + 1] - self.sigmas[i])
-            ops.head3(self.x[:rows], self.head_w, self.head_b, None, None, eps=1e-6, mode=2, sample=sample, coef=(dt, 0, 0, 0, 0),
-                      mod_scale=self.mod[:B, nmod:], mod_div=S * T)
+            for k, (c, xb) in enumerate(sets):
+                ops.pool_act(c["cap_emb"][:B], c["silu_temb"][:B], T=1, pos=self.time_emb[i:i + 1], act="silu")
+                ops.linear(c["silu_temb"][:B], self.mod_w, bias=self.mod_b, out=c["mod"][:B])
+                ops.embed3(sample, self.ae_w, self.ae_b, out=xb[:rows], pos=self.pos_tab)
+                for l in range(self.nl):
+                    self._dit_layer(l, B, c, xb)
+                if cfg_on:    # prediction only (mode 0); the update needs both halves
+                    ops.head3(xb[:rows], self.head_w, self.head_b, None, None, eps=1e-6, mode=0, eps_out=self.pred[k][:rows],
+                              mod_scale=c["mod"][:B, nmod:], mod_div=S * T)
+                else:
+                    ops.head3(xb[:rows], self.head_w, self.head_b, None, None, eps=1e-6, mode=2, sample=sample, coef=(dt, 0, 0, 0, 0),
+                              mod_scale=c["mod"][:B, nmod:], mod_div=S * T)
+            if cfg_on:
+                # sample += dt * (u + g (c - u)) = dt g * c + dt (1 - g) * u   (FlowMatchEulerDiscreteScheduler.step on the guided prediction)
+                for pred, wgt in ((self.pred[0], coefs[i, 0:1]), (self.pred[1], coefs[i, 1:2])):
+                    Tr.affine(pred[:rows], scale=wgt, s_div=rows, out=sample, accumulate=True)
         return sample.view(B, S, T, 3)

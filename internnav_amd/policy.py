@@ -192,20 +192,19 @@ class InternVLAN1ForCausalLM:
         """Engine capacity defaults to the longest prompt the reference's harness can build for (num_history, resize, camera size):
         see `s2_capacity`; exceeding it raises `CapacityError` (never a silent STOP)."""
         self.device = torch.device(device)
-        if system1 not in ("nextdit_async", "navdp_async"):
-            # the engines implement the checkpoints' async branches (internvla_n1.py:359-432 'nextdit'+'async', navdp.py:197-253); the
-            # no-memory 'nextdit' / non-async 'navdp' variants take differently shaped inputs and are not built
-            raise NotImplementedError(f"system1={system1!r}: only 'nextdit_async' (DualVLN) and 'navdp_async' are implemented")
+        if system1 not in ("nextdit_async", "navdp_async", "nextdit", "navdp"):
+            # the four System-1 types of generate_traj (internvla_n1.py:359-441): 'nextdit' [+ 'async'] and 'navdp' [+ 'async']
+            raise NotImplementedError(f"system1={system1!r}: known types are 'nextdit_async' (DualVLN), 'navdp_async', 'nextdit', 'navdp'")
         self.config = SimpleNamespace(system1=system1, n_query=qwen_cfg["n_query"], hidden_size=qwen_cfg["t_hidden"],
                                       image_token_id=qwen_cfg["image_token_id"])
         n_s2 = max_s2_seqs or max_envs   # System-2 runs on micro-batches of the envs whose plan expired (agent / bench schedule)
         cap_seq, cap_patches = s2_capacity(num_history, resize_w, resize_h, cam_w, cam_h, n_query=qwen_cfg["n_query"])
         self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=n_s2, max_seq_len=max_seq_len or cap_seq,
                                  max_patches=max_patches or n_s2 * cap_patches)
-        if system1 == "nextdit_async":
-            self.s1 = NextDiTSystem1(_Prefixed(weights, "model."), s1_cfg or synthetic.N1_NEXTDIT_CFG, device, max_envs)
+        if "nextdit" in system1:
+            self.s1 = NextDiTSystem1(_Prefixed(weights, "model."), s1_cfg or synthetic.N1_NEXTDIT_CFG, device, max_envs, use_async="async" in system1)
         else:
-            self.s1 = NavDPPolicyDAT(_Prefixed(weights, "model.navdp."), s1_cfg or synthetic.N1_NAVDP_CFG, device, max_envs)
+            self.s1 = NavDPPolicyDAT(_Prefixed(weights, "model.navdp."), s1_cfg or synthetic.N1_NAVDP_CFG, device, max_envs, use_async="async" in system1)
         self._noise_gen = torch.Generator(device=self.device).manual_seed(0)
 
     # ---- construction
@@ -321,12 +320,17 @@ class InternVLAN1ForCausalLM:
         x_init = noise["x_init"] if noise else torch.randn(B, S, T, 3, device=self.device, generator=self._noise_gen)
         lat = traj_latents.to(self.device, torch.bfloat16)
         if isinstance(s1, NextDiTSystem1):
-            assert guidance_scale == 1.0 and num_inference_steps == s1.cfg["num_inference_steps"] and predict_step_nums == T
-            out = s1.generate_traj(lat, images_dp.to(self.device), x_init)
+            assert num_inference_steps == s1.cfg["num_inference_steps"] and predict_step_nums == T and num_sample_trajs == S
+            # without 'async' the images are not part of the condition (internvla_n1.py:382-383): whatever the caller passes is ignored
+            img = images_dp.to(self.device) if (s1.use_async and torch.is_tensor(images_dp)) else None
+            out = s1.generate_traj(lat, img, x_init, guidance_scale=guidance_scale)
         else:
             K = s1.cfg["num_train_timesteps"]
             sn = noise["step_noise"] if noise else torch.randn(K, B, S, T, 3, device=self.device, generator=self._noise_gen)
-            out = s1.predict_pointgoal_action_async(lat, images_dp.to(self.device), depths_dp.to(self.device), x_init, sn)
+            if s1.use_async:
+                out = s1.predict_pointgoal_action_async(lat, images_dp.to(self.device), depths_dp.to(self.device), x_init, sn)
+            else:                                       # internvla_n1.py:438-439: predict_pointgoal_action(traj_latents) - no images
+                out = s1.predict_pointgoal_action(lat, x_init, sn)
         return out.reshape(B * S, T, 3).clone()
 
 

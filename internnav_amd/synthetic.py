@@ -385,6 +385,11 @@ def n1_full_spec(qwen_cfg=None, system1: str = "nextdit_async") -> Spec:
     """every parameter of an InternVLA-N1 checkpoint: Qwen2.5-VL (visual.*, model.*, lm_head) + the System-1 modules under `model.`."""
     s = qwen_spec(qwen_cfg or QWEN_N1_CFG)
     s1 = n1_nextdit_spec() if "nextdit" in system1 else {("navdp." + k): v for k, v in n1_navdp_spec().items()}
+    if "async" not in system1:
+        # the plain 'nextdit' / 'navdp' types condition on the VLM latents alone (internvla_n1.py:382-383, navdp.py:255-289): the look-down
+        # memory modules are not part of the engines' needs
+        drop = ("rgb_model.", "memory_encoder.", "rgb_resampler.") if "nextdit" in system1 else ("navdp.rgbd_encoder.", "navdp.goal_compressor.")
+        s1 = {k: v for k, v in s1.items() if not k.startswith(drop)}
     s.update({"model." + k: v for k, v in s1.items()})
     return s
 

@@ -137,7 +137,21 @@ def gold_n1_navdp(B=2):
             m.noise_scheduler.step = m.noise_scheduler.__class__.step.__get__(m.noise_scheduler)
         ref = torch.stack(outs)
         mine = o_navdp.n1_navdp_async(sd, inp["vlm_tokens"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"], cfg)
-    return dict(B=B, seed=1, trajectories=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
+        # the non-async 'navdp' System-1 type: predict_pointgoal_action(vlm_tokens) (internvla_n1/navdp.py:255-289), same weights
+        plain = []
+        for b in range(B):
+            _Inject(n1, m.noise_scheduler, inp["x_init"][b], inp["step_noise"][:, b])
+            real_randn = torch.randn
+            torch.randn = lambda *a, **k: inp["x_init"][b].clone()
+            try:
+                plain.append(m.predict_pointgoal_action(inp["vlm_tokens"][b:b + 1], vlm_mask=None))
+            finally:
+                torch.randn = real_randn
+            m.noise_scheduler.step = m.noise_scheduler.__class__.step.__get__(m.noise_scheduler)
+        plain = torch.stack(plain)
+        mine_plain = o_navdp.n1_navdp_plain(sd, inp["vlm_tokens"], inp["x_init"], inp["step_noise"], cfg)
+    d = max((ref - mine).abs().max().item(), (plain - mine_plain).abs().max().item())
+    return dict(B=B, seed=1, trajectories=ref, trajectories_plain=plain, oracle_max_abs_diff=d)
 
 
 def gold_n1_nextdit(B=2):
@@ -171,18 +185,22 @@ def gold_n1_nextdit(B=2):
 
     mean = torch.FloatTensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)
     std = torch.FloatTensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
-    outs = []
-    with torch.no_grad():
+    def run_reference(guidance_scale, use_async):
+        """generate_traj (internvla_n1.py:359-432) transcribed line by line on the reference modules, one env at a time."""
+        outs = []
         for b in range(B):
             scheduler = FlowMatchEulerDiscreteScheduler()
             traj_latents = m.cond_projector(inp["traj_latents"][b:b + 1])
-            images_dp = inp["images"][b:b + 1].permute(0, 1, 4, 2, 3)
-            images_dp_norm = (images_dp - mean) / std
-            feat = m.rgb_model.get_intermediate_layers(images_dp_norm.flatten(0, 1))[0].unflatten(dim=0, sizes=(1, -1))
-            memory_feat = m.memory_encoder(feat.flatten(1, 2))
-            memory_feat = torch.cat([feat.flatten(1, 2), memory_feat], dim=-1)
-            memory_tokens = m.rgb_resampler(memory_feat)
-            hidden_states = torch.cat([memory_tokens, traj_latents], dim=1)
+            if use_async:
+                images_dp = inp["images"][b:b + 1].permute(0, 1, 4, 2, 3)
+                images_dp_norm = (images_dp - mean) / std
+                feat = m.rgb_model.get_intermediate_layers(images_dp_norm.flatten(0, 1))[0].unflatten(dim=0, sizes=(1, -1))
+                memory_feat = m.memory_encoder(feat.flatten(1, 2))
+                memory_feat = torch.cat([feat.flatten(1, 2), memory_feat], dim=-1)
+                memory_tokens = m.rgb_resampler(memory_feat)
+                hidden_states = torch.cat([memory_tokens, traj_latents], dim=1)
+            else:
+                hidden_states = traj_latents
             hidden_states_input = torch.cat([torch.zeros_like(hidden_states), hidden_states], 0)
             latents = inp["x_init"][b].clone()
             sigmas = np.linspace(1.0, 1 / 10, 10)
@@ -197,12 +215,24 @@ def gold_n1_nextdit(B=2):
                                         z_latents=hidden_states_input)
                 noise_pred = m.action_decoder(noise_pred)
                 noise_pred_uncond, noise_pred = noise_pred.chunk(2)
-                noise_pred = noise_pred_uncond + 1.0 * (noise_pred - noise_pred_uncond)
+                noise_pred = noise_pred_uncond + guidance_scale * (noise_pred - noise_pred_uncond)
                 latents = scheduler.step(noise_pred, t, latents).prev_sample
             outs.append(latents)
+        return torch.stack(outs)
+
+    with torch.no_grad():
+        # the other branches of generate_traj: classifier-free guidance with a weight != 1 (:386-387,425-427) and the plain 'nextdit'
+        # System-1 type whose condition is the projected latents alone (:382-383)
+        variants = {}
+        for name, (gs, asy) in (("cfg_2p5", (2.5, True)), ("plain", (1.0, False)), ("plain_cfg_0p5", (0.5, False))):
+            r = run_reference(gs, asy)
+            o = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"], guidance_scale=gs, use_async=asy)
+            variants[name] = dict(guidance_scale=gs, use_async=asy, latents=r, oracle_max_abs_diff=(r - o).abs().max().item())
+        outs = list(run_reference(1.0, True))
         ref = torch.stack(outs)
         mine = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
-    return dict(B=B, seed=4, latents=ref, oracle_max_abs_diff=(ref - mine).abs().max().item())
+    worst = max([(ref - mine).abs().max().item()] + [v["oracle_max_abs_diff"] for v in variants.values()])
+    return dict(B=B, seed=4, latents=ref, variants=variants, oracle_max_abs_diff=worst)
 
 
 def gold_qwen(B=2, n_img=2):

@@ -189,3 +189,26 @@ def n1_navdp_async(sd, vlm_tokens, images, depths, x_init, step_noise, cfg, retu
         outs.append(x)
     out = torch.stack(outs)
     return (out, goal, rgbd) if return_all else out
+
+
+def n1_navdp_plain(sd, vlm_tokens, x_init, step_noise, cfg):
+    """predict_pointgoal_action (internvla_n1/navdp.py:255-289), the non-async 'navdp' System-1: vlm_embed = mean over the tokens of
+    vlm_embed_mlp(vlm_tokens), condition [time, vlm_embed] + cond_pos_embed[:, :2] (predict_noise with rgbd_embed=None, :186-187).
+    Looped over envs (the reference keeps only sample 0 of a batch, :265-268). vlm_tokens [B,n_query,3584] -> samples [B,S,T,3]."""
+    B = vlm_tokens.shape[0]
+    K = cfg["num_train_timesteps"]
+    sch = DDPMScheduler(num_train_timesteps=K)
+    sch.set_timesteps(K)
+    h = vlm_tokens.float()
+    h = F.relu(linear(h, sd, "vlm_embed_mlp.0"))
+    h = F.relu(linear(h, sd, "vlm_embed_mlp.2"))
+    goal = linear(h, sd, "vlm_embed_mlp.4").mean(dim=1, keepdim=True)
+    empty = goal[:, :0]
+    outs = []
+    for b in range(B):
+        x = x_init[b].float()
+        for i, t in enumerate(sch.timesteps.tolist()):
+            eps = n1_navdp_predict_noise(sd, x, t, goal[b:b + 1], empty[b:b + 1], cfg)
+            x = sch.step(eps, t, x, noise=step_noise[i, b].float()).prev_sample
+        outs.append(x)
+    return torch.stack(outs)

@@ -119,12 +119,16 @@ def condition_tokens(sd, traj_latents, images_dp):
     return torch.cat([tokens, lat], dim=1)
 
 
-def generate_traj(sd, traj_latents, images_dp, x_init, num_inference_steps=10, num_sample_trajs=32, guidance_scale=1.0):
-    """generate_traj, nextdit_async (internvla_n1.py:349-432), looped over envs. traj_latents [B,n_query,3584];
-    images_dp [B,2,224,224,3] in 0..1; x_init [B,S,T,3] (the reference's randn_tensor) -> latents [B,S,T,3]."""
+def generate_traj(sd, traj_latents, images_dp, x_init, num_inference_steps=10, num_sample_trajs=32, guidance_scale=1.0, use_async=True):
+    """generate_traj, 'nextdit' [+ 'async'] (internvla_n1.py:349-432), looped over envs. traj_latents [B,n_query,3584];
+    images_dp [B,2,224,224,3] in 0..1; x_init [B,S,T,3] (the reference's randn_tensor) -> latents [B,S,T,3].
+    use_async=False: hidden_states = cond_projector(traj_latents) alone (:382-383); guidance_scale: the CFG weight of :425-427."""
     B = traj_latents.shape[0]
     S, T = x_init.shape[1:3]
-    hidden = condition_tokens(sd, traj_latents, images_dp)
+    if use_async:
+        hidden = condition_tokens(sd, traj_latents, images_dp)
+    else:
+        hidden = linear(F.gelu(linear(traj_latents.float(), sd, "cond_projector.0"), approximate="tanh"), sd, "cond_projector.2")
     sig = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps).astype(np.float32)
     sigmas = torch.cat([torch.from_numpy(sig), torch.zeros(1)])
     timesteps = (torch.from_numpy(sig) * 1000.0)

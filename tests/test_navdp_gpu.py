@@ -104,6 +104,23 @@ def test_n1_navdp_head_vs_reference_fixture(built_lib):
     assert m < 1e-3 and mx < 5e-2        # north_star tolerance on waypoint increments in [-1, 1] (measured 9.4e-4)
 
 
+def test_n1_navdp_plain_head_vs_reference_fixture(built_lib):
+    """the non-async 'navdp' System-1 type: NavDP_Policy_DPT_CriticSum_DAT.predict_pointgoal_action (internvla_n1/navdp.py:255-289), fixture
+    from the reference module itself; the engine is built from a state dict WITHOUT the RGB-D / goal-compressor modules."""
+    from internnav_amd.navdp import NavDPPolicyDAT
+
+    gold = _gold("n1_navdp")
+    B = gold["B"]
+    sd = {k: v for k, v in W.n1_navdp_state_dict(seed=gold["seed"]).items() if not k.startswith(("rgbd_encoder.", "goal_compressor."))}
+    inp = W.n1_navdp_inputs(B, seed=gold["seed"])
+    net = NavDPPolicyDAT(sd, W.N1_NAVDP_CFG, DEV, max_envs=B, use_async=False)
+    out = net.predict_pointgoal_action(inp["vlm_tokens"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV), inp["step_noise"].to(DEV))
+    m, mx, ref = _stats(out, gold["trajectories_plain"])
+    print(f"n1 navdp (non-async) trajectories: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert m < 1e-3 and mx < 5e-2
+    assert (gold["trajectories_plain"] - gold["trajectories"]).abs().max().item() > 1e-2
+
+
 def test_navdpnet_batch_invariance(built_lib):
     """env b of a B = 3 call == the same env run alone (the reference's batch-1 semantics hold per env in the batched engine)."""
     from internnav_amd.navdp import NavDPNet

@@ -48,3 +48,29 @@ def test_nextdit_generate_traj_vs_reference_fixture(built_lib, fuse_rownorm, fus
     o1 = eng.generate_traj(inp["traj_latents"][1:2].to(DEV, torch.bfloat16), inp["images"][1:2].to(DEV, torch.bfloat16), inp["x_init"][1:2].to(DEV))
     # (not bit-exact: B = 1 and B = 2 select different GEMM tile kernels, i.e. a different fp32 accumulation order)
     assert (o1[0] - out2[1]).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("variant", ["cfg_2p5", "plain", "plain_cfg_0p5"])
+def test_nextdit_other_generate_traj_branches_vs_reference_fixture(built_lib, variant):
+    """the branches of generate_traj the released DualVLN checkpoint does not take (internvla_n1.py:382-387,425-427): classifier-free guidance
+    with a weight != 1 (conditional + all-zero-condition DiT pass per step) and the plain 'nextdit' System-1 type (condition = projected
+    latents alone, no look-down memory) - fixtures from the reference's own modules (oracle/make_golden.py gold_n1_nextdit variants)."""
+    from internnav_amd.nextdit import NextDiTSystem1
+
+    gold = torch.load(Path(__file__).resolve().parent / "golden" / "n1_nextdit.pt", weights_only=True)
+    v = gold["variants"][variant]
+    B = gold["B"]
+    sd = W.n1_nextdit_state_dict(seed=gold["seed"])
+    if not v["use_async"]:          # a plain 'nextdit' checkpoint has none of the memory modules: the engine must not ask for them
+        sd = {k: t for k, t in sd.items() if not k.startswith(("rgb_model.", "memory_encoder.", "rgb_resampler."))}
+    inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
+    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B, use_async=v["use_async"])
+    img = inp["images"].to(DEV, torch.bfloat16) if v["use_async"] else None
+    out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), img, inp["x_init"].to(DEV), guidance_scale=v["guidance_scale"])
+    d = (out.float().cpu() - v["latents"]).abs()
+    ref = v["latents"].abs().max().item()
+    print(f"nextdit {variant}: mean|err| {d.mean().item():.3e} max|err| {d.max().item():.3e} ref max {ref:.2f}")
+    # guidance extrapolates: u + g (c - u) multiplies the two predictions' rounding errors by |g| + |1 - g|
+    amp = abs(v["guidance_scale"]) + abs(1.0 - v["guidance_scale"])
+    assert d.mean().item() < 1e-3 * amp * max(1.0, ref) and d.max().item() < 5e-2 * amp * max(1.0, ref)
+    assert (v["latents"] - gold["latents"]).abs().max().item() > 1e-2          # the variant really is a different computation
