@@ -81,6 +81,12 @@ typedef struct ina_gemm_args {
     int64_t strideA, strideW, strideC, strideR;
     int32_t force_cfg;      /* 0 = auto tile selection */
     int32_t group_m;        /* tile order of the LDS-DMA kernels: 0 = auto, 1 = row-major, n > 1 = groups of n row-tiles (L2 locality) */
+    /* fused input RMSNorm (M <= 16, the single-token decode passes of the LLM: transformers Qwen2RMSNorm in front of q/k/v and gate/up):
+     * C = epilogue(bf16(A * rsqrt(mean(A^2) + norm_eps) * norm_gamma) . W^T) with A of dtype a_dtype - the separate norm launch and its
+     * bf16 round trip disappear (every workgroup normalises the <= 16 rows into LDS while its first weight tiles are in flight) */
+    const float* norm_gamma; /* f32 [K] or NULL (no fused norm; A is bf16) */
+    float norm_eps;
+    int32_t a_dtype;        /* dtype of A when norm_gamma is set: INA_BF16 | INA_F32 */
 } ina_gemm_args;
 int ina_gemm_bf16(const ina_gemm_args* args, void* stream);
 

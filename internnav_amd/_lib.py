@@ -24,6 +24,7 @@ class GemmArgs(C.Structure):
         ("rowscale_div", c_int32), ("batch", c_int32),
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
         ("force_cfg", c_int32), ("group_m", c_int32),
+        ("norm_gamma", c_void_p), ("norm_eps", c_float), ("a_dtype", c_int32),
     ]
 
 

@@ -179,6 +179,13 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
     INA_REQUIRE(!p.glu || (p.N % 32 == 0), "gemm: GLU mode needs N %% 32 == 0");
     // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
     // skinny M: HBM-bound weight streaming with split-K (gemm_skinny.hip) instead of an under-filled tile grid
+    if (p.norm_gamma) {
+        INA_REQUIRE(p.M <= 16 && p.batch <= 1 && p.K % 8 == 0 && p.K <= 4096 && p.N >= 256,
+                    "gemm: the fused input RMSNorm is built for the decode passes (M <= 16 rows, K <= 4096, one batch): M=%d K=%d N=%d batch=%d", p.M, p.K, p.N, p.batch);
+        INA_REQUIRE(p.a_dtype == INA_DT_BF16 || p.a_dtype == INA_DT_F32, "gemm: a_dtype must be bf16 or f32 with norm_gamma");
+        INA_REQUIRE(((uintptr_t)p.norm_gamma % 16) == 0 && (p.lda % (p.a_dtype == INA_DT_F32 ? 4 : 8)) == 0, "gemm(prenorm): misaligned gamma / lda");
+        return ina_launch_gemm_skinny_prenorm(p, stream);
+    }
     if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) return ina_launch_gemm_skinny_fused(p, stream);
     if (p.force_cfg == 31 || p.force_cfg == 32) {
         INA_REQUIRE(p.M <= 64 && p.batch == 1, "gemm: skinny kernels need M <= 64, batch 1 (M=%d)", p.M);

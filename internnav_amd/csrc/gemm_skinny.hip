@@ -298,6 +298,186 @@ void launch_skinny_fused(const GemmArgs& p, hipStream_t stream) {
 #undef INA_SKF
 }
 
+
+// ---- column-owner variant with the INPUT RMSNorm fused in front (M <= 16: the single-token decode passes of the LLM, where a separate
+// norm launch over 7 x 3584 values costs as much as a 30 MB projection). Every workgroup first requests its weight ring, then - while
+// those loads are in flight - normalises the <= 16 activation rows itself: one wave per row reads the row (f32 residual stream or bf16
+// embeddings, L2 hits: every workgroup reads the same <= 230 KB), reduces the sum of squares and writes bf16(x * rstd * gamma) into an
+// LDS image whose rows sit 16 bytes past a multiple of 256 (the 16 fragment rows of a ds_read_b128 land on 16 different bank quads).
+// The main loop is the fused kernel's with the activation fragments read from that image instead of global memory.
+template <int NT16, int NW, int NC, int DEPTH>
+__global__ __launch_bounds__(NW * NC * 64) void gemm_skinny_prenorm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    constexpr int NWAVES = NW * NC;
+    const int lds_ld = p.K + 8;
+    bf16* img = reinterpret_cast<bf16*>(sk_smem);                                                     // [M][K + 8]
+    float* red = reinterpret_cast<float*>(sk_smem + (((size_t)p.M * lds_ld * sizeof(bf16) + 15) & ~size_t(15)));   // [NC][NW][NT16][256]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave / NW, w = wave % NW;
+    const int n0 = (blockIdx.x * NC + grp) * (16 * NT16);
+    const int r16 = lane & 15, g = lane >> 4;
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W);
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16* wrow[NT16];
+    bool wok[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        const int wn = n0 + t * 16 + r16;
+        wok[t] = wn < p.N;
+        wrow[t] = W + (size_t)(wok[t] ? wn : 0) * p.ldw;
+    }
+    f32x4 acc[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ksteps = (p.K + SK_BK - 1) / SK_BK;
+    const int nmine = w < ksteps ? (ksteps - w + NW - 1) / NW : 0;
+    bf16x8 wf[DEPTH][NT16][4];
+    auto load_w = [&](int j, int slot) {
+        const int k0 = (w + j * NW) * SK_BK + g * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = k0 + s * 32;
+            const bool kok = j < nmine && k < p.K;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) wf[slot][t][s] = (kok && wok[t]) ? *reinterpret_cast<const bf16x8*>(wrow[t] + k) : zero8;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load_w(d, d);
+
+    // ---- fused RMSNorm: wave `wave` takes rows wave, wave + NWAVES, ...; lane l the 8-element chunks l, l + 64, ... of the row
+    {
+        const int nch = p.K >> 3;
+        const float invK = 1.0f / (float)p.K;
+        const bool a32 = p.a_dtype == INA_DT_F32;
+        auto load8 = [&](int m, int c, float (&v)[8]) {
+            if (a32) {
+                const float* q = reinterpret_cast<const float*>(p.A) + (size_t)m * p.lda + c * 8;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+            } else {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.A) + (size_t)m * p.lda + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+            }
+        };
+        for (int m = wave; m < p.M; m += NWAVES) {          // wave-uniform
+            float sq = 0.f;
+            for (int c = lane; c < nch; c += 64) {
+                float v[8];
+                load8(m, c, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sq += v[j] * v[j];
+            }
+            const float rstd = rsqrtf(wave_sum(sq) * invK + p.norm_eps);
+            for (int c = lane; c < nch; c += 64) {           // second read of the row: L1 / L2 hits, keeps the register budget small
+                float v[8];
+                load8(m, c, v);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(p.norm_gamma + c * 8), gb = *reinterpret_cast<const f32x4*>(p.norm_gamma + c * 8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (bf16)(v[j] * rstd * ga[j]);
+                    o[4 + j] = (bf16)(v[4 + j] * rstd * gb[j]);
+                }
+                *reinterpret_cast<bf16x8*>(img + (size_t)m * lds_ld + c * 8) = o;
+            }
+        }
+    }
+    __syncthreads();
+
+    // rows of the MFMA fragment beyond M read a valid row: their outputs are never stored
+    const bf16* arow = img + (size_t)(r16 < p.M ? r16 : p.M - 1) * lds_ld + g * 8;
+    for (int j0 = 0; j0 < nmine; j0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kb = (w + (j0 + d) * NW) * SK_BK;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = kb + s * 32;
+                const bf16x8 af = (j0 + d < nmine && k + g * 8 < p.K) ? *reinterpret_cast<const bf16x8*>(arow + k) : zero8;
+#pragma unroll
+                for (int t = 0; t < NT16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[d][t][s], af, acc[t], 0, 0, 0);
+            }
+            load_w(j0 + d + DEPTH, d);
+        }
+    }
+    if constexpr (NW > 1) {
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) *reinterpret_cast<f32x4*>(&red[(((size_t)grp * NW + w) * NT16 + t) * 256 + lane * 4]) = acc[t];
+        __syncthreads();
+        if (w != 0) return;        // one 16-row fragment: wave 0 of the group reduces and stores
+    }
+    const int m = r16, n = n0 + g * 4;
+    f32x4 sum[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        if constexpr (NW > 1) {
+            sum[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[(((size_t)grp * NW + ww) * NT16 + t) * 256 + lane * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[t][r] += v[r];
+            }
+        } else {
+            sum[t] = acc[t];
+        }
+    }
+    if (m >= p.M || n >= p.N) return;
+    const float rs = p.rowscale ? p.rowscale[m / p.rowscale_div] : 1.0f;
+    float v[4];
+    int no = n;
+    if constexpr (NT16 == 2) {
+        no = (n0 >> 1) + g * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gg = sum[0][r], uu = sum[1][r];
+            if (p.bias) { gg += p.bias[n + r]; uu += p.bias[n + 16 + r]; }
+            v[r] = ina_act(gg, p.act) * uu * rs;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = sum[0][r];
+            if (p.bias) x += p.bias[n + r];
+            x = ina_act(x, p.act);
+            if (p.colscale) x *= p.colscale[n + r];
+            v[r] = x * rs;
+        }
+        if (p.R) {
+            const size_t ro = (size_t)m * p.ldr + n;
+            if (p.res_dtype == INA_DT_BF16) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.R) + ro);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            } else {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+        }
+    }
+    const size_t co = (size_t)m * p.ldc + no;
+    if (p.out_dtype == INA_DT_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = f32x4{v[0], v[1], v[2], v[3]};
+}
+
+template <int NT16, int NW, int NC, int DEPTH>
+int launch_skinny_prenorm(const GemmArgs& p, hipStream_t stream, int tiles) {
+    const size_t lds = (((size_t)p.M * (p.K + 8) * sizeof(bf16) + 15) & ~size_t(15)) + (NW > 1 ? size_t(NC) * NW * NT16 * 256 * sizeof(float) : 0);
+    auto kern = gemm_skinny_prenorm_kernel<NT16, NW, NC, DEPTH>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((tiles + NC - 1) / NC), dim3(NW * NC * 64), lds, stream, p);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 int ina_launch_gemm_skinny_fused(const GemmArgs& p, hipStream_t stream) {
@@ -348,4 +528,19 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_skinny_epilogue, dim3(eb), dim3(256), 0, stream, p, part, splits);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+int ina_launch_gemm_skinny_prenorm(const GemmArgs& p, hipStream_t stream) {
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0, asz = p.a_dtype == INA_DT_F32 ? 4.0 : 2.0;
+    InaProfScope prof(INA_PROF_GEMM_SKINNY, 2.0 * p.M * p.N * p.K, asz * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
+    // every workgroup repeats the (cheap, L2-served) normalisation, so the column groups are packed NC per workgroup where one group
+    // alone would be a 4-wave workgroup; the group width follows the fused kernel's rule (a few thousand waves per launch)
+    if (p.glu) {
+        const int tiles = (p.N + 31) / 32;
+        if (tiles >= 1024) return launch_skinny_prenorm<2, 4, 2, 2>(p, stream, tiles);
+        return launch_skinny_prenorm<2, 8, 1, 2>(p, stream, tiles);
+    }
+    const int tiles = (p.N + 15) / 16;
+    if (tiles >= 1024) return launch_skinny_prenorm<1, 4, 2, 2>(p, stream, tiles);
+    return launch_skinny_prenorm<1, 8, 1, 4>(p, stream, tiles);
 }

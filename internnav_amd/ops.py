@@ -41,13 +41,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
            rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
-           batched: bool = False, group_m: int = 0) -> torch.Tensor:
+           batched: bool = False, group_m: int = 0, prenorm=None) -> torch.Tensor:
     """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
 
     batched=True: x is [Bt, M, K] and out [Bt, M, N] views with arbitrary batch strides (rows contiguous-strided inside a
     batch); residual is [Bt, M, N] or a [M, N] table broadcast over the batch (e.g. positional embeddings).
+    prenorm=(gamma f32 [K], eps): RMSNorm of x fused in front (x f32 or bf16, at most 16 rows): out = epilogue(bf16(rmsnorm(x) * gamma) @ w.T).
     """
-    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    assert (x.dtype == torch.bfloat16 or prenorm is not None) and w.dtype == torch.bfloat16
     assert w.dim() == 2 and w.stride(1) == 1
     N, K = w.shape
     n_out = N // 2 if glu else N
@@ -89,6 +90,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.rowscale_div = rowscale_div
     a.force_cfg = force_cfg
     a.group_m = group_m
+    if prenorm is not None:
+        gamma, eps = prenorm
+        assert not batched and x.dtype in (torch.bfloat16, torch.float32) and gamma.dtype == torch.float32 and gamma.is_contiguous() and gamma.numel() == K
+        a.norm_gamma, a.norm_eps, a.a_dtype = gamma.data_ptr(), float(eps), _DT[x.dtype]
     _lib.check(_lib.lib().ina_gemm_bf16(C.byref(a), _stream()), "gemm_bf16")
     return out
 

@@ -120,6 +120,7 @@ class QwenVLEngine:
         bf, f32 = torch.bfloat16, torch.float32
         self.cfg, self.device = cfg, dev
         self.B_max, self.S_max, self.Np_max = max_seqs, max_seq_len, max_patches
+        self.fuse_decode_norm = True   # decode passes: RMSNorm fused into the q|k|v and gate|up weight-streaming GEMMs
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
         Ip = (I + 63) // 64 * 64   # SwiGLU width padded with zero rows/cols: GLU tiles need N % 32 == 0, the LDS-DMA GEMM K % 64 == 0
@@ -269,17 +270,26 @@ class QwenVLEngine:
         x, h, att, qkv, ff = self.x[:rows], self.h[:rows], self.att[:rows], self.qkv[:rows], self.ff[:rows]
         ops.mrope_table(ph["pos"], self.inv_freq, self.axis_of, self.cos, self.sin)
         q4 = qkv[:, : nh * hd].view(B, S, nh, hd)
+        # single-token decode passes (<= 16 rows): the two RMSNorms of a layer run inside the weight-streaming GEMMs that consume them
+        # (ina_gemm_bf16 norm_gamma): 2 of the 9 launches per layer disappear from a chain that is launch / latency bound
+        fused_norm = rows <= 16 and self.fuse_decode_norm and self.tap is None
         for li, L in enumerate(self.layers):
             src = self.x_in[:rows] if li == 0 else x
-            ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
-            ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
+            if fused_norm:
+                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6))
+            else:
+                ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
+                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
             # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
             ops.rope(qkv, self.cos, self.sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[:B, : ph["Lk"]]
             ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
             ops.linear(att, L["o_w"], residual=src, out=x)
-            ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
-            ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
+            if fused_norm:
+                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6))
+            else:
+                ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
+                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
             ops.linear(ff, L["down_w"], residual=x, out=x)
             if self.tap is not None:
                 self.tap("llm", li, x)

@@ -187,6 +187,11 @@ def test_capacity_overflow_is_a_loud_configuration_error(ckpt):
     inp = S.qwen_inputs(1, 2, seed=9, cfg=cfg)
     with pytest.raises(CapacityError):
         m.generate(input_ids=inp["input_ids"], pixel_values=inp["pixel_values"], image_grid_thw=inp["grid_thw"], max_new_tokens=4)
-    for bad in ("nextdit", "navdp"):
-        with pytest.raises(NotImplementedError):
-            InternVLAN1ForCausalLM(sd, cfg, bad, device=DEV, max_envs=1, max_seq_len=256, max_patches=784)
+    with pytest.raises(NotImplementedError):            # not one of the four System-1 types of generate_traj (internvla_n1.py:359-441)
+        InternVLAN1ForCausalLM(sd, cfg, "unet", device=DEV, max_envs=1, max_seq_len=256, max_patches=784)
+    # the plain (non-async) 'nextdit' type: generate_traj ignores the images, classifier-free guidance weights other than 1 are accepted
+    plain = InternVLAN1ForCausalLM(sd, cfg, "nextdit", device=DEV, max_envs=1, max_seq_len=256, max_patches=784)
+    lat = torch.randn(1, cfg["n_query"], cfg["t_hidden"], device=DEV).to(torch.bfloat16)
+    t1 = plain.generate_traj(traj_latents=lat, images_dp=None, noise=dict(x_init=torch.zeros(1, 32, 32, 3, device=DEV)))
+    t2 = plain.generate_traj(traj_latents=lat, images_dp=None, guidance_scale=2.0, noise=dict(x_init=torch.zeros(1, 32, 32, 3, device=DEV)))
+    assert t1.shape == (32, 32, 3) and torch.isfinite(t1).all() and torch.isfinite(t2).all() and (t1 - t2).abs().max().item() > 0

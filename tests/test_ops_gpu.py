@@ -426,6 +426,38 @@ def test_gemm_skinny_glu(ops, cfg, M):
     _close(out, ref)
 
 
+@pytest.mark.parametrize("M,N,K,glu,xdt", [(7, 4608, 3584, False, torch.float32), (7, 37888, 3584, True, torch.float32), (1, 4608, 3584, False, torch.bfloat16),
+                                            (16, 512, 1024, False, torch.float32), (6, 2048, 384, True, torch.bfloat16), (7, 16384, 3584, False, torch.float32)])
+def test_gemm_skinny_fused_input_rmsnorm(ops, M, N, K, glu, xdt):
+    """decode passes: RMSNorm fused in front of the weight-streaming GEMM (one launch instead of norm + GEMM). Against the fp32 formula
+    and against the two-launch path it replaces (same bf16 operand up to the rounding of the row statistic's summation order)."""
+    g = torch.Generator().manual_seed(M * 31 + N)
+    x = (torch.randn(M, K, generator=g) * 3.0).to(xdt).to(_dev())
+    gamma = (1.0 + 0.1 * torch.randn(K, generator=g)).to(_dev())
+    w = _rand((N, K), g, scale=K ** -0.5)
+    bias = None if glu else torch.randn(N, generator=g).to(_dev())
+    res = None if glu else torch.randn(M, N, generator=g).to(_dev())
+    xn = x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6) * gamma
+    y = xn.bfloat16().float() @ w.float().t()
+    if glu:
+        I = N // 2
+        y4 = y.view(M, I // 16, 2, 16)
+        ref = (torch.nn.functional.silu(y4[:, :, 0]) * y4[:, :, 1]).reshape(M, I)
+        out = ops.linear(x, w, act="silu", glu=True, prenorm=(gamma, 1e-6))
+        h = ops.norm(x, gamma, None, eps=1e-6, rms=True)
+        two = ops.linear(h, w, act="silu", glu=True)
+    else:
+        ref = y + bias + res
+        out = ops.linear(x, w, bias=bias, residual=res, out_dtype=torch.float32, prenorm=(gamma, 1e-6))
+        h = ops.norm(x, gamma, None, eps=1e-6, rms=True)
+        two = ops.linear(h, w, bias=bias, residual=res, out_dtype=torch.float32)
+    _close(out, ref, rtol=4e-3, atol=1e-2)
+    d = (out.float() - two.float()).abs().max().item()
+    assert d <= 2e-2, d                      # identical up to a bf16 flip of single operand elements where the row statistic rounds differently
+    with pytest.raises(Exception):
+        ops.linear(torch.zeros(17, K, device=_dev()), w, prenorm=(gamma, 1e-6))      # built for <= 16 rows
+
+
 DECODE = [
     # B, Lq, Lk, H, Hkv, D, causal
     (7, 1, 927, 28, 4, 128, True), (7, 5, 932, 28, 4, 128, True), (3, 1, 300, 28, 4, 128, False), (2, 2, 513, 8, 8, 64, True),
