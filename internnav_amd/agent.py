@@ -228,8 +228,18 @@ class InternVLAN1Agent:
                     extra = {}
                     if all("cached_image_embeds" in it[2] for it in items):        # per-frame ViT cache of the policies (device pre-processing)
                         extra["cached_image_embeds"] = [c for it in items for c in it[2]["cached_image_embeds"]]
+                    # prefix-KV reuse of the policies: per env the K/V of its episode's constant prompt prefix (or a request to keep them)
+                    pref = [it[0].policy.prefix_request(it[2]) if hasattr(it[0].policy, "prefix_request") else (None, 0) for it in items]
+                    gen_extra = dict(extra)
+                    if any(kv is not None or want for kv, want in pref):
+                        gen_extra.update(prefix_kv=[kv for kv, _ in pref], export_prefix=[want for _, want in pref])
                     seqs = model.generate(input_ids=ids, pixel_values=pv, image_grid_thw=grid, max_new_tokens=128, do_sample=False,
-                                          use_cache=True, past_key_values=None, return_dict_in_generate=True, **ragged, **extra).sequences
+                                          use_cache=True, past_key_values=None, return_dict_in_generate=True, **ragged, **gen_extra).sequences
+                    if any(want for _, want in pref):
+                        kept = model.last_prefix_kv()
+                        for r, (it, (_, want)) in enumerate(zip(items, pref)):
+                            if want:
+                                it[0].policy.store_prefix(it[2], kept[r])
                     if extra:
                         fresh, o = model.last_image_embeds(), 0
                         for e, _, inputs in items:

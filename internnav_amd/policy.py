@@ -242,11 +242,17 @@ class InternVLAN1ForCausalLM:
     # ---- System 2
     def generate(self, input_ids=None, pixel_values=None, image_grid_thw=None, attention_mask=None, max_new_tokens: int = 128,
                  do_sample: bool = False, use_cache: bool = True, past_key_values=None, return_dict_in_generate: bool = False,
-                 decode_chunk: int = 8, eos_token_id=None, cached_image_embeds: Optional[list] = None, **_):
+                 decode_chunk: int = 8, eos_token_id=None, cached_image_embeds: Optional[list] = None, prefix_kv: Optional[list] = None,
+                 export_prefix: Optional[list] = None, **_):
         """greedy decoding (do_sample=False is the only mode the reference uses, internvla_n1_policy.py:169-176). Decodes in chunks of
         `decode_chunk` device-side steps and stops once every sequence has emitted EOS. Sequences are right-filled with EOS.
         cached_image_embeds (extension, per-frame ViT cache): one entry per image of the batch, None = encode it (its patches are in
-        pixel_values), else the embeddings an earlier call returned through `last_image_embeds()`."""
+        pixel_values), else the embeddings an earlier call returned through `last_image_embeds()`.
+        prefix_kv (extension, prefix-KV reuse): one entry per sequence - None, or the K/V bf16 [layers, P, 1024] of the sequence's first P
+        prompt tokens as an earlier call exported them (the prompt must start with the same P tokens: system prompt + instruction +
+        first history frame between the System-2 calls of an episode). Those tokens are not run and their images not encoded;
+        pixel_values may still hold every image's patches (the cached images' rows are skipped). Exact: causal attention.
+        export_prefix: one entry per sequence - 0, or the number of leading prompt tokens whose K/V to keep (`last_prefix_kv()`)."""
         assert not do_sample, "the reference only decodes greedily"
         eos = self.qwen.cfg["eos_token_id"] if eos_token_id is None else eos_token_id
         pv = pixel_values.to(self.device, torch.bfloat16) if pixel_values is not None and pixel_values.numel() else None
@@ -256,7 +262,28 @@ class InternVLAN1ForCausalLM:
         if attention_mask is not None:
             am = attention_mask.cpu().long()
             assert bool((am[:, 1:] <= am[:, :-1]).all()), "ragged System-2 batches are right-padded (mask = 1...1 0...0)"
-        state = self.qwen.prefill(input_ids, pv, image_grid_thw, cached_embeds=cached_image_embeds, seq_lens=plens if attention_mask is not None else None)
+        pl = 0
+        if prefix_kv is not None and any(k is not None for k in prefix_kv):
+            assert len(prefix_kv) == B and cached_image_embeds is None, "prefix_kv: one entry per sequence (not combined with cached_image_embeds)"
+            pl = np.asarray([0 if k is None else int(k.shape[1]) for k in prefix_kv], dtype=np.int64)
+            for b, k in enumerate(prefix_kv):
+                if k is not None:
+                    self.qwen.import_prefix_kv(b, k)
+            # drop the patch rows of the images whose tokens are cached K/V
+            skip = self.qwen.images_in_prefix(input_ids, image_grid_thw, pl)
+            if pv is not None and any(skip):
+                n_rows = [int(t * h * w) for t, h, w in image_grid_thw.tolist()]
+                assert pv.shape[0] == sum(n_rows), "prefix_kv: pixel_values must hold the patches of every image of the batch"
+                off = np.concatenate([[0], np.cumsum(n_rows)])
+                keep = [pv[off[i]:off[i + 1]] for i, s in enumerate(skip) if not s]
+                pv = torch.cat(keep, 0) if keep else None
+        state = self.qwen.prefill(input_ids, pv, image_grid_thw, cached_embeds=cached_image_embeds, seq_lens=plens if attention_mask is not None else None,
+                                  prefix_len=pl)
+        self._prefix_out = {}
+        if export_prefix is not None:
+            for b, n in enumerate(export_prefix):
+                if n:
+                    self._prefix_out[b] = self.qwen.export_prefix_kv(b, int(n))
         self._fresh = self.qwen.fresh_image_embeds(state["plan"]) if cached_image_embeds is not None else {}
         chunks, n = [], 0
         while n < max_new_tokens:
@@ -284,6 +311,10 @@ class InternVLAN1ForCausalLM:
             seqs[b, L:L + toks.shape[1]] = toks[b]
         seqs = seqs.to(self.device)
         return SimpleNamespace(sequences=seqs) if return_dict_in_generate else seqs
+
+    def last_prefix_kv(self) -> Dict[int, torch.Tensor]:
+        """sequence index of the last generate() call -> the prefix K/V it was asked to export (`export_prefix`)."""
+        return getattr(self, "_prefix_out", {})
 
     def last_image_embeds(self) -> Dict[int, torch.Tensor]:
         """image index (position in the last generate() call's image list) -> merged embeddings bf16 [tokens, 3584] of every image that
@@ -408,7 +439,7 @@ class InternVLAN1Net:
 
     def __init__(self, config=None, processor=None, num_history: int = 8, resize_w: int = 384, resize_h: int = 384,
                  continuous_traj: bool = True, frame_preprocessor=None, model: Optional[InternVLAN1ForCausalLM] = None,
-                 vit_cache: bool = False):
+                 vit_cache: bool = False, prefix_cache: bool = False):
         """Two ways in, both ending in (model, processor, episode state):
           * the reference's: `InternVLAN1Net(config=InternVLAN1ModelConfig(model_cfg={'model': model_settings}))`
             (internvla_n1_agent.py:39-43, internvla_n1_policy.py:29-48) - loads the checkpoint at model_settings['model_path'] on
@@ -435,6 +466,12 @@ class InternVLAN1Net:
         # call are kept, so the look-down turn (which re-sends every image of the turn before, internvla_n1_policy.py:140-147) and
         # re-sampled history frames (frame 0 is in every np.linspace sample) skip the vision tower. Exact: the tower attends per image.
         self.vit_cache = bool(vit_cache or (config is not None and dict(config.model_cfg["model"]).get("vit_cache", False))) and frame_preprocessor is not None
+        # prefix-KV reuse (model_settings['prefix_cache']): every System-2 prompt of an episode after the first starts with the same tokens -
+        # chat template, instruction, "These are your historical observations:" and history frame 0 (np.linspace always samples it,
+        # internvla_n1_policy.py:125-133); the look-down turn repeats the whole previous prompt. Their K/V of all 28 layers are kept per env
+        # (17 MB for 296 tokens) and handed back to generate(): those tokens are not prefilled, frame 0 is not encoded. Exact (causal mask).
+        self.prefix_cache = bool(prefix_cache or (config is not None and dict(config.model_cfg["model"]).get("prefix_cache", False))) \
+            and hasattr(getattr(model, "qwen", None), "export_prefix_kv") and not self.vit_cache
         self.tokenizer = getattr(processor, "tokenizer", None)
         self.num_history, self.resize_w, self.resize_h, self.continuous_traj = num_history, resize_w, resize_h, continuous_traj
         self.device = model.device
@@ -467,7 +504,8 @@ class InternVLAN1Net:
     def spawn(self) -> "InternVLAN1Net":
         """a fresh episode state on the same model / processor (the batched agent keeps one per environment)."""
         return InternVLAN1Net(processor=self.processor, num_history=self.num_history, resize_w=self.resize_w, resize_h=self.resize_h,
-                              continuous_traj=self.continuous_traj, frame_preprocessor=self.pre, model=self.model, vit_cache=self.vit_cache)
+                              continuous_traj=self.continuous_traj, frame_preprocessor=self.pre, model=self.model, vit_cache=self.vit_cache,
+                              prefix_cache=self.prefix_cache)
 
     def eval(self):
         return self
@@ -480,6 +518,7 @@ class InternVLAN1Net:
         self.input_images = []
         self.input_keys = []          # frame identity of every input image: index into rgb_list, or "look_down"
         self._emb_cache = {}          # frame key -> (embeds bf16 [tokens, H], grid) of the frames of the last System-2 call
+        self._prefix = None           # (token ids of the cached prompt prefix, K/V bf16 [layers, P, 1024]) of this episode
 
     def parse_actions(self, output: str) -> List[int]:
         regex = re.compile("|".join(re.escape(a) for a in self.ACTIONS2IDX))
@@ -561,6 +600,25 @@ class InternVLAN1Net:
             out["cached_image_embeds"] = cached
         return out
 
+    def prefix_request(self, inputs) -> Tuple[Optional[torch.Tensor], int]:
+        """(prefix K/V to hand to generate() or None, number of leading tokens to export after the call or 0) for the prompt in `inputs`.
+        The reusable prefix ends with the <|vision_end|> of the first image when that image is episode frame 0."""
+        if not self.prefix_cache or not self.input_keys or self.input_keys[0] != 0:
+            return None, 0
+        ids = inputs["input_ids"][0]
+        ve = (ids == self.model.qwen.cfg["vision_end_id"]).nonzero()
+        if ve.numel() == 0:
+            return None, 0
+        P = int(ve[0]) + 1
+        if P >= ids.shape[0]:
+            return None, 0
+        if self._prefix is not None and self._prefix[0].shape[0] == P and torch.equal(self._prefix[0], ids[:P].cpu()):
+            return self._prefix[1], 0
+        return None, P
+
+    def store_prefix(self, inputs, kv: torch.Tensor):
+        self._prefix = (inputs["input_ids"][0, : kv.shape[1]].cpu().clone(), kv)
+
     def update_frame_cache(self, inputs, fresh: Dict[int, torch.Tensor]):
         """keep the embeddings of exactly the frames of this call (bounded: <= num_history + 2 frames of 196 - 391 tokens)."""
         if not self.vit_cache:
@@ -595,10 +653,16 @@ class InternVLAN1Net:
     def s2_step(self, rgb, depth, pose, instruction, intrinsic, look_down: bool = False) -> S2Output:
         inputs = self.build_s2_inputs(rgb, instruction, look_down)
         extra = {"cached_image_embeds": inputs["cached_image_embeds"]} if "cached_image_embeds" in inputs else {}
+        kv, want = self.prefix_request(inputs)
+        if kv is not None or want:
+            extra.update(prefix_kv=[kv], export_prefix=[want])
         ids = self.model.generate(input_ids=inputs["input_ids"], pixel_values=inputs["pixel_values"], image_grid_thw=inputs["image_grid_thw"],
                                   max_new_tokens=128, do_sample=False, use_cache=True, past_key_values=None, return_dict_in_generate=True, **extra).sequences
-        if extra:
+        if "cached_image_embeds" in extra:
             self.update_frame_cache(inputs, self.model.last_image_embeds())
+        if want:
+            self.store_prefix(inputs, self.model.last_prefix_kv()[0])
+        extra = {k: v for k, v in extra.items() if k == "cached_image_embeds"}
         return self.finish_s2(inputs, ids, lambda: self.model.generate_latents(ids, inputs["pixel_values"], inputs["image_grid_thw"], **extra))
 
     def s1_step_latent(self, rgb, depth, latent) -> S1Output:

@@ -307,7 +307,7 @@ class QwenVLEngine:
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)
     def plan(self, input_ids, image_grid_thw, n_decode: int = 0, with_latents: bool = False, cached_embeds: Optional[list] = None,
-             prefix_len: int = 0) -> dict:
+             prefix_len=0) -> dict:
         """Host-side plan of one S2 call for B equal-length prompts: embedding / scatter indices, vision plan, position ids and cache
         rows of the prefill, of every decode step and of the latent-query pass (fixed-length answers of n_decode tokens).
         cached_embeds: one entry per image (prompt order over the batch), None = run the vision tower on it, else its merged embeddings
@@ -318,18 +318,23 @@ class QwenVLEngine:
         same tokens: system prompt + instruction + first history frame between the System-2 calls of an episode). With a causal mask
         the K/V of a token depend on the tokens before it only, so the suffix sees exactly what a full prefill would have cached.
         Images whose tokens lie inside the prefix are not encoded (pixel_values holds the patches of the other images); the prefix
-        must end on an image boundary."""
+        must end on an image boundary. prefix_len may be an int or one value per sequence (0 = nothing cached for that sequence): the
+        call then runs a right-padded rectangle of max(S - prefix_len) tokens per sequence behind each sequence's own prefix."""
         cfg, dev = self.cfg, self.device
         ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
         B, S = ids.shape
         if B > self.B_max or S > self.S_max:
             raise CapacityError(f"System-2 batch of {B} x {S} tokens exceeds the engine's max_seqs={self.B_max} / max_seq_len={self.S_max}")
-        assert 0 <= prefix_len < S, f"prefix_len={prefix_len} must leave at least one token of the {S}-token prompts to run"
+        pl = np.broadcast_to(np.asarray(prefix_len, dtype=np.int64).reshape(-1), (B,)).copy()
+        assert int(pl.min()) >= 0 and int(pl.max()) < S, f"prefix_len={pl.tolist()} must leave at least one token of the {S}-token prompts to run"
         grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
         grids_all = grids
-        Sr = S - prefix_len                                       # tokens per sequence this call runs
-        run = np.ascontiguousarray(ids[:, prefix_len:])
+        Sr = S - int(pl.min())                                    # tokens per sequence this call runs (rectangle width)
+        run = np.zeros((B, Sr), dtype=np.int64)                   # row b = ids[b, pl[b]:] right-padded
+        for b in range(B):
+            run[b, : S - pl[b]] = ids[b, pl[b]:]
         flat = run.reshape(-1)
+        prefix_len = pl
         P = dict(B=B, S=S, S_run=Sr, prefix_len=prefix_len, n_decode=n_decode, ids=torch.from_numpy(flat.astype(np.int32)).to(dev), vision=None,
                  cached=[], fresh_tokens=[])
         img_pos = np.nonzero(flat == cfg["image_token_id"])[0].astype(np.int32)
@@ -343,8 +348,8 @@ class QwenVLEngine:
                 while cum < ipos.size:
                     assert k < len(grids), "image count of the prompts and image_grid_thw disagree"
                     first, last = int(ipos[cum]), int(ipos[cum + ntok_all[k] - 1])
-                    assert last < prefix_len or first >= prefix_len, "the cached prefix must end on an image boundary"
-                    in_prefix.append(last < prefix_len)
+                    assert last < pl[b] or first >= pl[b], "the cached prefix must end on an image boundary"
+                    in_prefix.append(last < pl[b])
                     cum += ntok_all[k]
                     k += 1
             assert k == len(grids), "image count of the prompts and image_grid_thw disagree"
@@ -377,7 +382,17 @@ class QwenVLEngine:
             P["traj_src"] = torch.from_numpy((np.arange(traj_pos.size) % nq).astype(np.int32)).to(dev)
             P["traj_dst"] = torch.from_numpy(traj_pos).to(dev)
         pos3, _ = rope_index(ids, grids_all, cfg["image_token_id"], cfg["vision_start_id"])
-        P["prefill"] = self._phase(B, Sr, pos3[:, :, prefix_len:], prefix_len)
+        if int(pl.max()) == 0:
+            P["prefill"] = self._phase(B, Sr, pos3, 0)
+        else:
+            pos_run = np.zeros((3, B, Sr), dtype=np.int64)
+            for b in range(B):
+                n = S - pl[b]
+                pos_run[:, b, :n] = pos3[:, b, pl[b]:]
+                pos_run[:, b, n:] = pos3[:, b, -1:]                # pad rows: any position (never attended by real tokens, causal)
+            uniform = bool((pl == pl[0]).all())
+            # per-sequence prefixes: query i of sequence b sees keys <= pl[b] + i (the kernels align the causal mask to each k_len)
+            P["prefill"] = self._phase(B, Sr, pos_run, pl, k_len=None if uniform else pl + Sr)
         nxt = pos3[:, :, -1].max(axis=0) + 1                      # text position of the first generated token, per sequence
         P["next_pos"] = nxt
         P["decode"] = [self._phase(B, 1, (nxt + j)[None, :, None], S + j) for j in range(max(n_decode - 1, 0))]
@@ -443,6 +458,21 @@ class QwenVLEngine:
             self.run_latents(P, latents_out)
 
     # ---- prefix-KV reuse: the K/V of a prompt prefix leave / re-enter the batch's cache slots (device copies, no arithmetic)
+    def images_in_prefix(self, input_ids, image_grid_thw, prefix_len) -> List[bool]:
+        """per image of the batch (prompt order): do all of its tokens lie inside its sequence's cached prefix?"""
+        ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
+        pl = np.broadcast_to(np.asarray(prefix_len, dtype=np.int64).reshape(-1), (ids.shape[0],))
+        ntok = [int(t * h * w) // 4 for t, h, w in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
+        out, k = [], 0
+        for b in range(ids.shape[0]):
+            ipos = np.nonzero(ids[b] == self.cfg["image_token_id"])[0]
+            cum = 0
+            while cum < ipos.size:
+                out.append(int(ipos[cum + ntok[k] - 1]) < pl[b])
+                cum += ntok[k]
+                k += 1
+        return out
+
     def export_prefix_kv(self, seq: int, n_tokens: int) -> torch.Tensor:
         """K/V of the first n_tokens cached tokens of batch slot `seq`, all layers: bf16 [layers, n_tokens, 2 * kv_heads * head_dim]
         (a copy: what a caller keeps per environment between the System-2 calls of an episode)."""
@@ -477,7 +507,7 @@ class QwenVLEngine:
             lens = np.asarray(seq_lens, dtype=np.int64)
             assert lens.shape == (P["B"],) and int(lens.max()) <= P["S"] and int(lens.min()) >= 1
             if bool((lens != P["S"]).any()):
-                assert int(lens.min()) > prefix_len, "every sequence must have tokens behind the cached prefix"
+                assert bool((lens > P["prefix_len"]).all()), "every sequence must have tokens behind its cached prefix"
                 ids = (input_ids.cpu().numpy() if isinstance(input_ids, torch.Tensor) else np.asarray(input_ids)).astype(np.int64)
                 grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
                 pos3, _ = rope_index(ids, grids, self.cfg["image_token_id"], self.cfg["vision_start_id"])
@@ -493,11 +523,15 @@ class QwenVLEngine:
         out = torch.empty(B, n_steps, dtype=torch.int32, device=self.device)
         lens = state.get("lens")
         if "cur" not in state:
-            if lens is None:
+            if lens is None and bool((state["plan"]["prefix_len"] == state["plan"]["prefix_len"][0]).all()):
                 self._last_logits(B, Sr, Sr - 1)
                 state["cur"] = S
+            elif lens is None:       # equal-length prompts behind prefixes of different lengths: each sequence's last real row
+                rows = torch.from_numpy((np.arange(B) * Sr + S - state["plan"]["prefix_len"] - 1).astype(np.int32)).to(self.device)
+                self._last_logits(B, Sr, None, rows_idx=rows)
+                state["cur"] = S
             else:
-                rows = torch.from_numpy((np.arange(B) * Sr + lens - (S - Sr) - 1).astype(np.int32)).to(self.device)
+                rows = torch.from_numpy((np.arange(B) * Sr + lens - state["plan"]["prefix_len"] - 1).astype(np.int32)).to(self.device)
                 self._last_logits(B, Sr, None, rows_idx=rows)
                 state["cur"] = lens.copy()
         for j in range(n_steps):

@@ -88,3 +88,66 @@ def test_prefix_must_end_on_an_image_boundary_and_leave_tokens(eng):
         eng.plan(inp["input_ids"], inp["grid_thw"], prefix_len=N_TEXT + 50)
     with pytest.raises(AssertionError):
         eng.plan(inp["input_ids"], inp["grid_thw"], prefix_len=inp["input_ids"].shape[1])
+
+
+class _Tok:
+    def __call__(self, texts, return_tensors="pt"):
+        ids, i, t = [], 0, texts[0]
+        cfg = S.QWEN_TEST_CFG
+        special = {"<|image_pad|>": cfg["image_token_id"], "<|vision_start|>": cfg["vision_start_id"], "<|vision_end|>": cfg["vision_end_id"]}
+        while i < len(t):
+            for k, v in special.items():
+                if t.startswith(k, i):
+                    ids.append(v)
+                    i += len(k)
+                    break
+            else:
+                ids.append(ord(t[i]) % 3000)
+                i += 1
+        return {"input_ids": torch.tensor([ids])}
+
+    def decode(self, ids, skip_special_tokens=True):
+        return "12 34"                       # a pixel goal: every call also runs the latent queries
+
+
+class _Proc:
+    tokenizer = _Tok()
+    image_token = "<|image_pad|>"
+
+    def apply_chat_template(self, conv, tokenize=False, add_generation_prompt=True):
+        return "".join("<|vision_start|><|image_pad|><|vision_end|>" if c["type"] == "image" else c["text"] for m in conv for c in m["content"])
+
+
+def test_policy_reuses_the_episode_prefix_between_system2_calls(built_lib):
+    """through InternVLAN1Net (prefix_cache=True): the first call with history stores the K/V of [template | instruction | frame 0], later
+    calls (more history, the look-down continuation) hand them back; sequences and latents stay bit-identical to the uncached policy and
+    the engine prefills fewer rows."""
+    from internnav_amd.policy import InternVLAN1ForCausalLM, InternVLAN1Net
+    from internnav_amd.preprocess import FramePreprocessor
+
+    cfg = S.QWEN_TEST_CFG
+    sd = S.materialize(S.n1_full_spec(cfg, "nextdit_async"), 5)
+    model = InternVLAN1ForCausalLM(sd, cfg, "nextdit_async", device=DEV, max_envs=1, num_history=3, resize_w=280, resize_h=280, cam_w=320, cam_h=240)
+    pre = FramePreprocessor(DEV, resize_w=280, resize_h=280)
+    nets = [InternVLAN1Net(model, _Proc(), num_history=3, resize_w=280, resize_h=280, frame_preprocessor=pre, prefix_cache=pc) for pc in (False, True)]
+    assert nets[1].prefix_cache and not nets[0].prefix_cache
+    rng = np.random.default_rng(4)
+    frames = [rng.integers(0, 256, (240, 320, 3), dtype=np.uint8) for _ in range(9)]
+    outs, rows = [], []
+    for net in nets:
+        o, r = [], []
+        net.step_no_infer(frames[0], None, None)
+        net.step_no_infer(frames[1], None, None)
+        for f, look_down in ((frames[2], False), (frames[3], True), (frames[4], False), (frames[5], False)):
+            if not look_down and o:
+                net.step_no_infer(frames[6 + len(o) % 3], None, None)       # the episode moves on between System-2 calls
+            so = net.s2_step(f, None, None, "go to the door", None, look_down)
+            assert so.output_latent is not None
+            o.append((so.output_action, None if so.output_latent is None else so.output_latent.cpu()))
+            r.append(model._gen["state"]["S_run"])
+        outs.append(o)
+        rows.append(r)
+    for (a0, l0), (a1, l1) in zip(*outs):
+        assert a0 == a1 and ((l0 is None and l1 is None) or torch.equal(l0, l1))
+    assert rows[1][0] == rows[0][0]                       # first call of the episode: nothing cached yet (it stores the prefix)
+    assert all(c < u for c, u in zip(rows[1][1:], rows[0][1:])), (rows[0], rows[1])   # later calls run only what lies behind the prefix
