@@ -67,6 +67,9 @@ def parse():
                     help="n1_dual: prefix-KV reuse variant - the K/V of system prompt + instruction + first history frame (296 of the 920 prompt "
                          "tokens, identical between the System-2 calls of an episode) come from a per-env cache; the call encodes 3 of 4 frames and "
                          "prefills 624 tokens per env. Exact (causal mask); algorithmic FLOPs are accounted accordingly. Reported next to the headline.")
+    ap.add_argument("--s1-early-images", action="store_true",
+                    help="n1_dual experiment: the look-down frames of the System-2 envs are encoded (DINOv2, MemoryEncoder, QFormer) on the side stream "
+                         "at the start of the concurrent phase instead of after the decode chain")
     ap.add_argument("--fuse-rownorm", action="store_true",
                     help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
     ap.add_argument("--no-raw-frames", action="store_true",
@@ -228,6 +231,7 @@ class N1Dual:
         from internnav_amd.policy import InternVLAN1ForCausalLM, traj_to_actions
 
         self.traj_to_actions = traj_to_actions
+        self.a = a
         self.dev, self.B = dev, a.envs
         B = self.B
         self.name = f"n1_dual_b{B}"
@@ -343,9 +347,9 @@ class N1Dual:
             self.hostA = torch.empty(nA, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
             self.hostB = torch.empty(mmax, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
             self.idxA_host = [t.tolist() for t in self.idxA]
-            self.gA, self.gB, self.gP, self.gD = {}, {}, {}, {}
+            self.gA, self.gB, self.gP, self.gD, self.gBimg = {}, {}, {}, {}, {}
             self.overlap_at = a.overlap_at
-            self.ev, self.ev2 = torch.cuda.Event(), torch.cuda.Event()
+            self.ev, self.ev2, self.ev3 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
             # the decode / latent-query passes are chains of short kernels: on a high-priority stream their workgroups are dispatched
             # ahead of the queued workgroups of the concurrent System-1 kernels instead of waiting behind them
             self.hi = torch.cuda.Stream(device=dev, priority=-1) if getattr(a, "priority", "none") == "decode" else None
@@ -392,7 +396,10 @@ class N1Dual:
             for m in sorted(set(self.mb)):
                 nA = self.B - m
                 self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA]), {}, workspace_slot=1)
-                self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m]), {}, workspace_slot=2)
+                early = bool(getattr(self.a, "s1_early_images", False))
+                self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m], images_encoded=early), {}, workspace_slot=2)
+                if early:
+                    self.gBimg[m] = runtime.GraphedCall(lambda m=m: self.s1_small.encode_images(m, self.imgB[:m]), {}, workspace_slot=3)
                 if self.overlap_at == "decode":
                     s, q = self.s2[m], self.model.qwen
                     self.gP[m] = runtime.GraphedCall(lambda s=s: q.run_prefill(s["P"], s["pv"]), {})
@@ -455,6 +462,10 @@ class N1Dual:
             self.ev.record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ev)
+                if self.gBimg:                       # look-down frames of the System-2 envs: encoded ahead of the latents, off the main chain
+                    self.imgB[:m].copy_(self.images_dp[lo:lo + m])
+                    self.gBimg[m]()
+                    self.ev3.record(self.side)
                 trajA = self.gA[nA]()
             if self.hi is not None:
                 with torch.cuda.stream(self.hi):
@@ -468,7 +479,10 @@ class N1Dual:
             s["graph"]()
         self.latent_table[lo:lo + m].copy_(s["lat"])
         self.latB[:m].copy_(s["lat"])
-        self.imgB[:m].copy_(self.images_dp[lo:lo + m])
+        if self.gBimg and late:
+            main.wait_event(self.ev3)
+        else:
+            self.imgB[:m].copy_(self.images_dp[lo:lo + m])
         self.xB[:m].copy_(self.x_init[lo:lo + m])
         trajB = self.gB[m]()
         # host post-processing (vln_utils.traj_to_actions, as the reference does per env) of the side-stream envs runs while the main

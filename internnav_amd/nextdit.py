@@ -199,7 +199,27 @@ class NextDiTSystem1:
             self.pred = [torch.empty_like(self.sample), torch.empty_like(self.sample)]
         return self._null
 
-    def encode_condition(self, B: int, traj_latents: torch.Tensor, images_dp: torch.Tensor, cs: dict = None):
+    def encode_images(self, B: int, images_dp: torch.Tensor):
+        """the part of the condition that depends on the look-down frames only (DINOv2, MemoryEncoder, QFormer -> the 32 memory tokens of
+        z): a caller that has the frames before the VLM latents (the bench's System-2 envs) can launch it early, on another stream, and
+        call generate_traj(..., images_encoded=True) once the latents exist."""
+        assert self.use_async
+        D, L, nm, Lz = self.D, self.L, self.nm, self.Lz
+        z3 = self.z[: B * Lz].view(B, Lz, L)
+        if True:
+            mrows = B * nm
+            self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                             extra_outputs=[(self.me_ws.h[:mrows], self.me_ws.x[:mrows], None, self.mem_pos)])
+            self._memory_encoder(B)
+            qrows = B * 32
+            ops.embed3(None, None, None, out=self.q_ws.x[:qrows], pos=self.q_init, rows=qrows)
+            ops.embed3(None, None, None, out=self.q_ws.h[:qrows], pos=self.q_init, rows=qrows)
+            for Lr in self.q_layers:
+                ops.linear(self.memcat[:mrows], Lr.ca_kvw, bias=Lr.ca_kvb, out=self.q_kv[:mrows])
+                decoder_layer_postnorm(Lr, self.q_ws, B, 32, self.q_kv[:mrows], B, nm, 12, "relu")
+            z3[:, :32, :].copy_(self.q_ws.h[:qrows].view(B, 32, L))
+
+    def encode_condition(self, B: int, traj_latents: torch.Tensor, images_dp: torch.Tensor, cs: dict = None, images_encoded: bool = False):
         """internvla_n1.py:364-383 -> z [B, Lz, 768] (async: 32 memory tokens | n_query projected latents; otherwise the latents alone)
         and everything of the DiT that only depends on it."""
         D, L, nq, nm, Lz = self.D, self.L, self.nq, self.nm, self.Lz
@@ -208,7 +228,7 @@ class NextDiTSystem1:
         rows = B * nq
         ops.linear(traj_latents.reshape(rows, -1), self.cp[0][0], bias=self.cp[0][1], act="gelu_tanh", out=self.cp_h[:rows])
         ops.linear(self.cp_h[:rows].view(B, nq, L), self.cp[1][0], bias=self.cp[1][1], out=z3[:, Lz - nq:, :], batched=True)
-        if self.use_async:
+        if self.use_async and not images_encoded:
             # DINOv2 on the look-down frames: tokens -> left half of memcat, tokens + memory_pos -> MemoryEncoder stream
             mrows = B * nm
             self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
@@ -285,7 +305,8 @@ class NextDiTSystem1:
                 ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x,
                          out2=h, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt)
 
-    def generate_traj(self, traj_latents: torch.Tensor, images_dp: torch.Tensor, x_init: torch.Tensor, guidance_scale: float = 1.0) -> torch.Tensor:
+    def generate_traj(self, traj_latents: torch.Tensor, images_dp: torch.Tensor, x_init: torch.Tensor, guidance_scale: float = 1.0,
+                      images_encoded: bool = False) -> torch.Tensor:
         """traj_latents bf16 [B,n_query,3584]; images_dp bf16|f32 [B,2,224,224,3] in 0..1 (ignored without 'async'); x_init f32 [B,S,T,3]
         (the initial noise the reference draws with randn_tensor)  ->  latents f32 [B,S,T,3] (x4-scaled waypoint increments).
         guidance_scale: classifier-free guidance weight of internvla_n1.py:386-387,425-427 - noise = u + g (c - u) with u the prediction
@@ -296,7 +317,7 @@ class NextDiTSystem1:
         D, S, T = self.D, self.S, self.T
         rows = B * S * T
         cs = self._cond_set()
-        self.encode_condition(B, traj_latents, images_dp, cs)
+        self.encode_condition(B, traj_latents, images_dp, cs, images_encoded=images_encoded)
         cfg_on = float(guidance_scale) != 1.0
         sets = [(cs, self.x)]
         if cfg_on:
