@@ -57,8 +57,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--overlap-at", choices=["start", "decode"], default="decode",
                     help="n1_dual: side-stream System-1 starts with the System-2 micro-batch, or only once its prefill is done (decode phase)")
-    ap.add_argument("--priority", choices=["none", "decode", "s1"], default="none",
-                    help="n1_dual experiment: high-priority stream for the System-2 decode graph or for the side-stream System-1")
+    ap.add_argument("--priority", choices=["none", "decode", "s1", "main", "side-low"], default="none",
+                    help="n1_dual experiment: high-priority stream for the System-2 decode graph, for the side-stream System-1, for the whole "
+                         "main chain (prefill, decode, System-1 of the System-2 envs), or the lowest priority for the side stream")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     ap.add_argument("--vit-cache", action="store_true",
                     help="n1_dual: per-frame ViT cache variant - the first history frame of every env (frame 0, present in every np.linspace history "
@@ -355,6 +356,14 @@ class N1Dual:
             self.hi = torch.cuda.Stream(device=dev, priority=-1) if getattr(a, "priority", "none") == "decode" else None
             if getattr(a, "priority", "none") == "s1":
                 self.side = torch.cuda.Stream(device=dev, priority=-1)
+            if getattr(a, "priority", "none") == "side-low":
+                try:
+                    low = max(torch.cuda.Stream.priority_range())
+                except Exception:  # noqa: BLE001
+                    low = 1
+                self.side = torch.cuda.Stream(device=dev, priority=low)
+                self.desc["side_stream_priority"] = low
+            self.mainhi = torch.cuda.Stream(device=dev, priority=-1) if getattr(a, "priority", "none") == "main" else None
 
     def _ingest_s2(self, lo, m, dst):
         """System-2 images of envs [lo, lo + m): raw frames -> pixel_values of the micro-batch (or the round-1 resident tensor)."""
@@ -508,6 +517,12 @@ class N1Dual:
 
     def step(self, i):
         if self.overlap:
+            if getattr(self, "mainhi", None) is not None:      # experiment: the whole main chain on a high-priority stream
+                self.mainhi.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.mainhi):
+                    out = self.step_overlapped(i)
+                torch.cuda.current_stream().wait_stream(self.mainhi)
+                return out
             return self.step_overlapped(i)
         j = i % self.CADENCE
         m, lo = self.mb[j], int(self.mb_start[j])
