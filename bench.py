@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--s1-early-images", action="store_true",
                     help="n1_dual experiment: the look-down frames of the System-2 envs are encoded (DINOv2, MemoryEncoder, QFormer) on the side stream "
                          "at the start of the concurrent phase instead of after the decode chain")
+    ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
     ap.add_argument("--fuse-rownorm", action="store_true",
                     help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
     ap.add_argument("--no-raw-frames", action="store_true",
@@ -250,6 +251,8 @@ class N1Dual:
                                             max_patches=mmax * self.N_IMG * per, max_s2_seqs=mmax)
         if getattr(a, "fuse_rownorm", False):
             self.model.s1.fuse_rownorm = True
+        if getattr(a, "no_fuse_decode_norm", False):
+            self.model.qwen.fuse_decode_norm = False
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
         lim = qcfg["image_token_id"] - 16
         ids = torch.randint(0, lim, (B, self.S), device=dev, generator=g)

@@ -293,8 +293,12 @@ void launch_skinny_fused(const GemmArgs& p, hipStream_t stream) {
 #define INA_SKF(NW_, NC_, D_) hipLaunchKernelGGL((gemm_skinny_fused_kernel<MF, NT16, NW_, NC_, D_>), dim3((tiles + NC_ - 1) / NC_), dim3(NW_ * NC_ * 64), 0, stream, p)
     // experiment (round 3, INA_SKINNY_DEEP=1): twice the register ring for the single-fragment shapes - more bytes in flight per resident
     // wave for the decode chain that shares the GPU with System-1 (it gets a fraction of the wave slots there)
-    static int deep = -1;
+    static int deep = -1, small = -1;
     if (deep < 0) deep = (getenv("INA_SKINNY_DEEP") && atoi(getenv("INA_SKINNY_DEEP")) > 0) ? 1 : 0;
+    // experiment (INA_SKINNY_SMALL=1): 4-wave column groups with the 2-deep ring everywhere - workgroups that fit into what a retiring
+    // System-1 workgroup frees on a CU (an 8-wave, ~150-register workgroup has to wait for two of them)
+    if (small < 0) small = (getenv("INA_SKINNY_SMALL") && atoi(getenv("INA_SKINNY_SMALL")) > 0) ? 1 : 0;
+    if (small && nw == 8) { INA_SKF(4, 1, 2); return; }
     if constexpr (MF == 1) {
         if (deep) {
             if (nw == 1) INA_SKF(1, 4, 4);
