@@ -200,24 +200,26 @@ class NextDiTSystem1:
         return self._null
 
     def encode_images(self, B: int, images_dp: torch.Tensor):
-        """the part of the condition that depends on the look-down frames only (DINOv2, MemoryEncoder, QFormer -> the 32 memory tokens of
-        z): a caller that has the frames before the VLM latents (the bench's System-2 envs) can launch it early, on another stream, and
-        call generate_traj(..., images_encoded=True) once the latents exist."""
+        """the part of the condition that depends on the look-down frames only (internvla_n1.py:366-380: DINOv2, MemoryEncoder, QFormer -> the
+        32 memory tokens of z). A caller that has the frames before the VLM latents can launch it early and call
+        generate_traj(..., images_encoded=True) once the latents exist (bench.py --s1-early-images: measured slower inside the two-stream
+        step, kept as an experiment switch)."""
         assert self.use_async
         D, L, nm, Lz = self.D, self.L, self.nm, self.Lz
         z3 = self.z[: B * Lz].view(B, Lz, L)
-        if True:
-            mrows = B * nm
-            self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
-                             extra_outputs=[(self.me_ws.h[:mrows], self.me_ws.x[:mrows], None, self.mem_pos)])
-            self._memory_encoder(B)
-            qrows = B * 32
-            ops.embed3(None, None, None, out=self.q_ws.x[:qrows], pos=self.q_init, rows=qrows)
-            ops.embed3(None, None, None, out=self.q_ws.h[:qrows], pos=self.q_init, rows=qrows)
-            for Lr in self.q_layers:
-                ops.linear(self.memcat[:mrows], Lr.ca_kvw, bias=Lr.ca_kvb, out=self.q_kv[:mrows])
-                decoder_layer_postnorm(Lr, self.q_ws, B, 32, self.q_kv[:mrows], B, nm, 12, "relu")
-            z3[:, :32, :].copy_(self.q_ws.h[:qrows].view(B, 32, L))
+        # DINOv2 on the look-down frames: tokens -> left half of memcat, tokens + memory_pos -> MemoryEncoder stream
+        mrows = B * nm
+        self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                         extra_outputs=[(self.me_ws.h[:mrows], self.me_ws.x[:mrows], None, self.mem_pos)])
+        self._memory_encoder(B)
+        # QFormer (internvla_n1_arch.py:97-118): 32 learned queries attend to [feat | memory_feat]
+        qrows = B * 32
+        ops.embed3(None, None, None, out=self.q_ws.x[:qrows], pos=self.q_init, rows=qrows)
+        ops.embed3(None, None, None, out=self.q_ws.h[:qrows], pos=self.q_init, rows=qrows)
+        for Lr in self.q_layers:
+            ops.linear(self.memcat[:mrows], Lr.ca_kvw, bias=Lr.ca_kvb, out=self.q_kv[:mrows])
+            decoder_layer_postnorm(Lr, self.q_ws, B, 32, self.q_kv[:mrows], B, nm, 12, "relu")
+        z3[:, :32, :].copy_(self.q_ws.h[:qrows].view(B, 32, L))  # data movement only: memory tokens into the condition buffer
 
     def encode_condition(self, B: int, traj_latents: torch.Tensor, images_dp: torch.Tensor, cs: dict = None, images_encoded: bool = False):
         """internvla_n1.py:364-383 -> z [B, Lz, 768] (async: 32 memory tokens | n_query projected latents; otherwise the latents alone)
@@ -229,19 +231,7 @@ class NextDiTSystem1:
         ops.linear(traj_latents.reshape(rows, -1), self.cp[0][0], bias=self.cp[0][1], act="gelu_tanh", out=self.cp_h[:rows])
         ops.linear(self.cp_h[:rows].view(B, nq, L), self.cp[1][0], bias=self.cp[1][1], out=z3[:, Lz - nq:, :], batched=True)
         if self.use_async and not images_encoded:
-            # DINOv2 on the look-down frames: tokens -> left half of memcat, tokens + memory_pos -> MemoryEncoder stream
-            mrows = B * nm
-            self.vit.forward(images_dp.reshape(B * self.Fr, 224, 224, 3), self.vit_ws, self.memcat[:mrows, :D], mean=IMAGENET_MEAN, std=IMAGENET_STD,
-                             extra_outputs=[(self.me_ws.h[:mrows], self.me_ws.x[:mrows], None, self.mem_pos)])
-            self._memory_encoder(B)
-            # QFormer (internvla_n1_arch.py:97-118): 32 learned queries attend to [feat | memory_feat]
-            qrows = B * 32
-            ops.embed3(None, None, None, out=self.q_ws.x[:qrows], pos=self.q_init, rows=qrows)
-            ops.embed3(None, None, None, out=self.q_ws.h[:qrows], pos=self.q_init, rows=qrows)
-            for Lr in self.q_layers:
-                ops.linear(self.memcat[:mrows], Lr.ca_kvw, bias=Lr.ca_kvb, out=self.q_kv[:mrows])
-                decoder_layer_postnorm(Lr, self.q_ws, B, 32, self.q_kv[:mrows], B, nm, 12, "relu")
-            z3[:, :32, :].copy_(self.q_ws.h[:qrows].view(B, 32, L))  # data movement only: memory tokens into the condition buffer
+            self.encode_images(B, images_dp)
         self._derive_condition(B, cs)
 
     def _derive_condition(self, B: int, cs: dict):
