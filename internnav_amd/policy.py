@@ -266,6 +266,10 @@ class InternVLAN1ForCausalLM:
         if prefix_kv is not None and any(k is not None for k in prefix_kv):
             assert len(prefix_kv) == B and cached_image_embeds is None, "prefix_kv: one entry per sequence (not combined with cached_image_embeds)"
             pl = np.asarray([0 if k is None else int(k.shape[1]) for k in prefix_kv], dtype=np.int64)
+            if int(pl.max()) + S - int(pl.min()) + max_new_tokens + self.qwen.latent_q.shape[0] > self.qwen.S_max:
+                # prefixes of different lengths widen the rectangle the engine runs (every sequence's rows start behind ITS prefix): if that
+                # no longer fits the cache, run this call without the prefix caches - same results, only the saving is lost
+                prefix_kv, pl = [None] * B, np.zeros(B, dtype=np.int64)
             for b, k in enumerate(prefix_kv):
                 if k is not None:
                     self.qwen.import_prefix_kv(b, k)

@@ -335,3 +335,50 @@ def test_self_spawn_relaunches_one_process_per_gpu(tmp_path):
     assert out.stdout.strip() == "RANK none of none"                       # single GPU: no launcher involved
     bad = subprocess.run([sys.executable, str(script), "--gpus", "4"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_prefix_kv_plan_host_logic_on_cpu():
+    """QwenVLEngine.plan(prefix_len=...) is integer work (which images are skipped, which rows run, position ids, cache rows, key lengths):
+    checked here on a CPU-resident engine without any kernel launch. The arithmetic of the feature is tested on the GPU
+    (tests/test_prefix_kv_gpu.py)."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine, rope_index
+
+    cfg = dict(S.QWEN_TEST_CFG, v_depth=1, v_fullatt=(0,), t_layers=1)
+    eng = QwenVLEngine(S.qwen_state_dict(seed=1, cfg=cfg), cfg, "cpu", max_seqs=2, max_seq_len=1024, max_patches=2 * 3 * 784)
+    inp = S.qwen_inputs(2, 3, seed=1, cfg=cfg, n_text=40, n_tail=24)
+    ids, grid = inp["input_ids"], inp["grid_thw"]
+    S_ = ids.shape[1]
+    P0 = 40 + 196 + 2                                   # text | <vs> image 0 <ve>
+    full = eng.plan(ids, grid)
+    assert full["S_run"] == S_ and full["images_run"] == [0, 1, 2, 3, 4, 5] and full["prefill"]["k_len"] is None
+    # uniform prefix: image 0 of BOTH sequences is skipped, the run rows are the suffixes, cache rows start behind the prefix
+    uni = eng.plan(ids, grid, prefix_len=P0)
+    assert uni["S_run"] == S_ - P0 and uni["images_run"] == [1, 2, 4, 5] and uni["prefill"]["k_len"] is None and uni["prefill"]["Lk"] == S_
+    assert torch.equal(uni["ids"].view(2, -1).long(), ids[:, P0:])
+    rows = uni["prefill"]["rows"].view(2, -1)
+    assert rows[0, 0] == P0 and rows[1, 0] == eng.S_max + P0 and rows[0, -1] == S_ - 1
+    pos3, _ = rope_index(ids.numpy(), [tuple(g) for g in grid.tolist()], cfg["image_token_id"], cfg["vision_start_id"])
+    assert np.array_equal(uni["prefill"]["pos"].view(3, 2, -1).numpy(), pos3[:, :, P0:])          # positions of the full prompt, sliced
+    assert np.array_equal(uni["next_pos"], full["next_pos"])
+    # per-sequence prefixes (sequence 1 has nothing cached): rectangle of the longest suffix, key length = own prefix + rectangle width
+    mix = eng.plan(ids, grid, prefix_len=np.array([P0, 0]))
+    assert mix["S_run"] == S_ and mix["images_run"] == [1, 2, 3, 4, 5]
+    assert mix["prefill"]["k_len"].tolist() == [P0 + S_, S_] and mix["prefill"]["Lk"] == P0 + S_
+    r = mix["ids"].view(2, -1).long()
+    assert torch.equal(r[0, : S_ - P0], ids[0, P0:]) and int(r[0, S_ - P0:].abs().sum()) == 0 and torch.equal(r[1], ids[1])
+    assert eng.images_in_prefix(ids, grid, np.array([P0, 0])) == [True, False, False, False, False, False]
+    # a prefix that cuts an image, or that leaves nothing to run, is refused
+    with pytest.raises(AssertionError, match="image boundary"):
+        eng.plan(ids, grid, prefix_len=P0 - 5)
+    with pytest.raises(AssertionError):
+        eng.plan(ids, grid, prefix_len=S_)
+    # export / import are pure copies between the cache slots and per-env tensors
+    for L in eng.layers:
+        L["kv"].copy_(torch.randn(L["kv"].shape).to(L["kv"].dtype))
+    kv = eng.export_prefix_kv(1, P0)
+    assert kv.shape == (len(eng.layers), P0, eng.kv_w)
+    eng.import_prefix_kv(0, kv)
+    assert torch.equal(eng.export_prefix_kv(0, P0), kv)
+    eng.import_prefix_kv_batch(torch.stack([kv, kv]))
+    assert torch.equal(eng.export_prefix_kv(1, P0), kv)
