@@ -149,6 +149,45 @@ def test_agent_from_config_alone_steps_two_envs(ckpt, monkeypatch):
     InternVLAN1Net._shared.clear()
 
 
+def test_batched_agent_with_prefix_cache_equals_uncached_agent(ckpt, monkeypatch):
+    """model_settings['prefix_cache'] through the batched agent: three envs with instructions of different lengths (ragged System-2 batches,
+    per-env prefixes of different lengths, envs with and without a stored prefix in one call, a mid-run episode reset, look-down turns):
+    every action and every latent equals the uncached agent's bit for bit, and the engine prefills fewer rows once prefixes exist."""
+    from internnav_amd.agent import InternVLAN1Agent
+    from internnav_amd.policy import InternVLAN1Net
+
+    d, _ = ckpt
+    monkeypatch.setattr(InternVLAN1Net, "load_processor", staticmethod(lambda path: _load_processor(path, scripted=True)))
+    instr = ["go to the door", "walk past the sofa and stop at the door", "turn left at the kitchen, then enter the second bedroom on the right"]
+    runs = []
+    for pc in (False, True):
+        InternVLAN1Net._shared.clear()                       # a fresh model per agent: same sampler-noise stream for both runs
+        agent = InternVLAN1Agent(SimpleNamespace(model_name="internvla_n1", model_settings=_settings(d, env_num=3, prefix_cache=pc)))
+        assert all(e.policy.prefix_cache == pc for e in [agent._env(i) for i in range(3)])
+        agent.reset()
+        rng = np.random.default_rng(7)
+        acts, lats, widths = [], [], []
+        for step in range(14):
+            obs = _obs(rng, 3)
+            for o, t in zip(obs, instr):
+                o["instruction"] = t
+            out = agent.step(obs)
+            acts.append([o["action"][0] for o in out])
+            lats.append([None if e.s2_output.output_latent is None else e.s2_output.output_latent.float().cpu().clone() for e in agent.envs])
+            g = getattr(agent.model, "_gen", None)
+            widths.append(None if g is None else int(g["state"]["S_run"]))
+            if step == 6:
+                agent.reset([2])
+        runs.append((acts, lats, widths, agent.s2_failures))
+    InternVLAN1Net._shared.clear()
+    (a0, l0, w0, f0), (a1, l1, w1, f1) = runs
+    assert a0 == a1 and f0 == f1, (a0, a1)
+    for x, y in zip(l0, l1):
+        for u, v in zip(x, y):
+            assert (u is None) == (v is None) and (u is None or torch.equal(u, v))
+    assert any(c is not None and u is not None and c < u for c, u in zip(w1, w0)), (w0, w1)     # some System-2 call ran a narrower rectangle
+
+
 def test_full_history_plus_camera_size_lookdown_frame_fits(ckpt, monkeypatch):
     """step >= 8 of an episode: 8 history + current frame (196 tokens each) + the 640 x 480 look-down frame (34 x 46 patches, 391
     tokens): 2155 image tokens / 8620 patches in ONE prompt. Round 1 asserted here (max_seq_len 2048) and the agent turned it into STOP."""
