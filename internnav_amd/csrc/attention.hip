@@ -407,11 +407,6 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
     //  leave one workgroup per CU, 351 vs 184 us on the LLM prefill shape; equal at d = 80, slower at d = 64)
     const bool small_k = p.Lk <= 48;
     int nw = (p.Lq <= 16) ? 1 : (p.Lq <= 32 ? 2 : 4);
-    // experiment (round 3, INA_ATTN_NW8=1): 8-wave workgroups (128 query rows share each staged K / V block) for long dense sequences:
-    // the global fetch and the transposing LDS stores of a block are amortised over twice the MFMA work
-    static int nw8 = -1;
-    if (nw8 < 0) nw8 = (getenv("INA_ATTN_NW8") && atoi(getenv("INA_ATTN_NW8")) > 0) ? 1 : 0;
-    if (nw8 && p.Lq >= 256 && !p.drop_thresh && !small_k) nw = 8;
     dim3 grid((p.Lq + nw * 16 - 1) / (nw * 16), p.H, p.B);
     // algorithmic FLOPs: QK^T + PV over the unmasked keys (dense bound Lq x Lk for varlen: cu_* lengths live on the device)
     const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)(p.Lk - p.kv_start);
@@ -436,7 +431,6 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
     hipLaunchKernelGGL((attn_fwd_kernel<DP, DV, NW_, KVB_>), grid, dim3(NW_ * 64), 0, stream, p)
     if (nw == 1) { if (small_k) INA_ATTN_LAUNCH(1, 32); else INA_ATTN_LAUNCH(1, 64); }
     else if (nw == 2) { if (small_k) INA_ATTN_LAUNCH(2, 32); else INA_ATTN_LAUNCH(2, 64); }
-    else if (nw == 8) INA_ATTN_LAUNCH(8, 64);
     else { if (small_k) INA_ATTN_LAUNCH(4, 32); else INA_ATTN_LAUNCH(4, 64); }
 #undef INA_ATTN_LAUNCH
     INA_HIP_CHECK(hipGetLastError());
