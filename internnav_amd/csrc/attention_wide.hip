@@ -41,10 +41,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16* a0, const bf16* a1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// DEFER: keep the running maximum while no row of the wave grew by more than 2^DEFER_THR (the accumulator rescale is skipped)
+// DEFER: a row keeps its running maximum until it grows by more than 2^DEFER_THR (P <= 2^DEFER_THR instead of <= 1; the accumulator
+// rescale is skipped while no row of the wave moves)
 constexpr float DEFER_THR = 6.0f;
 
-template <int D, int NW, bool DEFER>
+template <int D, int NW, bool DEFER, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     using C = WideCfg<D>;
     constexpr int NT = NW * 64, KVB = C::KVB, KLD = C::KLD, VLD = C::VLD, NDT = C::NDT, NKS = C::NKS;
@@ -58,7 +59,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // 1-D grid. Tiles are aligned to the END of the query sequence and counted from it (tile t = rows len_q - (t + 1) QT ...): the
+    // partial tile of a sequence is its FIRST rows. Causal: tile slowest - every sequence's tile 0 (the longest) first, then every
+    // tile 1, ...: longest-first over the whole grid, the tail of the launch is made of the short tiles (108.8 -> 71.0 us on the LLM
+    // prefill shape together with the end alignment). Not causal (equal tiles): tile fastest, so that the tiles of one (sequence, head)
+    // run together and share its K / V in L2 (the tile-slowest order costs 15 % there).
+    const int nbh = p.H * p.B, ntile = gridDim.x / nbh;
+    const int tile = p.causal ? blockIdx.x / nbh : blockIdx.x % ntile;
+    const int bh = p.causal ? blockIdx.x % nbh : blockIdx.x / ntile;
+    const int b = bh / p.H, h = bh % p.H;
     const int kb = b / p.kv_bdiv;
     const int kh = h / (p.H / p.Hkv);
 
@@ -66,8 +75,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     if (p.cu_q) { q_off = p.cu_q[b]; len_q = p.cu_q[b + 1] - q_off; }
     if (p.cu_k) { k_off = p.cu_k[kb]; len_k = p.cu_k[kb + 1] - k_off; }
     else if (p.k_len) len_k = min(p.k_len[kb], p.Lk);
-    const int qt0 = (p.causal ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * QT;   // causal: longest query tiles first
-    if (qt0 >= len_q) return;
+    const int qt0 = len_q - (tile + 1) * QT;         // may be negative: rows < 0 do not exist
+    if (qt0 + QT <= 0) return;
 
     const bf16* __restrict__ Q = reinterpret_cast<const bf16*>(p.Q) + (size_t)b * p.q_bs + (size_t)q_off * p.q_rs + (size_t)h * p.q_hs;
     const bf16* __restrict__ K = reinterpret_cast<const bf16*>(p.K) + (size_t)kb * p.k_bs + (size_t)k_off * p.k_rs + (size_t)kh * p.k_hs;
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     bf16x8 qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (size_t)min(q_abs, len_q - 1) * p.q_rs + ks * 16 + hi * 8);   // rows past the end: never stored
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (size_t)max(q_abs, 0) * p.q_rs + ks * 16 + hi * 8);   // rows < 0: never stored
 
     f32x16 acc[NDT];
 #pragma unroll
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     if (p.causal) kv_end = min(len_k, min(qt0 + QT, len_q) - 1 + causal_shift + 1);
     const int kv_begin = (p.kv_start / KVB) * KVB;
     // wave: its own rows' bound (blocks past it are skipped, the wave still takes part in the staging and the barriers)
-    const bool wave_live = wq0 < len_q;
+    const bool wave_live = wq0 + 32 > 0;
     int wave_kv_end = kv_end;
     if (p.causal) wave_kv_end = min(kv_end, min(wq0 + 32, len_q) - 1 + causal_shift + 1);
 
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     for (int ib = 0; ib < nblk; ++ib) {
         const int kv0 = kv_begin + ib * KVB, buf = ib & 1;
         const bool more = ib + 1 < nblk;
-        if (more) fetch(kv0 + KVB);
+        if (more && !(VAR & 1)) fetch(kv0 + KVB);
         if (wave_live && kv0 < wave_kv_end) {
             const bf16* Kb = Ks + buf * C::K_ELEMS;
             const bf16* Vb = Vs + buf * C::V_ELEMS;
@@ -180,19 +189,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
                                 kf[(g + 1) & 1][j][t] = *reinterpret_cast<const bf16x8*>(kbase + t * 32 * KLD + (2 * g + 2 + j) * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         if (2 * g + j < NKS) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g & 1][j][t], qf[2 * g + j], s[t], 0, 0, 0);
+                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // first V^T tile: requested now, consumed after the softmax
-            bf16x8 vf[2][4];
+            if constexpr (VAR & 1) { if (more) fetch(kv0 + KVB); }
+            // V^T fragments of the first 16-key slice (all d tiles): requested now, consumed after the softmax
+            bf16x8 vf[2][NDT];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const bf16* a0 = Vb + tr_off + s4 * 16 * VLD;
-                vf[0][s4] = tr_pair(a0, a0 + 8 * VLD);
+            for (int dt = 0; dt < NDT; ++dt) {
+                const bf16* a0 = Vb + tr_off + dt * 32;
+                vf[0][dt] = tr_pair(a0, a0 + 8 * VLD);
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- mask (edge / diagonal blocks only) + online softmax; lane: query q_abs, keys kv0 + 32 t + crow(r, hi)
@@ -225,8 +237,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             mx *= sc;
             const bool grow = DEFER ? (mx > m_run + DEFER_THR) : (mx > m_run);
-            if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
-                const float m_new = fmaxf(m_run, mx);
+            if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {   // the branch is wave-wide, the decision is per row: a row's arithmetic never
+                const float m_new = grow ? fmaxf(m_run, mx) : m_run;   // depends on which rows share its wave (prefix-KV reuse stays bit-exact)
                 const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
                 l_run *= alpha;
 #pragma unroll
@@ -247,19 +259,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
                     pf[t * 2 + (r >> 3)][r & 7] = (bf16)e;
                 }
             l_run += rs;
-            // ---- O^T += V^T . P^T: per 32-wide d tile, 4 key slices of 16; the next tile's V^T fragments are read under this tile's MFMAs
+            // ---- O^T += V^T . P^T: key slices of 16 outermost, so that consecutive MFMAs go to NDT independent accumulators; the next
+            // slice's V^T fragments are read under this slice's MFMAs
 #pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) {
-                if (dt + 1 < NDT) {
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 + 1 < 4) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const bf16* a0 = Vb + tr_off + s4 * 16 * VLD + (dt + 1) * 32;
-                        vf[(dt + 1) & 1][s4] = tr_pair(a0, a0 + 8 * VLD);
+                    for (int dt = 0; dt < NDT; ++dt) {
+                        const bf16* a0 = Vb + tr_off + (s4 + 1) * 16 * VLD + dt * 32;
+                        vf[(s4 + 1) & 1][dt] = tr_pair(a0, a0 + 8 * VLD);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt & 1][s4], pf[s4], acc[dt], 0, 0, 0);
+                for (int dt = 0; dt < NDT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s4 & 1][dt], pf[s4], acc[dt], 0, 0, 0);
+                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -286,21 +301,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
 #pragma unroll
     for (int u = 0; u < (32 * KCH + 63) / 64; ++u) {
         const int q = lane + u * 64, row = q / KCH, c = q % KCH;
-        if (q < 32 * KCH && wq0 + row < len_q)
+        if (q < 32 * KCH && wq0 + row >= 0)
             *reinterpret_cast<bf16x8*>(O + (size_t)(wq0 + row) * p.o_rs + c * 8) = *reinterpret_cast<const bf16x8*>(&Ow[row * OLD + c * 8]);
     }
 }
 
-template <int D, int NW, bool DEFER>
+template <int D, int NW, bool DEFER, int VAR = 0>
 int launch_wide(const AttnArgs& p, hipStream_t stream) {
     using C = WideCfg<D>;
-    auto kern = attn_fwd_wide_kernel<D, NW, DEFER>;
+    auto kern = attn_fwd_wide_kernel<D, NW, DEFER, VAR>;
     static bool attr_done = false;
     if (!attr_done) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
         attr_done = true;
     }
-    dim3 grid((p.Lq + NW * 32 - 1) / (NW * 32), p.H, p.B);
+    dim3 grid(((p.Lq + NW * 32 - 1) / (NW * 32)) * p.H * p.B);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), C::LDS, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
@@ -309,6 +324,14 @@ int launch_wide(const AttnArgs& p, hipStream_t stream) {
 template <int D>
 int launch_wide_d(const AttnArgs& p, hipStream_t stream, int nw, bool defer) {
     if (nw == 8) return defer ? launch_wide<D, 8, true>(p, stream) : launch_wide<D, 8, false>(p, stream);
+    if (const char* e = getenv("INA_ATTN_VAR"); e && defer) {   // schedule experiments: 1 = K/V prefetch issued after Q.K^T, 2 = s_setprio around the MFMA groups
+        switch (atoi(e)) {
+            case 1: return launch_wide<D, 4, true, 1>(p, stream);
+            case 2: return launch_wide<D, 4, true, 2>(p, stream);
+            case 3: return launch_wide<D, 4, true, 3>(p, stream);
+            default: break;
+        }
+    }
     return defer ? launch_wide<D, 4, true>(p, stream) : launch_wide<D, 4, false>(p, stream);
 }
 

@@ -37,14 +37,19 @@ import os  # noqa: E402
 
 for cfg in ({"INA_ATTN_WIDE": "0"}, {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1"},
             {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "0"},
-            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "8", "INA_ATTN_DEFER": "1"}):
+            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "8", "INA_ATTN_DEFER": "1"},
+            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1", "INA_ATTN_VAR": "1"},
+            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1", "INA_ATTN_VAR": "2"},
+            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1", "INA_ATTN_VAR": "3"}):
+    os.environ.pop("INA_ATTN_VAR", None)
     os.environ.update(cfg)
     print("==", " ".join(f"{k}={v}" for k, v in cfg.items()), "(0 = 16-row kernel, 1 = 32-rows-per-wave kernel)")
     dense("LLM prefill 7x920 28/4 x128 causal", 7, 920, 28, 4, 128, True)
     dense("LLM prefill 6x920 28/4 x128 causal", 6, 920, 28, 4, 128, True)
+    dense("7x920 28/4 x128 NOT causal", 7, 920, 28, 4, 128, False)
     dense("ViT full 28x784 16 x80", 28, 784, 16, 16, 80, False)
     dense("DINOv2 128x257 6 x64", 128, 257, 6, 6, 64, False)
-for k in ("INA_ATTN_WIDE", "INA_ATTN_WIDE_NW", "INA_ATTN_DEFER"):
+for k in ("INA_ATTN_WIDE", "INA_ATTN_WIDE_NW", "INA_ATTN_DEFER", "INA_ATTN_VAR"):
     os.environ.pop(k, None)
 # ViT windows: 64-token windows packed on one axis
 Np, H, D = 21952, 16, 80
