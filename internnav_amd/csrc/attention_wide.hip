@@ -324,7 +324,7 @@ int launch_wide(const AttnArgs& p, hipStream_t stream) {
 template <int D>
 int launch_wide_d(const AttnArgs& p, hipStream_t stream, int nw, bool defer) {
     if (nw == 8) return defer ? launch_wide<D, 8, true>(p, stream) : launch_wide<D, 8, false>(p, stream);
-    if (const char* e = getenv("INA_ATTN_VAR"); e && defer) {   // schedule experiments: 1 = K/V prefetch issued after Q.K^T, 2 = s_setprio around the MFMA groups
+    if (const char* e = getenv("INA_ATTN_VAR"); e && defer) {   // (experiments were run with the deferred maximum)   // schedule experiments: 1 = K/V prefetch issued after Q.K^T, 2 = s_setprio around the MFMA groups
         switch (atoi(e)) {
             case 1: return launch_wide<D, 4, true, 1>(p, stream);
             case 2: return launch_wide<D, 4, true, 2>(p, stream);
@@ -339,8 +339,12 @@ int launch_wide_d(const AttnArgs& p, hipStream_t stream, int nw, bool defer) {
 
 bool ina_attention_wide_eligible(const AttnArgs& p) {
     // experiment switches are read per call (tests and tools flip them inside one process)
-    if (const char* e = getenv("INA_ATTN_WIDE"); e && e[0] == '0') return false;
-    if (p.D != 128 && p.D != 80 && p.D != 64) return false;
+    const char* e = getenv("INA_ATTN_WIDE");     // unset: d 128 / d 80 (LLM prefill, Qwen ViT); "1": d 64 as well; "0": never
+    if (e && e[0] == '0') return false;
+    // d 64 (DINOv2, 257 tokens) stays on the 16-row kernel by default: 41.9 vs 67.1 us per launch there, but the NavDP heads behind it are
+    // checked at the north-star tolerance with no margin (mean |err| 9.4e-4 vs 1e-3) and ten clipped DDPM steps amplify ANY change of
+    // rounding order: with the numerically equivalent wide kernel (same mean error to 4 digits on the op) the fixture lands at 1.003e-3
+    if (p.D != 128 && p.D != 80 && !(p.D == 64 && e && e[0] == '1')) return false;
     if (p.accumulate || p.head_gate || p.drop_thresh) return false;
     if (p.Lq < 128 || p.Lk < 128 || p.scale <= 0.f) return false;
     // whole-row 16-byte output stores
@@ -354,7 +358,7 @@ int ina_launch_attention_wide(const AttnArgs& p, hipStream_t stream) {
     const char* e_nw = getenv("INA_ATTN_WIDE_NW");
     const char* e_df = getenv("INA_ATTN_DEFER");
     const int nw = (e_nw && atoi(e_nw) == 8) ? 8 : 4;
-    const bool defer = !(e_df && e_df[0] == '0');
+    const bool defer = e_df && e_df[0] == '1';   // default: exact running maximum (the largest P of a row is exactly 1, as in the 16-row kernel)
     switch (p.D) {
         case 128: return launch_wide_d<128>(p, stream, nw, defer);
         case 80: return launch_wide_d<80>(p, stream, nw, defer);
