@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--s1-early-images", action="store_true",
                     help="n1_dual experiment: the look-down frames of the System-2 envs are encoded (DINOv2, MemoryEncoder, QFormer) on the side stream "
                          "at the start of the concurrent phase instead of after the decode chain")
+    ap.add_argument("--no-split-prefill", action="store_true",
+                    help="n1_dual: System-2 prefill as ONE launch sequence instead of two half micro-batches on two streams")
     ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
     ap.add_argument("--fuse-rownorm", action="store_true",
                     help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
@@ -253,6 +255,8 @@ class N1Dual:
             self.model.s1.fuse_rownorm = True
         if getattr(a, "no_fuse_decode_norm", False):
             self.model.qwen.fuse_decode_norm = False
+        if getattr(a, "no_split_prefill", False):
+            self.model.qwen.split_prefill = False
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
         lim = qcfg["image_token_id"] - 16
         ids = torch.randint(0, lim, (B, self.S), device=dev, generator=g)
@@ -284,6 +288,8 @@ class N1Dual:
                                if self.raw else "pre-processed pixel_values / 224x224 frames resident in HBM"),
                      "s2": f"{self.N_IMG} frames x 784 patches + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
                      "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps", "s2_microbatches_per_10_steps": self.mb}
+        self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence)"
+                                   if self.model.qwen.split_prefill else "one launch sequence")
         self.vit_cache = bool(getattr(a, "vit_cache", False)) and self.raw
         self.prefix_kv = bool(getattr(a, "prefix_kv", False)) and self.raw
         assert not (self.vit_cache and self.prefix_kv), "--prefix-kv already covers frame 0 (its tokens are cached K/V): use one of the two"
@@ -547,7 +553,12 @@ class N1Dual:
 
     def instrumented(self):
         m = max(self.mb)
-        self._s2_call(m)
+        q = self.model.qwen
+        keep, q.split_prefill = q.split_prefill, False      # one stream: the per-launch HIP events time kernels that do not overlap
+        try:
+            self._s2_call(m)
+        finally:
+            q.split_prefill = keep
         self._s1_call()
         return m
 

@@ -39,6 +39,7 @@ class GraphedCall:
     def __init__(self, fn: Callable, static_inputs: Dict[str, torch.Tensor], warmup: int = 2, workspace_slot: int = 0):
         """workspace_slot: library scratch slot baked into this graph; graphs that may replay concurrently need different slots."""
         self.inputs = static_inputs
+        self.fn = fn   # keeps the closure (engine, plan, buffers whose addresses are baked into the graph) alive as long as the graph
         _lib.check(_lib.lib().ina_set_workspace_slot(workspace_slot), "set_workspace_slot")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -121,6 +121,48 @@ def test_planned_launch_sequence_equals_eager_and_is_graph_capturable(setup):
     assert torch.equal(toks, toks_ref) and torch.equal(lat, lat_ref)
 
 
+def test_split_prefill_two_streams_equals_joint_prefill(setup):
+    """The prefill of >= 2 plain prompts as two half batches on two streams (engine.split_prefill, fork / join inside the launch
+    sequence) against the joint launch sequence: same greedy tokens, logits / latents / K-V cache equal to rounding (the halves may
+    pick other GEMM tile shapes than the joint batch), eagerly and replayed from ONE captured graph; the frame-cache rows as well."""
+    from internnav_amd.runtime import GraphedCall
+
+    gold, cfg, inp, eng = setup
+    pv = inp["pixel_values"].to(DEV, torch.bfloat16)
+    B, S = inp["input_ids"].shape
+    assert B >= 2
+    out = {}
+    for split in (False, True):
+        eng.split_prefill = split
+        P = eng.plan(inp["input_ids"], inp["grid_thw"], n_decode=3, with_latents=True)
+        assert ("split" in P) == split
+        toks = torch.zeros(B, 3, dtype=torch.int32, device=DEV)
+        lat = torch.zeros(B, cfg["n_query"], cfg["t_hidden"], dtype=torch.bfloat16, device=DEV)
+        for L in eng.layers:
+            L["kv"].zero_()
+        eng.run_s2(P, pv, toks, lat)
+        torch.cuda.synchronize()
+        kv = torch.stack([L["kv"].view(eng.B_max, eng.S_max, -1)[:B, :S].clone() for L in eng.layers])
+        out[split] = dict(toks=toks.clone(), lat=lat.clone(), kv=kv, logits=eng.logits[:B].clone(), emb_tok=eng.emb_tok.clone(), P=P)
+    eng.split_prefill = True
+    a, b = out[False], out[True]
+    assert torch.equal(a["toks"], b["toks"])
+    for k in ("lat", "kv", "logits", "emb_tok"):
+        d = (a[k].float() - b[k].float()).abs()
+        print(f"split vs joint prefill, {k}: bit-equal {torch.equal(a[k], b[k])}, max|diff| {d.max().item():.3e} (scale {a[k].float().abs().max().item():.2f})")
+        assert d.max().item() <= 2e-2 * max(1.0, a[k].float().abs().max().item())
+    # one captured graph with the fork / join inside
+    P = b["P"]
+    toks = torch.zeros(B, 3, dtype=torch.int32, device=DEV)
+    lat = torch.zeros(B, cfg["n_query"], cfg["t_hidden"], dtype=torch.bfloat16, device=DEV)
+    g = GraphedCall(lambda pixel_values: eng.run_s2(P, pixel_values, toks, lat), {"pixel_values": pv})
+    toks.zero_()
+    lat.zero_()
+    g()
+    torch.cuda.synchronize()
+    assert torch.equal(toks, b["toks"]) and torch.equal(lat, b["lat"])
+
+
 def test_facade_generate_then_latents_reuses_cache(setup):
     """InternVLAN1ForCausalLM surface: generate(...).sequences then generate_latents(output_ids, ...) as the reference's policy calls them."""
     from internnav_amd.policy import InternVLAN1ForCausalLM
