@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--s1-early-images", action="store_true",
                     help="n1_dual experiment: the look-down frames of the System-2 envs are encoded (DINOv2, MemoryEncoder, QFormer) on the side stream "
                          "at the start of the concurrent phase instead of after the decode chain")
+    ap.add_argument("--s1-split", action="store_true",
+                    help="n1_dual experiment: the side-stream System-1 call (envs keeping their plan) as two half batches on two streams "
+                         "(76.1 -> 69.4 ms alone, the step does not move: 282.2 / 282.3 vs 283.0 - the main chain is the critical one)")
     ap.add_argument("--no-split-prefill", action="store_true",
                     help="n1_dual: System-2 prefill as ONE launch sequence instead of two half micro-batches on two streams")
     ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
@@ -347,6 +350,15 @@ class N1Dual:
             self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
             self.side = torch.cuda.Stream(device=dev)
             nA = B - min(self.mb)
+            # experiment (--s1-split): the side-stream call as two half batches on two streams (a second engine instance with its own
+            # buffers): the MFMA-bound GEMM launches of one half run beside the HBM-bound norm / attention launches of the other (57
+            # envs: 76.1 -> 69.4 ms alone, profiles/r03t_two_stream_s1_probe.log) - neutral in the step, where the main chain is critical
+            self.s1_split = bool(getattr(a, "s1_split", False))
+            if self.s1_split:
+                self.s1_half = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=nA // 2, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
+                self.side2 = torch.cuda.Stream(device=dev)
+                self.gA2 = {}
+                self.desc["s1_side_call"] = "two half batches on two streams"
             self.latA, self.imgA, self.xA = (torch.empty((nA,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
                                              for t in (self.latent_table, self.images_dp, self.x_init))
             self.latB, self.imgB, self.xB = (torch.empty((mmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
@@ -413,7 +425,11 @@ class N1Dual:
         if self.overlap:
             for m in sorted(set(self.mb)):
                 nA = self.B - m
-                self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA]), {}, workspace_slot=1)
+                n1 = nA - nA // 2 if self.s1_split else nA          # envs [0, n1) on the first engine, [n1, nA) on the second
+                self.gA[nA] = runtime.GraphedCall(lambda n1=n1: self.model.s1.generate_traj(self.latA[:n1], self.imgA[:n1], self.xA[:n1]), {}, workspace_slot=1)
+                if self.s1_split:
+                    self.gA2[nA] = runtime.GraphedCall(lambda n1=n1, nA=nA: self.s1_half.generate_traj(self.latA[n1:nA], self.imgA[n1:nA], self.xA[n1:nA]), {},
+                                                       workspace_slot=4)
                 early = bool(getattr(self.a, "s1_early_images", False))
                 self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m], images_encoded=early), {}, workspace_slot=2)
                 if early:
@@ -468,10 +484,17 @@ class N1Dual:
         torch.index_select(self.images_dp, 0, idx, out=self.imgA[:nA])
         torch.index_select(self.x_init, 0, idx, out=self.xA[:nA])
         late = self.overlap_at == "decode"
+        split = self.s1_split
+        n1 = nA - nA // 2 if split else nA
+        trajA2 = None
         if not late:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
                 trajA = self.gA[nA]()
+            if split:
+                self.side2.wait_stream(main)
+                with torch.cuda.stream(self.side2):
+                    trajA2 = self.gA2[nA]()
         # main stream: System-2 micro-batch, then System-1 for exactly those envs
         s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
         self._ingest_s2(lo, m, s["pv"])
@@ -485,6 +508,10 @@ class N1Dual:
                     self.gBimg[m]()
                     self.ev3.record(self.side)
                 trajA = self.gA[nA]()
+            if split:
+                with torch.cuda.stream(self.side2):
+                    self.side2.wait_event(self.ev)
+                    trajA2 = self.gA2[nA]()
             if self.hi is not None:
                 with torch.cuda.stream(self.hi):
                     self.hi.wait_event(self.ev)
@@ -507,7 +534,11 @@ class N1Dual:
         # stream is still busy with the System-2 decode passes and the System-1 call of the System-2 envs
         acts = np.zeros((self.B, 4), dtype=np.int32)
         with torch.cuda.stream(self.side):
-            self.hostA[:nA].copy_(trajA, non_blocking=True)
+            self.hostA[:n1].copy_(trajA, non_blocking=True)
+        if split:
+            with torch.cuda.stream(self.side2):
+                self.hostA[n1:nA].copy_(trajA2, non_blocking=True)
+            self.side2.synchronize()
         self.side.synchronize()
         for k, b in enumerate(self.idxA_host[j]):
             al = [x for x in self.traj_to_actions(self.hostA[k]) if x != 0][:4]
@@ -518,7 +549,7 @@ class N1Dual:
             al = [x for x in self.traj_to_actions(self.hostB[k]) if x != 0][:4]
             acts[lo + k, :len(al)] = al
         if getattr(self, "freeze_noise", False):   # schedule check: keep the assembled trajectories
-            self.traj.index_copy_(0, idx, trajA)
+            self.traj.index_copy_(0, idx, torch.cat([trajA, trajA2]) if split else trajA)
             self.traj[lo:lo + m].copy_(trajB)
             self.last_traj = self.traj
         self.actions.copy_(torch.from_numpy(acts))
