@@ -11,6 +11,7 @@ import bench  # noqa: E402
 which, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3
 wl = bench.N1Dual(SimpleNamespace(envs=64, no_overlap=True, no_graph=True), torch.device("cuda:0"), 0)
 m = max(wl.mb)
+wl.model.qwen.split_prefill = False   # one launch sequence on one stream: per-kernel durations of kernels that do not overlap (as bench.py's instrumented pass)
 wl._ingest_s2(0, m, wl.s2[m]["pv"])
 for _ in range(n):
     if which == "s2":
