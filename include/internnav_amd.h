@@ -79,7 +79,7 @@ typedef struct ina_gemm_args {
     int32_t rowscale_div;   /* 0 means 1 */
     int32_t batch;          /* 0 means 1; grid.y batches with the element strides below */
     int64_t strideA, strideW, strideC, strideR;
-    int32_t force_cfg;      /* 0 = auto tile selection */
+    int32_t force_cfg;      /* 0 = auto tile selection; -1 = auto for a launch that shares the device with another stream's GEMMs (tile quantisation not charged); > 0 = that tile config */
     int32_t group_m;        /* tile order of the LDS-DMA kernels: 0 = auto, 1 = row-major, n > 1 = groups of n row-tiles (L2 locality) */
     /* fused input RMSNorm (M <= 16, the single-token decode passes of the LLM: transformers Qwen2RMSNorm in front of q/k/v and gate/up):
      * C = epilogue(bf16(A * rsqrt(mean(A^2) + norm_eps) * norm_gamma) . W^T) with A of dtype a_dtype - the separate norm launch and its

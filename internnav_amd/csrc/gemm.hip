@@ -208,10 +208,17 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         // instead of 64 FLOP per operand byte, 3 workgroups per CU: +14-15 % (740-816 vs 632-704 TF/s, profiles/r02m_gemm_s1_tile_sweep.log)
         if (p.K <= 512 && p.N >= 1024 && p.M >= 4096) cfg = p.N >= 1536 ? 26 : 27;
         if (p.K >= 768 && p.N > 512) {   // narrow outputs (N = 384 heads): 128x128 measured 6-15 % ahead of 256x128 at K = 1024 / 1536
+            // force_cfg = -1 (INA_GEMM_AUTO_SHARED): auto selection for a launch that runs BESIDE another stream's GEMMs (the two half
+            // micro-batches of the System-2 prefill): the CUs its last round leaves idle are taken by the other stream's workgroups, so
+            // tile quantisation is not charged (fractional rounds) and the tile with the best per-CU rate wins. Measured on the decoder
+            // chain of the two halves, two streams: 60.7 vs 62.7 ms (2760 + 2760 rows), 71.7 vs 72.7 ms (3680 + 2760)
+            // (profiles/r03w_native_chain_sweep.log). Every tile shape accumulates K in the same order: the choice never changes a bit.
+            const bool shared = p.force_cfg == -1;
             auto cost = [&](int bm, int bn, int wg_per_cu, double rate) {
                 const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch;
                 const long slots = 256L * wg_per_cu;
-                return (double)((tiles + slots - 1) / slots) * wg_per_cu * (bm / 128.0) * (bn / 128.0) / rate;
+                const double rounds = shared ? (double)tiles / slots : (double)((tiles + slots - 1) / slots);
+                return rounds * wg_per_cu * (bm / 128.0) * (bn / 128.0) / rate;
             };
             const double c11 = cost(128, 128, 2, 0.85), c14 = cost(256, 128, 1, 0.92), c18 = cost(256, 256, 1, 1.18);
             const double c21 = cost(192, 256, 1, 0.97);   // 192-row ping-pong tiles: the row counts of 6 / 7 prompts (5520 / 6440) round better

@@ -5,6 +5,7 @@ kernels of libinternnav_amd.so. Tensors must live on the current HIP device.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional
 
@@ -15,6 +16,23 @@ from ._lib import AttnArgs, GemmArgs, NormArgs
 
 ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "gelu_tanh": 2, "relu": 3, "silu": 4, "mish": 5}
 _DT = {torch.bfloat16: 0, torch.float32: 1}
+
+
+# Tile selection of the GEMMs that leave it to the library (force_cfg = 0): inside `shared_tail()` they are issued with force_cfg = -1 -
+# "this launch runs beside another stream's GEMMs" (include/internnav_amd.h) - so the tile cost model does not charge the under-filled last
+# round that the other stream's workgroups fill. Every tile shape accumulates K in the same order, so the choice changes no bit of the
+# result; that also makes the process-wide switch harmless if a launch of another host thread picks it up.
+_AUTO_CFG = 0
+
+
+@contextlib.contextmanager
+def shared_tail():
+    global _AUTO_CFG
+    keep, _AUTO_CFG = _AUTO_CFG, -1
+    try:
+        yield
+    finally:
+        _AUTO_CFG = keep
 
 
 def _stream() -> int:
@@ -88,7 +106,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.out_dtype = _DT[out.dtype]
     a.glu = 1 if glu else 0
     a.rowscale_div = rowscale_div
-    a.force_cfg = force_cfg
+    a.force_cfg = force_cfg if force_cfg else _AUTO_CFG
     a.group_m = group_m
     if prenorm is not None:
         gamma, eps = prenorm
