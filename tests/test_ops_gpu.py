@@ -393,6 +393,23 @@ def test_gemm_glds_grouped_tile_order(ops, cfg, group_m):
     _close(out, x.float() @ w.float().t(), rtol=2e-3, atol=5e-3)
 
 
+@pytest.mark.parametrize("M,N,K,glu", [(2760, 3584, 3584, False), (3680, 4608, 3584, False), (2760, 4096, 3584, True), (9408, 1280, 3456, False), (7, 4608, 3584, False)])
+def test_gemm_shared_tail_selection_is_bit_equal(ops, M, N, K, glu):
+    """ops.shared_tail() (force_cfg = -1: the launch runs beside another stream's GEMMs, tile quantisation not charged) only changes WHICH
+    tile kernel runs - 256 x 256 where the single-stream cost model takes 192 x 256 (e.g. 2760 x 3584 x 3584) - and every tile shape
+    accumulates K in the same order: the result equals the plain auto selection bit for bit (also on the weight-streaming M <= 64 path,
+    which ignores the mode). Same comparison at the full prefill shapes on the device: profiles/r03v_native_gemm_sweep.log."""
+    g = torch.Generator().manual_seed(M + N)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    res = None if glu else torch.randn(M, N, generator=g).to(_dev())
+    kw = dict(act="silu", glu=True) if glu else dict(residual=res, out_dtype=torch.float32)
+    plain = ops.linear(x, w, **kw)
+    with ops.shared_tail():
+        shared = ops.linear(x, w, **kw)
+    assert torch.equal(plain, shared)
+    assert torch.equal(plain, ops.linear(x, w, force_cfg=-1, **kw))
+
+
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]
 
 
