@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path

@@ -225,6 +225,12 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
             cfg = (c18 < c14 && c18 < c11) ? 18 : (c14 < c11 ? 14 : 11);
             const double best = cfg == 18 ? c18 : cfg == 14 ? c14 : c11;
             if (c21 < best) cfg = 21;
+            // 256 x 256 tile, fp32-residual epilogue, short K loop (the vision blocks' proj / down projections; K = 3584 is neutral): the
+            // lock-step kernel with SIXTEEN waves (wave tile 64 x 64, cfg 33) instead of the 8-wave ping-pong. Such a tile spends as long
+            // reading and writing its 512 KB of fp32 as in its K loop, and twice the waves keep twice the epilogue loads in flight:
+            // vision chain of the two prefill halves 26.9 vs 28.1-28.3 ms; decoder chain and the d = 384 heads unchanged
+            // (profiles/r03z_native_chain_16wave.log). Same tile geometry and K order: bit-equal (r03z_native_gemm_16wave.log).
+            if (cfg == 18 && p.R && p.out_dtype == INA_DT_F32 && p.K <= 4096) cfg = 33;
         }
     }
     ina_prof_set_sub(cfg);
@@ -237,7 +243,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

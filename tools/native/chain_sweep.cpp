@@ -268,6 +268,54 @@ int main(int argc, char** argv) {
     const std::string mode = argc > 3 ? argv[3] : "part";          // part = partitions over 1 .. 4 streams, coord = coordinate sweep of the tile policy
 
     const int H = 3584, I = 18944, QKV = 4608, VH = 1280, VI = 3456;
+    if (mode == "spec") {
+        // tools/native/chain_sweep <lib> <spec file> spec: one line per measurement, `chain rowsA rowsB cfg_qkv cfg_o cfg_gateup cfg_down [reps]`
+        // (chain = llm | vit | s1; rowsB = 0: one stream; two streams otherwise); `#` lines are echoed
+        const int SD = 384, SF = 1024;
+        ChainDef defs[3] = {
+            {"llm", 28, {{"qkv", QKV, H, 0, 0, INA_ACT_NONE_C, 0, 1}, {"o+res", H, H, 0, 1, INA_ACT_NONE_C, 0, 2},
+                         {"gate|up", 2 * I, H, 1, 0, INA_ACT_SILU_C, 0, 3}, {"down+res", H, I, 0, 1, INA_ACT_NONE_C, 3, 2}}, {H, QKV, H, I}, {2, 2, 4, 2}},
+            {"vit", 32, {{"qkv", 3 * VH, VH, 0, 0, INA_ACT_NONE_C, 0, 1}, {"proj+res", VH, VH, 0, 1, INA_ACT_NONE_C, 0, 2},
+                         {"gate|up", 2 * VI, VH, 1, 0, INA_ACT_SILU_C, 0, 3}, {"down+res", VH, VI, 0, 1, INA_ACT_NONE_C, 3, 2}}, {VH, 3 * VH, VH, VI}, {2, 2, 4, 2}},
+            // the four tiled GEMMs of a NextDiT block at d = 384 (fused q|k|v|q2, attention out + f32 residual, SwiGLU gate|up, down + f32 residual), 48 blocks
+            {"s1", 48, {{"qkvq2", 4 * SD, SD, 0, 0, INA_ACT_NONE_C, 0, 1}, {"out+res", SD, SD, 0, 1, INA_ACT_NONE_C, 0, 2},
+                        {"gate|up", 2 * SF, SD, 1, 0, INA_ACT_SILU_C, 0, 3}, {"down+res", SD, SF, 0, 1, INA_ACT_NONE_C, 3, 2}}, {SD, 4 * SD, SD, SF}, {2, 2, 4, 2}}};
+        void* Wt[3][4];
+        for (int d = 0; d < 3; ++d)
+            for (int gi = 0; gi < 4; ++gi) Wt[d][gi] = dalloc((size_t)defs[d].g[gi].N * defs[d].g[gi].K * 2, 40 + 4 * d + gi, 0.03f);
+        FILE* f = fopen(which.c_str(), "r");
+        if (!f) { fprintf(stderr, "cannot open %s\n", which.c_str()); return 1; }
+        char line[512];
+        Inst ia{0, {}}, ib{0, {}};
+        int cur = -1;
+        while (fgets(line, sizeof line, f)) {
+            if (line[0] == '#' || line[0] == '\n') { if (line[0] == '#') fputs(line, stdout); continue; }
+            char cn[16];
+            int ra, rb, c0, c1, c2, c3, reps = 3;
+            if (sscanf(line, "%15s %d %d %d %d %d %d %d", cn, &ra, &rb, &c0, &c1, &c2, &c3, &reps) < 7) continue;
+            const int d = !strcmp(cn, "llm") ? 0 : !strcmp(cn, "vit") ? 1 : 2;
+            if (d != cur || ia.M != ra || ib.M != rb) {
+                if (ia.M) free_inst(ia);
+                if (ib.M) free_inst(ib);
+                ia = make_inst(defs[d], ra, 100);
+                ib.M = 0;
+                if (rb) ib = make_inst(defs[d], rb, 200);
+                cur = d;
+            }
+            const Policy p{{c0, c1, c2, c3}, {0, 0, 0, 0}};
+            double flop_row = 0;
+            for (int gi = 0; gi < 4; ++gi) flop_row += 2.0 * defs[d].g[gi].N * defs[d].g[gi].K;
+            flop_row *= defs[d].layers;
+            double mn, med;
+            if (rb) time_two_streams(defs[d], ia, ib, Wt[d], p, reps, mn, med);
+            else time_one_stream(defs[d], ia, Wt[d], p, reps, mn, med);
+            printf("%-4s rows %6d%s  cfg %2d %2d %2d %2d  min %8.3f ms  median %8.3f ms  %7.1f TF/s\n", cn, ra + rb, rb ? " (2 streams)" : " (1 stream) ", c0, c1, c2, c3, mn, med,
+                   flop_row * (ra + rb) / (mn * 1e-3) * 1e-12);
+            fflush(stdout);
+        }
+        printf("# done\n");
+        return 0;
+    }
     if (which == "all" || which == "llm") {
         // activation buffers: 0 x bf16 [M,H], 1 qkv bf16 [M,4608] (the o projection reads its first H columns' worth as a stand-in), 2 residual f32 [M,H], 3 ff bf16 [M,I]
         ChainDef c{"llm", 28,

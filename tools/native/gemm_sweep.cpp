@@ -112,7 +112,7 @@ static double time_us(const ina_gemm_args& a, int reps) {
 
 int main(int argc, char** argv) {
     const char* lib = argc > 1 ? argv[1] : "internnav_amd/libinternnav_amd.so";
-    const bool quick = argc > 2 && !strcmp(argv[2], "quick");
+    const bool quick = argc > 2 && !strcmp(argv[2], "quick");   // otherwise argv[2] names a spec file (section 0 below)
     void* h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", lib, dlerror()); return 1; }
     g_gemm = (gemm_fn)dlsym(h, "ina_gemm_bf16");
@@ -139,6 +139,54 @@ int main(int argc, char** argv) {
 
     auto tf = [](const Shape& s, double us) { return 2.0 * s.M * s.N * s.K / us * 1e-6; };
     const int reps = quick ? 4 : 10;
+
+    // ---------------------------------------------------------------------------------------------- 0. spec file: free-form sweeps
+    // tools/native/gemm_sweep <lib> <spec file>: one line per shape, `name M N K glu res cfg[,group_m] cfg[,group_m] ...`; the first config
+    // is the reference of the bit comparison (0 = auto); res = 1: f32 output with an f32 residual, else bf16 output; `#` starts a comment
+    if (argc > 2 && !quick) {
+        FILE* f = fopen(argv[2], "r");
+        if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
+        printf("# spec %s: us, TF/s; '=' bit-equal to the first config of the line\n", argv[2]);
+        char line[1024];
+        while (fgets(line, sizeof line, f)) {
+            if (line[0] == '#' || line[0] == '\n') { if (line[0] == '#') fputs(line, stdout); continue; }
+            char name[64];
+            int M, N, K, glu, res, off = 0;
+            if (sscanf(line, "%63s %d %d %d %d %d%n", name, &M, &N, &K, &glu, &res, &off) != 6) continue;
+            const Shape s{name, M, N, K, glu, res, res, glu ? INA_ACT_SILU_C : INA_ACT_NONE_C};
+            const size_t out_bytes = (size_t)M * (glu ? N / 2 : N) * (res ? 4 : 2);
+            if ((size_t)M * K * 2 > A.bytes || (size_t)N * K * 2 > W.bytes || out_bytes > C0.bytes || (res && (size_t)M * N * 4 > R.bytes)) {
+                printf("%-13s too large for the probe's buffers\n", name);
+                continue;
+            }
+            printf("%-13s M %5d N %5d K %5d :", name, M, N, K);
+            const char* q = line + off;
+            int cfg, gm, adv, first = 1;
+            while (sscanf(q, " %d%n", &cfg, &adv) == 1) {
+                q += adv;
+                gm = 0;
+                if (*q == ',') { ++q; sscanf(q, "%d%n", &gm, &adv); q += adv; }
+                void* out = first ? C0.p : C1.p;
+                ina_gemm_args a = make(s, A.p, W.p, out, R.p, cfg, gm);
+                const double us = time_us(a, reps);
+                unsigned long long d = 0;
+                if (!first) {
+                    HIP_OK(hipMemsetAsync(cnt.p, 0, 8, 0));
+                    hipLaunchKernelGGL(count_diff, dim3(2048), dim3(256), 0, 0, (const uint32_t*)C0.p, (const uint32_t*)C1.p, out_bytes / 4,
+                                       (unsigned long long*)cnt.p);
+                    HIP_OK(hipMemcpy(&d, cnt.p, 8, hipMemcpyDeviceToHost));
+                }
+                printf("  cfg%d/g%d %7.1f us %6.1f TF%s", cfg, gm, us, tf(s, us), first ? "" : (d ? " DIFF" : " ="));
+                if (d) printf("(%llu)", d);
+                first = 0;
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+        fclose(f);
+        printf("# done\n");
+        return 0;
+    }
 
     // ---------------------------------------------------------------------------------------------- 1. isolated launches
     printf("# isolated launches: us, TF/s (algorithmic), bit-equal to the auto config (differing 32-bit words)\n");
