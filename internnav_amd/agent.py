@@ -206,8 +206,7 @@ class InternVLAN1Agent:
         # camera-size look-down frame) are right-padded to the longest of the chunk - causal attention makes the padding invisible to
         # the real tokens (QwenVLEngine.prefill seq_lens). Sorted by length so a chunk pads as little as possible.
         built.sort(key=lambda it: it[2]["input_ids"].shape[1])
-        groups = {0: built} if built else {}
-        for items_all in groups.values():
+        for items_all in ([built] if built else []):
             model = items_all[0][0].policy.model
             cap = getattr(getattr(model, "qwen", None), "B_max", None) or len(items_all)
             singles = []
