@@ -89,6 +89,12 @@ typedef struct ina_gemm_args {
     int32_t a_dtype;        /* dtype of A when norm_gamma is set: INA_BF16 | INA_F32 */
 } ina_gemm_args;
 int ina_gemm_bf16(const ina_gemm_args* args, void* stream);
+/* Which kernel ina_gemm_bf16 would run for these arguments - validation and tile selection only, nothing is launched and no GPU is needed
+ * (the selection is host arithmetic on M / N / K, the epilogue and force_cfg): *kernel = 1-8 register-staged tiles, 11-29 / 33 LDS-DMA tiles
+ * (18 = 256x256 ping-pong, 21 = 192x256 ping-pong, 22 / 26 / 27 single-buffer tiles of the d = 384 heads, 33 = 256x256 with 16 waves),
+ * 30 = weight streaming with the fused input RMSNorm, 31 / 32 = weight streaming (M <= 64). Returns non-zero (and sets ina_last_error)
+ * exactly when ina_gemm_bf16 would reject the arguments. */
+int ina_gemm_select(const ina_gemm_args* args, int* kernel);
 
 /* ---- flash-style attention forward (bf16, fp32 softmax): replaces flash_attn / SDPA / nn.MultiheadAttention
  *      (reference call sites: dinov2_layers/attention.py:49-62, navdp.py:57-66,192, navdp_backbone.py:77,148,

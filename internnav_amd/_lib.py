@@ -278,6 +278,7 @@ SYMBOLS = {
     "ina_last_error": (C.c_char_p, []),
     "ina_device_check": (C.c_int, [C.c_char_p, C.c_int]),
     "ina_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_void_p]),
+    "ina_gemm_select": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int)]),
     "ina_attention_bf16": (C.c_int, [C.POINTER(AttnArgs), c_void_p]),
     "ina_norm_bf16": (C.c_int, [C.POINTER(NormArgs), c_void_p]),
     "ina_patchify": (C.c_int, [C.POINTER(PatchifyArgs), c_void_p]),

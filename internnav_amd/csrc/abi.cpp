@@ -158,6 +158,12 @@ int ina_gemm_bf16(const ina_gemm_args* args, void* stream) {
     return ina_launch_gemm(*args, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ina_gemm_select(const ina_gemm_args* args, int* kernel) {
+    INA_REQUIRE(args != nullptr && kernel != nullptr, "gemm_select: null argument");
+    GemmArgs p;
+    return ina_plan_gemm(*args, p, *kernel);
+}
+
 int ina_attention_bf16(const ina_attn_args* args, void* stream) {
     INA_REQUIRE(args != nullptr, "attention: null args");
     return ina_launch_attention(*args, reinterpret_cast<hipStream_t>(stream));

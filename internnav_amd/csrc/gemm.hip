@@ -166,8 +166,12 @@ int launch_cfg(const GemmArgs& p, hipStream_t stream) {
 
 }  // namespace
 
-int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
-    GemmArgs p = p_in;
+// Validation + kernel selection of one GEMM call, without launching anything (host arithmetic only: also reachable as ina_gemm_select so
+// that the selection can be inspected / tested without a GPU). `kernel`: 1-8 register-staged tiles (gemm_bf16_nt_kernel), 11-29 / 33
+// LDS-DMA tiles (gemm_glds.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 31 = split-K weight streaming, 32 = fused
+// weight streaming (gemm_skinny.hip).
+int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
+    p = p_in;
     if (p.rowscale_div <= 0) p.rowscale_div = 1;
     if (p.batch <= 0) p.batch = 1;
     INA_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -184,12 +188,15 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
                     "gemm: the fused input RMSNorm is built for the decode passes (M <= 16 rows, K <= 4096, one batch): M=%d K=%d N=%d batch=%d", p.M, p.K, p.N, p.batch);
         INA_REQUIRE(p.a_dtype == INA_DT_BF16 || p.a_dtype == INA_DT_F32, "gemm: a_dtype must be bf16 or f32 with norm_gamma");
         INA_REQUIRE(((uintptr_t)p.norm_gamma % 16) == 0 && (p.lda % (p.a_dtype == INA_DT_F32 ? 4 : 8)) == 0, "gemm(prenorm): misaligned gamma / lda");
-        return ina_launch_gemm_skinny_prenorm(p, stream);
+        kernel = 30;
+        return 0;
     }
-    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) return ina_launch_gemm_skinny_fused(p, stream);
+    INA_REQUIRE(p.force_cfg != 30, "gemm: kernel 30 (fused input RMSNorm) is selected by norm_gamma, not by force_cfg");
+    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) { kernel = 32; return 0; }
     if (p.force_cfg == 31 || p.force_cfg == 32) {
         INA_REQUIRE(p.M <= 64 && p.batch == 1, "gemm: skinny kernels need M <= 64, batch 1 (M=%d)", p.M);
-        return p.force_cfg == 31 ? ina_launch_gemm_skinny(p, stream) : ina_launch_gemm_skinny_fused(p, stream);
+        kernel = p.force_cfg;
+        return 0;
     }
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     int cfg = p.force_cfg;
@@ -233,6 +240,17 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
             if (cfg == 18 && p.R && p.out_dtype == INA_DT_F32 && p.K <= 4096) cfg = 33;
         }
     }
+    kernel = cfg;
+    return 0;
+}
+
+int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
+    GemmArgs p;
+    int cfg = 0;
+    if (int rc = ina_plan_gemm(p_in, p, cfg)) return rc;
+    if (cfg == 30) return ina_launch_gemm_skinny_prenorm(p, stream);
+    if (cfg == 31) return ina_launch_gemm_skinny(p, stream);
+    if (cfg == 32) return ina_launch_gemm_skinny_fused(p, stream);
     ina_prof_set_sub(cfg);
     switch (cfg) {
         case 1: return launch_cfg<128, 128, 64, 2, 2>(p, stream);
