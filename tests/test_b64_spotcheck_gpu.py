@@ -32,8 +32,18 @@ def test_navdpnet_b64_vs_per_env_oracle(built_lib):
                                                                       inp["x_init"][b:b + 1], inp["step_noise"][:, b:b + 1], cfg, return_all=True)
         e = (fin[b] - o_fin[0]).abs()
         ec = (cr[b] - o_cr[0]).abs()
-        print(f"NavDPNet B=64 env {b}: samples mean|err| {e.mean():.3e} max {e.max():.3e}; critic max|err| {ec.max():.3e} (range {o_cr.abs().max():.2f})")
-        assert e.mean().item() < 1.5e-3 and e.max().item() < 5e-2     # measured 1.09e-3 at B = 64 (8.2e-4 on the B = 2 fixture): 10 DDPM steps with clip
+        # yardstick: the same oracle under bf16 autocast = the precision the reference itself runs at. Ten DDPM steps with clipping amplify
+        # last-bit differences in a few elements: over the 64 envs of this batch bf16 PyTorch's own max|err| against fp32 has a median of
+        # 4.7e-2 and exceeds 5e-2 for 29 of them (profiles/r03E_navdp_bf16_yardstick_cpu.log), env 31 sits at 4.63e-2 - where the engine
+        # measures 4.65e-2. The max bound therefore never asks for more than 1.25x the reference's own precision on the same env.
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            _, _, y_fin, _, _ = o_navdp.navdpnet_pointgoal(sd, inp["goal"][b:b + 1], inp["images"][b:b + 1], inp["depths"][b:b + 1],
+                                                           inp["x_init"][b:b + 1], inp["step_noise"][:, b:b + 1], cfg, return_all=True)
+        ey = (y_fin[0].float() - o_fin[0]).abs()
+        print(f"NavDPNet B=64 env {b}: samples mean|err| {e.mean():.3e} max {e.max():.3e} (bf16 PyTorch: mean {ey.mean():.3e} max {ey.max():.3e}); "
+              f"critic max|err| {ec.max():.3e} (range {o_cr.abs().max():.2f})")
+        assert e.mean().item() < 1.5e-3     # measured 1.09e-3 at B = 64 (8.2e-4 on the B = 2 fixture): 10 DDPM steps with clip
+        assert e.max().item() < max(5e-2, 1.25 * ey.max().item())
         assert ec.max().item() < 5e-2 * max(1.0, o_cr.abs().max().item())
         order = o_cr[0].argsort()
         if (o_cr[0][order[8]] - o_cr[0][order[7]]) > 2 * ec.max():
