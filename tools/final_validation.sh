@@ -22,7 +22,16 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt_$w -o kt -- pyt
 python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/kt_$w/*.db | head -1) 40 > $R/gpurun_out/${TAG}_${w}_3calls_kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/kt_$w
 done
-# (PMC passes: tools/pmc_s2_traffic.sh / profiles/r03h_pmc_* - the GEMM kernels are unchanged since)
+# torch-free native probes over the C-ABI (seconds each; tools/native/build.sh builds them next to their sources before the snapshot is sent)
+cd $R
+if [ -x tools/native/chain_sweep ]; then
+  timeout 60 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_gemm_sweep.log 2>&1
+  timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so all part > $R/gpurun_out/${TAG}_native_chain_partitions.log 2>&1
+  timeout 20 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
+  timeout 20 tools/native/head3_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_head3.log 2>&1
+  timeout 20 tools/native/dit_attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_dit_attn.log 2>&1
+fi
+# (PMC passes: tools/pmc_s2_traffic.sh / profiles/r03h_pmc_* - collected before the tile-selection changes of the end of round 3, see profiles/INDEX.md)
 tail -3 $R/gpurun_out/${TAG}_pytest_gpu.log
 tail -2 $R/gpurun_out/${TAG}_smoke.log
 head -c 400 $R/gpurun_out/${TAG}_bench_n1_dual_b64.json; echo
