@@ -30,6 +30,7 @@ if [ -x tools/native/chain_sweep ]; then
   timeout 20 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
   timeout 20 tools/native/head3_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_head3.log 2>&1
   timeout 20 tools/native/dit_attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_dit_attn.log 2>&1
+  timeout 20 tools/native/attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_attn.log 2>&1
 fi
 # (PMC passes: tools/pmc_s2_traffic.sh / profiles/r03h_pmc_* - collected before the tile-selection changes of the end of round 3, see profiles/INDEX.md)
 tail -3 $R/gpurun_out/${TAG}_pytest_gpu.log
