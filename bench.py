@@ -291,7 +291,7 @@ class N1Dual:
                                if self.raw else "pre-processed pixel_values / 224x224 frames resident in HBM"),
                      "s2": f"{self.N_IMG} frames x 784 patches + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
                      "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps", "s2_microbatches_per_10_steps": self.mb}
-        self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence)"
+        self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
         self.vit_cache = bool(getattr(a, "vit_cache", False)) and self.raw
         self.prefix_kv = bool(getattr(a, "prefix_kv", False)) and self.raw
