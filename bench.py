@@ -49,31 +49,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=64, help="environments per GPU")
-    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "navdp_s1", "unet1d_s1", "sft"],
-                    help="n1_dual = the BASELINE metric's configuration (default); navdp_s1 = config #2; unet1d_s1 = the diffusion-policy UNet head; "
-                         "sft = config #5 (the SFT step, bench_sft.py: its own flags pass through)")
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default 64; 7 for --workload s2_only)")
+    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "s2_only", "navdp_s1", "unet1d_s1", "sft"],
+                    help="n1_dual = the BASELINE metric's configuration (default); s2_only = config #3 (System-2 calls/s); navdp_s1 = config #2; "
+                         "unet1d_s1 = the diffusion-policy UNet head; sft = config #5 (the SFT step, bench_sft.py: its own flags pass through)")
+    ap.add_argument("--cadence", choices=["nominal", "reference"], default="nominal",
+                    help="n1_dual: nominal = 1 S2 : 10 S1 per env (the BASELINE metric, default); reference = the agent's own schedule, (1 S2 + 2 S1) per 8 "
+                         "actions and env (SURVEY.md 8d, internvla_n1_agent.py:210-241)")
+    ap.add_argument("--num-history", type=int, default=3,
+                    help="n1_dual / s2_only: history frames per System-2 prompt besides the current frame (3 = the metric's 4 frames; the reference's "
+                         "evaluation harness uses 8, scripts/eval/configs/habitat_dual_system_cfg.py:10-12)")
+    ap.add_argument("--lookdown", action="store_true",
+                    help="n1_dual / s2_only: the look-down turn's prompt - previous turn + answer + the UN-RESIZED 640x480 look-down frame "
+                         "(internvla_n1_policy.py:113-116,140)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
-    ap.add_argument("--overlap-at", choices=["start", "decode"], default="decode",
-                    help="n1_dual: side-stream System-1 starts with the System-2 micro-batch, or only once its prefill is done (decode phase)")
-    ap.add_argument("--priority", choices=["none", "decode", "s1", "main", "side-low"], default="none",
-                    help="n1_dual experiment: high-priority stream for the System-2 decode graph, for the side-stream System-1, for the whole "
-                         "main chain (prefill, decode, System-1 of the System-2 envs), or the lowest priority for the side stream")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     ap.add_argument("--vit-cache", action="store_true",
                     help="n1_dual: per-frame ViT cache variant - the first history frame of every env (frame 0, present in every np.linspace history "
-                         "sample of the reference) comes from the cache, 3 of the 4 frames are encoded; algorithmic FLOPs are accounted accordingly")
+                         "sample of the reference) comes from the cache; algorithmic FLOPs are accounted accordingly")
     ap.add_argument("--prefix-kv", action="store_true",
                     help="n1_dual: prefix-KV reuse variant - the K/V of system prompt + instruction + first history frame (296 of the 920 prompt "
                          "tokens, identical between the System-2 calls of an episode) come from a per-env cache; the call encodes 3 of 4 frames and "
                          "prefills 624 tokens per env. Exact (causal mask); algorithmic FLOPs are accounted accordingly. Reported next to the headline.")
-    ap.add_argument("--s1-early-images", action="store_true",
-                    help="n1_dual experiment: the look-down frames of the System-2 envs are encoded (DINOv2, MemoryEncoder, QFormer) on the side stream "
-                         "at the start of the concurrent phase instead of after the decode chain")
-    ap.add_argument("--s1-split", action="store_true",
-                    help="n1_dual experiment: the side-stream System-1 call (envs keeping their plan) as two half batches on two streams "
-                         "(76.1 -> 69.4 ms alone, the step does not move: 282.2 / 282.3 vs 283.0 - the main chain is the critical one)")
     ap.add_argument("--no-split-prefill", action="store_true",
                     help="n1_dual: System-2 prefill as ONE launch sequence instead of two half micro-batches on two streams")
     ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
@@ -81,10 +79,25 @@ def parse():
                     help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
     ap.add_argument("--no-raw-frames", action="store_true",
                     help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
+    # (round-3 schedule experiments - stream priorities, System-1 started with the prefill, early look-down encoding, a split side-stream
+    #  call - were all measured neutral or negative, profiles/r03d/e/f/u_*; their switches are gone)
     a, rest = ap.parse_known_args()
     if rest and a.workload != "sft":
         ap.error(f"unrecognized arguments: {' '.join(rest)}")
     a.rest = rest
+    if a.envs is None:
+        a.envs = 7 if a.workload == "s2_only" else 64
+    return a
+
+
+def default_args(**kw):
+    """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
+    a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
+                           no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
+                           fuse_rownorm=False, no_raw_frames=False, rest=[])
+    for k, v in kw.items():
+        assert hasattr(a, k), k
+        setattr(a, k, v)
     return a
 
 
@@ -229,31 +242,78 @@ class UNet1DS1:
 
 
 class N1Dual:
-    """InternVLA-N1 full dual system at the nominal cadence (the configuration the BASELINE metric is quoted on)."""
+    """InternVLA-N1 dual system (the configuration the BASELINE metric is quoted on) - cadence and System-2 prompt shape are parameters:
 
-    N_IMG, GRID, N_INSTR, N_DECODE, CADENCE = 4, (1, 28, 28), 64, 8, 10
+      cadence 'nominal'   (default, BASELINE): S2 @ 1 Hz : S1 @ 10 Hz - every env runs System-1 every step and System-2 once per 10 steps
+      cadence 'reference' (internvla_n1_agent.py:210-241 + :331-352): per env and 8 actions ONE System-2 call and TWO System-1
+                          calls (each System-1 plan yields 4 discrete actions, sys2_max_forward_step = 8); the other 6 steps pop queued
+                          actions on the host (step_no_infer). Per bench step: System-2 for 8 envs, System-1 for those 8 + the 8 envs half a
+                          period away, 64 actions out.
+      cadence 's2_only'   (BASELINE config #3): every env of the (small) batch runs System-2 every step, no System-1; unit = System-2 calls/s
+
+      --num-history H   H history frames + the current frame per System-2 prompt (default 3 -> the metric's 4 frames; the reference's
+                        evaluation harness runs 8, scripts/eval/configs/habitat_dual_system_cfg.py:10-12)
+      --lookdown        the look-down turn: the prompt of the previous turn + its answer + the UN-RESIZED 640x480 look-down frame
+                        (internvla_n1_policy.py:113-116,140: 46 x 34 patches = 391 tokens) - the longest prompt the harness produces
+    """
+
+    GRID, N_INSTR, N_DECODE = (1, 28, 28), 64, 8
 
     def __init__(self, a, dev, rank):
         from internnav_amd import flops, synthetic
         from internnav_amd.policy import InternVLAN1ForCausalLM, traj_to_actions
+        from internnav_amd.preprocess import smart_resize
 
         self.traj_to_actions = traj_to_actions
         self.a = a
+        self.cadence = "s2_only" if a.workload == "s2_only" else a.cadence
         self.dev, self.B = dev, a.envs
         B = self.B
-        self.name = f"n1_dual_b{B}"
+        self.N_IMG = a.num_history + 1
+        self.lookdown = bool(a.lookdown)
+        tag = ("" if self.cadence == "nominal" else f"_{self.cadence}") + ("" if a.num_history == 3 else f"_h{a.num_history}") + ("_lookdown" if self.lookdown else "")
+        self.name = (f"n1_s2_only_b{B}" if self.cadence == "s2_only" else f"n1_dual_b{B}") + tag.replace("_s2_only", "")
         qcfg, scfg = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_CFG
         self.qcfg, self.scfg = qcfg, scfg
         per = self.GRID[1] * self.GRID[2]
-        # prompt layout (HF chat template shape): 34 template tokens | 64 instruction tokens | 4 x (<vs> 196 x <img> <ve>) | 30 tail tokens
-        self.S = 34 + self.N_INSTR + self.N_IMG * (per // 4 + 2) + 30
-        self.mb = [B // self.CADENCE + (1 if j < B % self.CADENCE else 0) for j in range(self.CADENCE)]   # micro-batch sizes, sum = B
+        hb, wb = smart_resize(480, 640)                                   # the look-down frame enters the HF processor at camera size
+        self.LD_GRID = (1, hb // 14, wb // 14)
+        per_ld = self.LD_GRID[1] * self.LD_GRID[2]
+        self.grids_seq = [self.GRID] * self.N_IMG + ([self.LD_GRID] if self.lookdown else [])
+        self.pv_rows_seq = self.N_IMG * per + (per_ld if self.lookdown else 0)
+        # prompt layout (HF chat template shape): 34 template tokens | 64 instruction tokens | N x (<vs> 196 x <img> <ve>) | 30 tail tokens
+        # look-down turn: + 16 tokens (the previous answer and the next turn's template) | <vs> 391 x <img> <ve> | 8 tail tokens
+        self.S = 34 + self.N_INSTR + self.N_IMG * (per // 4 + 2) + 30 + ((16 + per_ld // 4 + 2 + 8) if self.lookdown else 0)
+        # ---- schedule: per step j of the period, the envs of the System-2 micro-batch (contiguous) and the envs whose System-1 call does
+        # not depend on it (side stream)
+        if self.cadence == "nominal":
+            self.PERIOD = 10
+        elif self.cadence == "reference":
+            self.PERIOD = 8
+        else:
+            self.PERIOD = 1
+        P_ = self.PERIOD
+        self.mb = [B // P_ + (1 if j < B % P_ else 0) for j in range(P_)]   # micro-batch sizes, sum = B
         self.mb_start = np.concatenate([[0], np.cumsum(self.mb)])
+        assert min(self.mb) >= 1, f"--envs {B} is smaller than the cadence period {P_}"
         mmax = max(self.mb)
+
+        def envs_of(j):
+            return list(range(int(self.mb_start[j]), int(self.mb_start[j]) + self.mb[j]))
+        if self.cadence == "nominal":
+            side = [[e for e in range(B) if e not in set(envs_of(j))] for j in range(P_)]
+        elif self.cadence == "reference":
+            side = [envs_of((j + P_ // 2) % P_) for j in range(P_)]
+        else:
+            side = [[] for _ in range(P_)]
+        self.idxA_host = side
+        self.with_s1 = self.cadence != "s2_only"
+        s1_max = max(len(side[j]) + self.mb[j] for j in range(P_)) if self.with_s1 else 1     # (the single-stream schedule runs both groups in one call)
         spec = synthetic.n1_full_spec(qcfg, "nextdit_async")
         weights = synthetic.LazyDeviceWeights(spec, dev, seed=0)
-        self.model = InternVLAN1ForCausalLM(weights, qcfg, "nextdit_async", scfg, device=dev, max_envs=B, max_seq_len=1024,
-                                            max_patches=mmax * self.N_IMG * per, max_s2_seqs=mmax)
+        S_max = (self.S + self.N_DECODE + 8 + 63) // 64 * 64
+        self.model = InternVLAN1ForCausalLM(weights, qcfg, "nextdit_async", scfg, device=dev, max_envs=(B if self.cadence == "nominal" else s1_max),
+                                            max_seq_len=max(1024, S_max), max_patches=mmax * self.pv_rows_seq, max_s2_seqs=mmax)
         if getattr(a, "fuse_rownorm", False):
             self.model.s1.fuse_rownorm = True
         if getattr(a, "no_fuse_decode_norm", False):
@@ -269,39 +329,54 @@ class N1Dual:
             ids[:, o + 1:o + 1 + per // 4] = qcfg["image_token_id"]
             ids[:, o + 1 + per // 4] = qcfg["vision_end_id"]
             o += per // 4 + 2
+        if self.lookdown:
+            o += 30 + 16
+            ids[:, o] = qcfg["vision_start_id"]
+            ids[:, o + 1:o + 1 + per_ld // 4] = qcfg["image_token_id"]
+            ids[:, o + 1 + per_ld // 4] = qcfg["vision_end_id"]
         self.ids = ids
-        self.pixel_values = torch.randn(B, self.N_IMG * per, 1176, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
-        self.grid = torch.tensor([list(self.GRID)] * self.N_IMG)
+        self.grid = torch.tensor([list(gr) for gr in self.grids_seq])
         self.images_dp = torch.rand(B, 2, 224, 224, 3, device=dev, generator=g).to(torch.bfloat16)
-        # raw camera frames (the metric's input: 4 x 640x480 RGB per env) resident in HBM; every step runs them through the
+        # raw camera frames (the metric's input: N x 640x480 RGB per env) resident in HBM; every step runs them through the
         # bit-exact device pre-processor (PIL bicubic 640x480 -> 384x384 -> 392x392, rescale / normalise / patchify for the System-2
-        # micro-batch; 640x480 -> 224x224, / 255 for the System-1 look-down pair = frames 0 and 3), one batched launch per stage
+        # micro-batch; 640x480 -> 224x224, / 255 for the System-1 look-down pair = frames 0 and N-1), one batched launch per stage
         self.raw = not getattr(a, "no_raw_frames", False)
+        assert self.raw or not self.lookdown, "--lookdown needs the raw-frame path (the look-down frame is pre-processed at camera size)"
         if self.raw:
             from internnav_amd.preprocess import FramePreprocessor
 
             self.pre = FramePreprocessor(dev, resize_w=384, resize_h=384)
-            self.frames_u8 = torch.randint(0, 256, (B, self.N_IMG, 480, 640, 3), device=dev, generator=g, dtype=torch.uint8)
+            self.frames_u8 = torch.randint(0, 256, (B, self.N_IMG + (1 if self.lookdown else 0), 480, 640, 3), device=dev, generator=g, dtype=torch.uint8)
             self.s1_sel = torch.tensor([0, self.N_IMG - 1], device=dev)
-            self.s1_raw = torch.empty(B, 2, 480, 640, 3, dtype=torch.uint8, device=dev)
+        else:
+            self.pixel_values = torch.randn(B, self.N_IMG * per, 1176, device=dev, generator=g, dtype=torch.float32).to(torch.bfloat16)
         self.latent_table = torch.randn(B, qcfg["n_query"], qcfg["t_hidden"], device=dev, generator=g).to(torch.bfloat16)
         self.x_init = torch.randn(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev, generator=g)
-        self.desc = {"policy": "InternVLA-N1 dual system (Qwen2.5-VL-7B S2 + NextDiT-async S1), nominal cadence 1 S2 : 10 S1",
+        self.desc = {"policy": "InternVLA-N1 dual system (Qwen2.5-VL-7B S2 + NextDiT-async S1)",
+                     "cadence": {"nominal": "nominal: 1 S2 : 10 S1 per env (S2 @ 1 Hz, S1 @ 10 Hz)",
+                                 "reference": "reference agent: (1 S2 + 2 S1) per 8 actions and env (internvla_n1_agent.py:210-241,331-352); 6 of 8 steps pop queued actions",
+                                 "s2_only": "System-2 only (BASELINE config #3): every env runs one System-2 call per step; value = System-2 calls/s"}[self.cadence],
                      "input": ("raw uint8 640x480 RGB frames resident in HBM, device pre-processing (PIL-exact resize, HF rescale/normalise/patchify) inside the timed step"
                                if self.raw else "pre-processed pixel_values / 224x224 frames resident in HBM"),
-                     "s2": f"{self.N_IMG} frames x 784 patches + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
-                     "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps", "s2_microbatches_per_10_steps": self.mb}
+                     "s2": f"{self.N_IMG} frames x 784 patches" + (f" + the un-resized look-down frame ({per_ld} patches)" if self.lookdown else "") +
+                           f" + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
+                     "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps" if self.with_s1 else "none",
+                     "s2_microbatches_per_period": self.mb, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
         self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
         self.vit_cache = bool(getattr(a, "vit_cache", False)) and self.raw
         self.prefix_kv = bool(getattr(a, "prefix_kv", False)) and self.raw
         assert not (self.vit_cache and self.prefix_kv), "--prefix-kv already covers frame 0 (its tokens are cached K/V): use one of the two"
+        assert not ((self.vit_cache or self.prefix_kv) and self.lookdown), "the exact-reuse variants are benchmarked on the plain prompt shape"
         self.prefix_len = (34 + self.N_INSTR + per // 4 + 2) if self.prefix_kv else 0     # template + instruction + <vs> frame 0 <ve>
         n_fresh = self.N_IMG - 1 if (self.vit_cache or self.prefix_kv) else self.N_IMG
-        f2 = flops.s2_call_flops(self.S, [self.GRID] * n_fresh, self.N_DECODE, qcfg, prefix_len=self.prefix_len)   # cached frames / tokens cost no FLOPs
+        fresh_grids = [self.GRID] * n_fresh + ([self.LD_GRID] if self.lookdown else [])
+        self.pv_rows_fresh = n_fresh * per + (per_ld if self.lookdown else 0)
+        f2 = flops.s2_call_flops(self.S, fresh_grids, self.N_DECODE, qcfg, prefix_len=self.prefix_len)   # cached frames / tokens cost no FLOPs
         f1 = flops.nextdit_s1_flops_per_env(scfg)
-        self.f_alg = f1["total"] + f2["total"] / self.CADENCE
+        self.f_alg = {"nominal": f1["total"] + f2["total"] / 10, "reference": (f2["total"] + 2 * f1["total"]) / 8, "s2_only": f2["total"]}[self.cadence]
         self.f_parts = {"s1_per_env": f1["total"], "s2_per_call": f2["total"]}
+        self.unit = "System-2 calls/s" if self.cadence == "s2_only" else "policy steps/s"
         # static S2 buffers per micro-batch size
         q = self.model.qwen
         self.s2 = {}
@@ -313,7 +388,7 @@ class N1Dual:
                 pv0, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:hi, 0].contiguous())
                 emb, inv = q.vision(pv0, [self.GRID] * (hi - lo))
                 self.emb0[lo:hi].copy_(emb[torch.from_numpy(inv).to(dev).long()].view(hi - lo, per // 4, -1))
-            self.desc["vit_cache"] = "frame 0 of every env from the per-frame ViT cache (3 of 4 frames encoded per System-2 call)"
+            self.desc["vit_cache"] = f"frame 0 of every env from the per-frame ViT cache ({n_fresh} of {self.N_IMG} frames encoded per System-2 call)"
         if self.prefix_kv:
             # prefix K/V of every env, computed once by a prefill of the prefix alone (they would have been left behind by the env's
             # previous System-2 call): bf16 [B, layers, prefix_len, 1024] = 17 MB per env
@@ -326,94 +401,91 @@ class N1Dual:
                 for k in range(hi - lo):
                     self.kv_prefix[lo + k].copy_(q.export_prefix_kv(k, pl))
             self.desc["prefix_kv"] = (f"K/V of the first {pl} prompt tokens (template + instruction + frame 0) of every env from the prefix cache: "
-                                      f"{self.S - pl} tokens prefilled and 3 of 4 frames encoded per System-2 call")
+                                      f"{self.S - pl} tokens prefilled and {n_fresh} of {self.N_IMG} frames encoded per System-2 call")
         for m in sorted(set(self.mb)):
             cache0 = torch.empty(m, per // 4, qcfg["t_hidden"], dtype=torch.bfloat16, device=dev) if self.vit_cache else None
             cached = [c for k in range(m) for c in ([cache0[k]] + [None] * (self.N_IMG - 1))] if self.vit_cache else None
             P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True, cached_embeds=cached,
                        prefix_len=self.prefix_len)
-            self.s2[m] = dict(P=P, cache0=cache0, pv=torch.empty(m * n_fresh * per, 1176, dtype=torch.bfloat16, device=dev),
+            self.s2[m] = dict(P=P, cache0=cache0, pv=torch.empty(m * self.pv_rows_fresh, 1176, dtype=torch.bfloat16, device=dev),
                               toks=torch.zeros(m, self.N_DECODE, dtype=torch.int32, device=dev),
                               lat=torch.zeros(m, qcfg["n_query"], qcfg["t_hidden"], dtype=torch.bfloat16, device=dev), graph=None)
         self.s1_graph = None
         self.action_shape = (B, 4)
         self.actions = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+        self.queue = [[] for _ in range(B)]           # reference cadence: the actions of an env's current System-1 plan not yet executed
         # Two-stream schedule (same results, different order): System-1 of the envs that do NOT run System-2 this step is independent
-        # of it and is launched on a side stream, concurrently with the System-2 micro-batch (whose decode passes are launch-latency /
-        # HBM bound and leave the MFMA pipes idle); System-1 of the 6-7 System-2 envs follows System-2 on the main stream, on a second
-        # small engine instance (own workspace).
-        self.overlap = not getattr(a, "no_overlap", False) and not a.no_graph
+        # of it and is launched on a side stream, concurrently with the decode + latent-query passes of the System-2 micro-batch (chains of
+        # short weight-streaming kernels that leave the MFMA pipes idle); System-1 of the System-2 envs follows System-2 on the main
+        # stream, on a second small engine instance (own workspace).
+        self.overlap = self.with_s1 and not getattr(a, "no_overlap", False) and not a.no_graph
         if self.overlap:
             from internnav_amd.nextdit import NextDiTSystem1
             from internnav_amd.policy import _Prefixed
 
             self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
             self.side = torch.cuda.Stream(device=dev)
-            nA = B - min(self.mb)
-            # experiment (--s1-split): the side-stream call as two half batches on two streams (a second engine instance with its own
-            # buffers): the MFMA-bound GEMM launches of one half run beside the HBM-bound norm / attention launches of the other (57
-            # envs: 76.1 -> 69.4 ms alone, profiles/r03t_two_stream_s1_probe.log) - neutral in the step, where the main chain is critical
-            self.s1_split = bool(getattr(a, "s1_split", False))
-            if self.s1_split:
-                self.s1_half = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=nA // 2, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
-                self.side2 = torch.cuda.Stream(device=dev)
-                self.gA2 = {}
-                self.desc["s1_side_call"] = "two half batches on two streams"
+            nA = max(len(x) for x in side)
             self.latA, self.imgA, self.xA = (torch.empty((nA,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
                                              for t in (self.latent_table, self.images_dp, self.x_init))
             self.latB, self.imgB, self.xB = (torch.empty((mmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
                                              for t in (self.latent_table, self.images_dp, self.x_init))
-            self.idxA = [torch.tensor([e for e in range(B) if not (int(self.mb_start[j]) <= e < int(self.mb_start[j]) + self.mb[j])],
-                                      device=dev) for j in range(self.CADENCE)]
-            self.traj = torch.empty(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
+            self.idxA = [torch.tensor(x, device=dev, dtype=torch.long) for x in side]
+            self.traj = torch.zeros(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
             self.hostA = torch.empty(nA, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
             self.hostB = torch.empty(mmax, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
-            self.idxA_host = [t.tolist() for t in self.idxA]
-            self.gA, self.gB, self.gP, self.gD, self.gBimg = {}, {}, {}, {}, {}
-            self.overlap_at = a.overlap_at
-            self.ev, self.ev2, self.ev3 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            # the decode / latent-query passes are chains of short kernels: on a high-priority stream their workgroups are dispatched
-            # ahead of the queued workgroups of the concurrent System-1 kernels instead of waiting behind them
-            self.hi = torch.cuda.Stream(device=dev, priority=-1) if getattr(a, "priority", "none") == "decode" else None
-            if getattr(a, "priority", "none") == "s1":
-                self.side = torch.cuda.Stream(device=dev, priority=-1)
-            if getattr(a, "priority", "none") == "side-low":
-                try:
-                    low = max(torch.cuda.Stream.priority_range())
-                except Exception:  # noqa: BLE001
-                    low = 1
-                self.side = torch.cuda.Stream(device=dev, priority=low)
-                self.desc["side_stream_priority"] = low
-            self.mainhi = torch.cuda.Stream(device=dev, priority=-1) if getattr(a, "priority", "none") == "main" else None
+            self.gA, self.gB, self.gP, self.gD = {}, {}, {}, {}
+            self.ev = torch.cuda.Event()
 
+    # ---- ingest: raw frames -> engine inputs (inside the timed step)
     def _ingest_s2(self, lo, m, dst):
         """System-2 images of envs [lo, lo + m): raw frames -> pixel_values of the micro-batch (or the round-1 resident tensor)."""
-        if self.prefix_kv:
-            self.model.qwen.import_prefix_kv_batch(self.kv_prefix[lo:lo + m])           # 28 strided device copies, inside the timed step
-            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, 1:].reshape(m * (self.N_IMG - 1), 480, 640, 3))
+        N = self.N_IMG
+        if self.prefix_kv or self.vit_cache:
+            if self.prefix_kv:
+                self.model.qwen.import_prefix_kv_batch(self.kv_prefix[lo:lo + m])       # 28 strided device copies, inside the timed step
+            else:
+                self.s2[m]["cache0"].copy_(self.emb0[lo:lo + m])
+            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, 1:].reshape(m * (N - 1), 480, 640, 3))
             dst.copy_(pv)
-        elif self.vit_cache:
-            self.s2[m]["cache0"].copy_(self.emb0[lo:lo + m])
-            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, 1:].reshape(m * (self.N_IMG - 1), 480, 640, 3))
+        elif self.raw and not self.lookdown:
+            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m].reshape(m * N, 480, 640, 3))
             dst.copy_(pv)
         elif self.raw:
-            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m].reshape(m * self.N_IMG, 480, 640, 3))
-            dst.copy_(pv)
+            # history / current frames through the 384 x 384 resize, the look-down frame at camera size (smart_resize -> 644 x 476): the
+            # rows of one sequence are [N x 784 | 1564] in prompt order
+            per = self.GRID[1] * self.GRID[2]
+            d3 = dst.view(m, self.pv_rows_fresh, 1176)
+            pv, _ = self.pre.qwen_pixel_values(self.frames_u8[lo:lo + m, :N].reshape(m * N, 480, 640, 3))
+            d3[:, : N * per].copy_(pv.view(m, N * per, 1176))
+            x = self.pre.resize(self.frames_u8[lo:lo + m, N].contiguous(), self.LD_GRID[2] * 14, self.LD_GRID[1] * 14)
+            pvl = torch.empty(m * self.LD_GRID[1] * self.LD_GRID[2], 1176, dtype=torch.bfloat16, device=self.dev)
+            from internnav_amd import ops
+
+            ops.qwen_patchify_u8(x, pvl, self.pre.qwen_lut, 14, 2, 2)
+            d3[:, N * per:].copy_(pvl.view(m, -1, 1176))
         else:
             dst.copy_(self.pixel_values[lo:lo + m].reshape(-1, 1176))
 
-    def _ingest_s1(self):
-        """System-1 look-down pairs of every env (goal frame = frame 0, current = last frame) -> images_dp bf16 [B, 2, 224, 224, 3]."""
-        if self.raw:
-            torch.index_select(self.frames_u8, 1, self.s1_sel, out=self.s1_raw)
-            self.images_dp.copy_(self.pre.s1_frames(self.s1_raw.view(self.B * 2, 480, 640, 3)).view(self.B, 2, 224, 224, 3))
+    def _ingest_s1(self, envs=None):
+        """System-1 look-down pairs (goal frame = frame 0, current = last frame) -> images_dp bf16 [B, 2, 224, 224, 3]; envs: LongTensor of
+        the envs that run System-1 this step (None = all)."""
+        if not self.raw:
+            return
+        if envs is None:
+            raw = torch.index_select(self.frames_u8, 1, self.s1_sel)
+            self.images_dp.copy_(self.pre.s1_frames(raw.view(self.B * 2, 480, 640, 3)).view(self.B, 2, 224, 224, 3))
+        else:
+            raw = torch.index_select(torch.index_select(self.frames_u8, 0, envs), 1, self.s1_sel)
+            self.images_dp.index_copy_(0, envs, self.pre.s1_frames(raw.view(-1, 480, 640, 3)).view(-1, 2, 224, 224, 3))
 
     def _s2_call(self, m):
         s = self.s2[m]
         self.model.qwen.run_s2(s["P"], s["pv"], s["toks"], s["lat"])
 
-    def _s1_call(self):
-        return self.model.s1.generate_traj(self.latent_table, self.images_dp, self.x_init)
+    def _s1_call(self, n=None):
+        n = self.B if n is None else n
+        return self.model.s1.generate_traj(self.latent_table[:n], self.images_dp[:n], self.x_init[:n])
 
     def capture(self):
         from internnav_amd import runtime
@@ -421,21 +493,17 @@ class N1Dual:
         for m, s in self.s2.items():
             self._ingest_s2(0, m, s["pv"])
             s["graph"] = runtime.GraphedCall(lambda m=m: self._s2_call(m), {})
-        self.s1_graph = runtime.GraphedCall(lambda: self._s1_call(), {})
+        if self.with_s1 and self.cadence == "nominal":
+            self.s1_graph = runtime.GraphedCall(lambda: self._s1_call(), {})
         if self.overlap:
-            for m in sorted(set(self.mb)):
-                nA = self.B - m
-                n1 = nA - nA // 2 if self.s1_split else nA          # envs [0, n1) on the first engine, [n1, nA) on the second
-                self.gA[nA] = runtime.GraphedCall(lambda n1=n1: self.model.s1.generate_traj(self.latA[:n1], self.imgA[:n1], self.xA[:n1]), {}, workspace_slot=1)
-                if self.s1_split:
-                    self.gA2[nA] = runtime.GraphedCall(lambda n1=n1, nA=nA: self.s1_half.generate_traj(self.latA[n1:nA], self.imgA[n1:nA], self.xA[n1:nA]), {},
-                                                       workspace_slot=4)
-                early = bool(getattr(self.a, "s1_early_images", False))
-                self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m], images_encoded=early), {}, workspace_slot=2)
-                if early:
-                    self.gBimg[m] = runtime.GraphedCall(lambda m=m: self.s1_small.encode_images(m, self.imgB[:m]), {}, workspace_slot=3)
-                if self.overlap_at == "decode":
-                    s, q = self.s2[m], self.model.qwen
+            q = self.model.qwen
+            for j in range(self.PERIOD):
+                m, nA = self.mb[j], len(self.idxA_host[j])
+                if nA not in self.gA:
+                    self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA]), {}, workspace_slot=1)
+                if m not in self.gB:
+                    self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m]), {}, workspace_slot=2)
+                    s = self.s2[m]
                     self.gP[m] = runtime.GraphedCall(lambda s=s: q.run_prefill(s["P"], s["pv"]), {})
 
                     def dec(s=s):
@@ -458,126 +526,117 @@ class N1Dual:
         t2 = self.last_traj.clone()
         self.latent_table.copy_(lat0)
         self.freeze_noise = False
+        self.queue = [[] for _ in range(self.B)]
         return float((t1 - t2).abs().max().item()), float(t1.abs().max().item())
 
-    def _finish(self, traj):
-        self.last_traj = traj
-        t = traj.cpu()                                        # [B, 32, 32, 3] -> host post-processing of the reference (vln_utils)
-        acts = np.zeros((self.B, 4), dtype=np.int32)
-        for b in range(self.B):
-            al = [x for x in self.traj_to_actions(t[b]) if x != 0][:4]
-            acts[b, :len(al)] = al
-        self.actions.copy_(torch.from_numpy(acts))
-        return self.actions
+    # ---- host post-processing (vln_utils.traj_to_actions per env, as internvla_n1_policy.py:205-213) and the action table of the step
+    def _plan(self, traj_host):
+        return [x for x in self.traj_to_actions(traj_host) if x != 0][:4]
+
+    def _emit(self, acts, plans):
+        """plans: {env: action list of its fresh System-1 plan}. nominal cadence: the row of an env = its plan (<= 4 ids, zero padded).
+        reference cadence: an env executes ONE action per step - the head of its fresh plan or the next queued action of its current
+        one (internvla_n1_agent.py:279-300,331-340) - reported in column 0."""
+        if self.cadence == "reference":
+            for b, al in plans.items():
+                self.queue[b] = list(al)
+            for b in range(self.B):
+                acts[b, 0] = self.queue[b].pop(0) if self.queue[b] else 0
+        else:
+            for b, al in plans.items():
+                acts[b, :len(al)] = al
 
     def step_overlapped(self, i):
-        j = i % self.CADENCE
+        j = i % self.PERIOD
         m, lo = self.mb[j], int(self.mb_start[j])
-        nA, idx = self.B - m, self.idxA[j]
+        idx, hostidx = self.idxA[j], self.idxA_host[j]
+        nA = len(hostidx)
         s = self.s2[m]
         main = torch.cuda.current_stream()
         if not getattr(self, "freeze_noise", False):
             self.x_init.normal_(generator=self.g)
-        self._ingest_s1()
-        # side stream: System-1 for the envs keeping their current plan (latents of earlier System-2 calls)
+        if self.cadence == "nominal":
+            self._ingest_s1()
+        else:
+            self._ingest_s1(torch.cat([idx, torch.arange(lo, lo + m, device=self.dev)]))
+        # side stream: System-1 for the envs keeping their current plan's latents (earlier System-2 calls)
         torch.index_select(self.latent_table, 0, idx, out=self.latA[:nA])
         torch.index_select(self.images_dp, 0, idx, out=self.imgA[:nA])
         torch.index_select(self.x_init, 0, idx, out=self.xA[:nA])
-        late = self.overlap_at == "decode"
-        split = self.s1_split
-        n1 = nA - nA // 2 if split else nA
-        trajA2 = None
-        if not late:
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                trajA = self.gA[nA]()
-            if split:
-                self.side2.wait_stream(main)
-                with torch.cuda.stream(self.side2):
-                    trajA2 = self.gA2[nA]()
-        # main stream: System-2 micro-batch, then System-1 for exactly those envs
+        # main stream: System-2 micro-batch (prefill alone: MFMA bound), then decode + latent queries || side-stream System-1
         s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
         self._ingest_s2(lo, m, s["pv"])
-        if late:
-            self.gP[m]()
-            self.ev.record(main)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ev)
-                if self.gBimg:                       # look-down frames of the System-2 envs: encoded ahead of the latents, off the main chain
-                    self.imgB[:m].copy_(self.images_dp[lo:lo + m])
-                    self.gBimg[m]()
-                    self.ev3.record(self.side)
-                trajA = self.gA[nA]()
-            if split:
-                with torch.cuda.stream(self.side2):
-                    self.side2.wait_event(self.ev)
-                    trajA2 = self.gA2[nA]()
-            if self.hi is not None:
-                with torch.cuda.stream(self.hi):
-                    self.hi.wait_event(self.ev)
-                    self.gD[m]()
-                    self.ev2.record(self.hi)
-                main.wait_event(self.ev2)
-            else:
-                self.gD[m]()
-        else:
-            s["graph"]()
+        self.gP[m]()
+        self.ev.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev)
+            trajA = self.gA[nA]()
+        self.gD[m]()
         self.latent_table[lo:lo + m].copy_(s["lat"])
         self.latB[:m].copy_(s["lat"])
-        if self.gBimg and late:
-            main.wait_event(self.ev3)
-        else:
-            self.imgB[:m].copy_(self.images_dp[lo:lo + m])
+        self.imgB[:m].copy_(self.images_dp[lo:lo + m])
         self.xB[:m].copy_(self.x_init[lo:lo + m])
         trajB = self.gB[m]()
-        # host post-processing (vln_utils.traj_to_actions, as the reference does per env) of the side-stream envs runs while the main
-        # stream is still busy with the System-2 decode passes and the System-1 call of the System-2 envs
+        # host post-processing of the side-stream envs runs while the main stream is still busy with the System-2 decode passes and the
+        # System-1 call of the System-2 envs
         acts = np.zeros((self.B, 4), dtype=np.int32)
+        plans = {}
         with torch.cuda.stream(self.side):
-            self.hostA[:n1].copy_(trajA, non_blocking=True)
-        if split:
-            with torch.cuda.stream(self.side2):
-                self.hostA[n1:nA].copy_(trajA2, non_blocking=True)
-            self.side2.synchronize()
+            self.hostA[:nA].copy_(trajA, non_blocking=True)
         self.side.synchronize()
-        for k, b in enumerate(self.idxA_host[j]):
-            al = [x for x in self.traj_to_actions(self.hostA[k]) if x != 0][:4]
-            acts[b, :len(al)] = al
+        for k, b in enumerate(hostidx):
+            plans[b] = self._plan(self.hostA[k])
         self.hostB[:m].copy_(trajB, non_blocking=True)
         main.synchronize()
         for k in range(m):
-            al = [x for x in self.traj_to_actions(self.hostB[k]) if x != 0][:4]
-            acts[lo + k, :len(al)] = al
+            plans[lo + k] = self._plan(self.hostB[k])
+        self._emit(acts, plans)
         if getattr(self, "freeze_noise", False):   # schedule check: keep the assembled trajectories
-            self.traj.index_copy_(0, idx, torch.cat([trajA, trajA2]) if split else trajA)
+            self.traj.index_copy_(0, idx, trajA)
             self.traj[lo:lo + m].copy_(trajB)
-            self.last_traj = self.traj
+            self.last_traj = self.traj.clone()
         self.actions.copy_(torch.from_numpy(acts))
         return self.actions
 
     def step(self, i):
         if self.overlap:
-            if getattr(self, "mainhi", None) is not None:      # experiment: the whole main chain on a high-priority stream
-                self.mainhi.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.mainhi):
-                    out = self.step_overlapped(i)
-                torch.cuda.current_stream().wait_stream(self.mainhi)
-                return out
             return self.step_overlapped(i)
-        j = i % self.CADENCE
+        j = i % self.PERIOD
         m, lo = self.mb[j], int(self.mb_start[j])
         s = self.s2[m]
         # System-2 for the envs whose plan expires this step: gather their prompt / frames, run, scatter the latents back
         s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
         self._ingest_s2(lo, m, s["pv"])
-        self._ingest_s1()
         s["graph"]() if s["graph"] else self._s2_call(m)
         self.latent_table[lo:lo + m].copy_(s["lat"])
-        # System-1 for every env
+        if not self.with_s1:
+            self.actions[lo:lo + m, 0].copy_(s["toks"][:, 0] % 4)           # something that depends on the call's output
+            return self.actions
         if not getattr(self, "freeze_noise", False):
             self.x_init.normal_(generator=self.g)
-        traj = self.s1_graph() if self.s1_graph else self._s1_call()
-        return self._finish(traj)
+        acts = np.zeros((self.B, 4), dtype=np.int32)
+        if self.cadence == "nominal":
+            # System-1 for every env
+            self._ingest_s1()
+            traj = self.s1_graph() if self.s1_graph else self._s1_call()
+            self.last_traj = traj
+            t = traj.cpu()                                        # [B, 32, 32, 3] -> host post-processing of the reference (vln_utils)
+            self._emit(acts, {b: self._plan(t[b]) for b in range(self.B)})
+        else:
+            # reference cadence on one stream: System-1 for the System-2 envs and the envs half a period away, eager gather / scatter
+            envs = self.idxA_host[j] + list(range(lo, lo + m))
+            e = torch.tensor(envs, device=self.dev)
+            self._ingest_s1(e)
+            n = len(envs)
+            traj = self.model.s1.generate_traj(self.latent_table[e].contiguous(), self.images_dp[e].contiguous(), self.x_init[e].contiguous())
+            full = torch.zeros(self.B, *traj.shape[1:], device=self.dev)
+            full[e] = traj
+            self.last_traj = full
+            t = traj.cpu()
+            self._emit(acts, {b: self._plan(t[k]) for k, b in enumerate(envs)})
+            assert n <= self.model.s1.b_max
+        self.actions.copy_(torch.from_numpy(acts))
+        return self.actions
 
     def step_output_for_check(self):
         return self.actions
@@ -585,54 +644,126 @@ class N1Dual:
     def instrumented(self):
         m = max(self.mb)
         q = self.model.qwen
-        keep, q.split_prefill = q.split_prefill, False      # one stream: the per-launch HIP events time kernels that do not overlap
+        # the launches of the timed step (two half micro-batches, tiles selected in the shared-tail mode), issued back to back on ONE stream
+        # so that the per-launch HIP events time kernels that do not overlap (round 3 timed the joint launch sequence instead: a tile
+        # selection the timed step does not run)
+        keep, q.split_serial = q.split_serial, True
         try:
             self._s2_call(m)
         finally:
-            q.split_prefill = keep
-        self._s1_call()
-        return m
+            q.split_serial = keep
+        if self.with_s1:
+            n = self.B if self.cadence == "nominal" else min(self.model.s1.b_max, 2 * m)
+            self._s1_call(n)
+            return f"one System-1 call over {n} envs + one System-2 call over {m} envs"
+        return f"one System-2 call over {m} envs"
 
     def cpu_baseline(self):
-        """reference PyTorch path on the host cores = the CPU oracle, on a bounded sample of one env's policy step: the complete
-        System-1 call, and for System-2 two ViT blocks (1 window + 1 full) on 3136 patches and two decoder layers on S = 920 tokens at
-        the true widths, scaled linearly to the 32 / 28 layers of one call; combined at the 1 : 10 cadence."""
-        from internnav_amd import synthetic
-        from oracle import nextdit as o_nd  # cpu_baseline leg only
-        from oracle import qwen_vl as o_q
+        return n1_cpu_baseline(self.qcfg, self.grids_seq, self.pv_rows_seq, self.ids[:1].cpu().long(), self.N_DECODE, self.cadence, self.with_s1, self.unit)
 
-        cores = min(64, os.cpu_count() or 1)
-        torch.set_num_threads(cores)
+
+def n1_cpu_baseline(qc, grids, pv_rows, ids, n_decode, cadence, with_s1, unit, depth_cycle: int = 2):
+    """the reference PyTorch path on the host cores = the CPU oracle, ONE env, bf16 (weights held in bf16 as the reference loads them,
+    torch.autocast for the activations), at FULL depth and AS THE REFERENCE EXECUTES a pixel-goal System-2 call
+    (internvla_n1_policy.py:163-199): ViT (v_depth blocks) + prefill (t_layers layers, lm_head on every position, internvla_n1.py:220) +
+    n_decode - 1 cached single-token steps of `generate`, then `generate_latents` = a SECOND ViT + prefill over the prompt + answer + the TRAJ
+    tokens (internvla_n1.py:320-347); and the complete System-1 call. System-2 is timed once at full depth (the layer executions cycle
+    through `depth_cycle` distinct sets of layer weights - the timing does not depend on the values, and drawing 15 GB of weights does not
+    fit a bounded sample), System-1 as 1 warm-up + the median of 3 (fp32) / 2 (bf16) runs, the faster counts. The round-3 sample (two
+    blocks + two layers scaled linearly) is kept as a cross-check. qc: the Qwen configuration; grids: the images of one prompt; ids [1, S]."""
+    from internnav_amd import synthetic
+    from oracle import nextdit as o_nd  # cpu_baseline leg only
+    from oracle import qwen_vl as o_q
+
+    cores = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    out = {}
+    t_s1 = 0.0
+    if with_s1:
         sd = synthetic.n1_nextdit_state_dict(0)
         inp = synthetic.n1_nextdit_inputs(1, 0)
-        cfg = dict(self.qcfg, v_depth=2, v_fullatt=(1,), t_layers=2, vocab=8)
-        sdq = synthetic.materialize({k: v for k, v in synthetic.qwen_spec(cfg).items()}, 0)
-        pv = torch.randn(self.N_IMG * 784, 1176)
-        x = torch.randn(1, self.S, self.qcfg["t_hidden"])
-        pos = torch.arange(self.S).view(1, 1, -1).expand(3, 1, -1)
-        legs = {"s1_call": lambda: o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"]),
-                "s2_vit_2_blocks": lambda: o_q.vision_tower(pv, [self.GRID] * self.N_IMG, sdq, cfg),
-                "s2_prefill_2_layers": lambda: o_q.decoder_stack(x, pos, sdq, cfg)}
-        out = {}
-        for dtype in ("fp32", "bf16"):
-            sec = {}
-            for name, fn in legs.items():
-                if dtype == "bf16" and name == "s1_call":
-                    runs = 2           # bounded sample: the bf16 System-1 leg is the slowest on hosts without AMX
-                else:
-                    runs = 3
-                sec[name] = _median_time(fn, runs, autocast=dtype == "bf16")
-            t_vit = sec["s2_vit_2_blocks"] * self.qcfg["v_depth"] / 2
-            t_llm = sec["s2_prefill_2_layers"] * self.qcfg["t_layers"] / 2
-            t_step = sec["s1_call"] + (t_vit + t_llm) / self.CADENCE      # prefill only: decode + latent queries add < 2 % of the FLOPs
-            out[dtype] = {"policy_steps_per_s": round(1.0 / t_step, 4),
-                          "seconds": {"s1_call": round(sec["s1_call"], 2), "s2_vit_scaled": round(t_vit, 2), "s2_prefill_scaled": round(t_llm, 2)}}
-        best = max(out.values(), key=lambda v: v["policy_steps_per_s"])
-        return {"value": best["policy_steps_per_s"], "unit": "policy steps/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
-                "fp32": out["fp32"], "bf16_autocast": out["bf16"],
-                "sample": "1 env: full System-1 call + (2 of 32 ViT blocks on 3136 patches and 2 of 28 decoder layers on S=920, scaled linearly) combined at "
-                          "1 S2 : 10 S1; torch CPU, batch-1 as the reference executes; each leg: 1 warm-up + median of 3 runs (2 for the bf16 System-1 leg); "
-                          "value = the faster of fp32 and bf16-autocast"}
+        s1 = lambda: o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])  # noqa: E731
+        t32, t16 = _median_time(s1, 3), _median_time(s1, 2, autocast=True)
+        t_s1 = min(t32, t16)
+        out["s1_call_s"] = {"fp32": round(t32, 2), "bf16_autocast": round(t16, 2)}
+    # ---- System-2 at full depth: `depth_cycle` sets of layer weights at the true widths, bf16; embed_tokens aliases lm_head (same shape)
+    cfg2 = dict(qc, v_depth=depth_cycle, v_fullatt=(depth_cycle - 1,), t_layers=depth_cycle)
+    spec = dict(synthetic.qwen_spec(cfg2))
+    spec.pop("model.embed_tokens.weight")
+    sd2 = {k: (v.to(torch.bfloat16) if v.dim() >= 2 else v) for k, v in synthetic.materialize(spec, 0).items()}
+    sd2["model.embed_tokens.weight"] = sd2["lm_head.weight"]
+
+    class Cyclic(dict):
+        """state dict of the FULL configuration whose block / layer i reads the weights of block / layer i % depth_cycle"""
+
+        def __missing__(self, key):
+            for pre in ("visual.blocks.", "model.layers."):
+                if key.startswith(pre):
+                    i, rest = key[len(pre):].split(".", 1)
+                    return self[f"{pre}{int(i) % depth_cycle}.{rest}"]
+            raise KeyError(key)
+    sdc = Cyclic(sd2)
+    S = ids.shape[1]
+    pv = torch.randn(pv_rows, 1176).to(torch.bfloat16)
+    t = {}
+
+    def timed(name, fn):
+        t0 = time.time()
+        r = fn()
+        t[name] = time.time() - t0
+        return r
+
+    def s2_as_executed():
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            img = timed("vit", lambda: o_q.vision_tower(pv, grids, sdc, qc))
+            x = o_q.input_embeds(ids, img, sdc, qc)
+            pos, _ = o_q.rope_index(ids, grids, qc["image_token_id"], qc["vision_start_id"])
+            cache = [None] * qc["t_layers"]
+            h = timed("prefill", lambda: o_q.decoder_stack(x, pos, sdc, qc, cache=cache))
+            logits = timed("lm_head_all_positions", lambda: torch.nn.functional.linear(h, sdc["lm_head.weight"]))
+            toks = [logits[:, -1].argmax(-1)]
+            t0 = time.time()
+            for jj in range(n_decode - 1):
+                xe = sdc["model.embed_tokens.weight"][toks[-1]][:, None]
+                h1 = o_q.decoder_stack(xe, pos[:, :, -1:] + 1 + jj, sdc, qc, cache=cache)
+                toks.append(torch.nn.functional.linear(h1, sdc["lm_head.weight"])[:, -1].argmax(-1))
+            t["decode_cached_steps"] = time.time() - t0
+            # generate_latents: the whole forward again on prompt + answer + N_QUERY TRAJ tokens
+            ids2 = torch.cat([ids, torch.stack(toks, 1), torch.full((1, qc["n_query"]), qc["traj_token_id"], dtype=ids.dtype)], 1)
+            img2 = timed("latents_vit", lambda: o_q.vision_tower(pv, grids, sdc, qc))
+            x2 = o_q.input_embeds(ids2, img2, sdc, qc)
+            pos2, _ = o_q.rope_index(ids2, grids, qc["image_token_id"], qc["vision_start_id"])
+            timed("latents_prefill", lambda: o_q.decoder_stack(x2, pos2, sdc, qc))
+
+    # warm-up at `depth_cycle` layers on a short input (pages the kernels in), then ONE timed run at full depth
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        n0 = grids[0][0] * grids[0][1] * grids[0][2]
+        o_q.vision_tower(pv[:n0], grids[:1], sd2, cfg2)
+        o_q.decoder_stack(torch.randn(1, 64, qc["t_hidden"]), torch.arange(64).view(1, 1, -1).expand(3, 1, -1), sd2, cfg2)
+    s2_as_executed()
+    t_exec = sum(t.values())
+    t_once = t["vit"] + t["prefill"] + t["decode_cached_steps"]      # + the latent queries on the cache (4 rows): less than one decode step
+    out["s2_call_s"] = {k: round(v, 2) for k, v in t.items()}
+    out["s2_call_as_executed_s"] = round(t_exec, 2)
+    out["s2_call_without_the_second_forward_s"] = round(t_once, 2)
+    # cross-check: the round-3 sample
+    xs = torch.randn(1, S, qc["t_hidden"])
+    ps = torch.arange(S).view(1, 1, -1).expand(3, 1, -1)
+    c_vit = _median_time(lambda: o_q.vision_tower(pv, grids, sd2, cfg2), 2, autocast=True) * qc["v_depth"] / depth_cycle
+    c_llm = _median_time(lambda: o_q.decoder_stack(xs, ps, sd2, cfg2), 2, autocast=True) * qc["t_layers"] / depth_cycle
+    out["cross_check_scaled_sample_s"] = {"vit": round(c_vit, 2), "prefill": round(c_llm, 2)}
+    if cadence == "nominal":
+        t_step, how = t_s1 + t_exec / 10, "S1 call + 0.1 x S2 call"
+    elif cadence == "reference":
+        t_step, how = (t_exec + 2 * t_s1) / 8, "(S2 call + 2 S1 calls) / 8"
+    else:
+        t_step, how = t_exec, "one S2 call"
+    return dict({"value": round(1.0 / t_step, 4), "unit": unit, "cores": cores, "cpu": _cpu_model(), "kind": "port",
+                 "sample": f"1 env, batch-1 as the reference executes, torch CPU bf16 (bf16 weights + autocast): full-depth System-2 call as executed by the "
+                           f"reference (ViT {qc['v_depth']} blocks + prefill {qc['t_layers']} layers at S={S} + lm_head on all positions + {n_decode - 1} cached decode "
+                           f"steps + generate_latents' second ViT + prefill), timed once after a short warm-up, layer weights cycling through {depth_cycle} sets"
+                           + ("; System-1 call: 1 warm-up + median of 3 (fp32) / 2 (bf16) runs, the faster counts" if with_s1 else "")
+                           + f"; combined as {how}"}, **out)
 
 
 def _median_time(fn, runs: int, autocast: bool = False) -> float:
@@ -698,11 +829,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # own slice of the host cores per rank
-    wl = {"n1_dual": N1Dual, "navdp_s1": NavDPS1, "unet1d_s1": UNet1DS1}[a.workload](a, dev, rank)
+    wl = {"n1_dual": N1Dual, "s2_only": N1Dual, "navdp_s1": NavDPS1, "unet1d_s1": UNet1DS1}[a.workload](a, dev, rank)
     if not a.no_graph:
         wl.capture()
     gathered = torch.empty((world * wl.action_shape[0],) + tuple(wl.action_shape[1:]), device=dev,
-                           dtype=torch.int32 if a.workload == "n1_dual" else torch.float32) if world > 1 else None
+                           dtype=torch.int32 if a.workload in ("n1_dual", "s2_only") else torch.float32) if world > 1 else None
 
     def step(i):
         out = wl.step(i)
@@ -730,7 +861,7 @@ def main():
         # the exchanged actions are really everybody's: this rank's slice equals its own last output, every slice is a valid action table
         mine = wl.step_output_for_check()
         assert torch.equal(gathered[rank * wl.B:(rank + 1) * wl.B], mine), "all_gather: own slice differs from the local actions"
-        if a.workload == "n1_dual":
+        if a.workload in ("n1_dual", "s2_only"):
             assert int(gathered.min()) >= 0 and int(gathered.max()) <= 3, "all_gather: action ids outside {0..3}"
         chk = torch.stack([gathered[r * wl.B:(r + 1) * wl.B].double().sum() for r in range(world)])
         ref = chk.clone()
@@ -759,6 +890,8 @@ def main():
         roofline = {
             "bound": "mfma", "kernel": dom_name,
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            # the same fraction over ALL tiled MFMA GEMM launches of the pass: a launch moving to another tile kernel cannot change it
+            "frac_gemm_class_blend": round(blend / PEAK_BF16_TFLOPS, 4),
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_tflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e12, 4),
             "traffic": pmc_traffic(a.workload),
@@ -766,7 +899,7 @@ def main():
                                  "frac": round(blend / PEAK_BF16_TFLOPS, 4)},
             "per_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["flops"] / 1e12, 3),
                                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in per_kernel.items()},
-            "instrumented_pass": {"what": "one System-1 call over all envs" + (f" + one System-2 call over {extra} envs" if extra else ""),
+            "instrumented_pass": {"what": extra if isinstance(extra, str) else "one engine call over all envs",
                                   "gemm_launches": gm["launches"], "gemm_avg_launch_us": round(gm["ms"] * 1e3 / max(gm["launches"], 1), 2),
                                   "gemm_tflop": round(gm["flops"] / 1e12, 3),
                                   "kernel_class_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
@@ -776,15 +909,14 @@ def main():
                            "achieved_tflops_per_gpu": round(step_tflops, 1), "frac": round(step_tflops / PEAK_BF16_TFLOPS, 4)},
         }
         line = {
-            "metric": "policy steps/sec/node", "value": round(value, 2), "unit": "policy steps/s", "n_gpus": world,
+            "metric": "policy steps/sec/node" if getattr(wl, "unit", "policy steps/s") == "policy steps/s" else "System-2 calls/sec/node",
+            "value": round(value, 2), "unit": getattr(wl, "unit", "policy steps/s"), "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at the true shapes, synthetic camera frames / prompts)",
             "rccl_ranks": world,
             "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}", "calibration": calib,
                             "launch": "eager" if a.no_graph else "hipGraph replay",
-                            "schedule": (("S2 ViT+prefill, then S2 decode+latent queries || S1(non-S2 envs) on a side stream, then S1(S2 envs)"
-                                          if getattr(wl, "overlap_at", "") == "decode" else
-                                          "S1(non-S2 envs) on a side stream || S2 micro-batch, then S1(S2 envs)")
+                            "schedule": ("S2 ViT+prefill, then S2 decode+latent queries || S1(envs keeping their latents) on a side stream, then S1(S2 envs)"
                                          if getattr(wl, "overlap", False) else "single stream"),
                             "device": arch}, **wl.desc),
             "roofline": roofline,

@@ -126,6 +126,11 @@ typedef struct ina_attn_args {
     uint32_t drop_seed;
     uint32_t drop_thresh;
     float drop_scale;
+    int32_t kernel;         /* 0 = automatic (long dense shapes run the 32-rows-per-wave kernel of attention_wide.hip, everything else the
+                             * 16-rows-per-wave kernel), 1 = the 16-rows-per-wave kernel, 2 = the 32-rows-per-wave kernel (an error outside its
+                             * contract: d 64 / 80 / 128, Lq and Lk >= 128, no head gate / accumulate / dropout). Same result up to the bf16
+                             * rounding of P and O; parity tests pin both and compare them. */
+    int32_t _pad0;
 } ina_attn_args;
 int ina_attention_bf16(const ina_attn_args* args, void* stream);
 

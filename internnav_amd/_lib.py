@@ -41,6 +41,7 @@ class AttnArgs(C.Structure):
         ("scale", c_float),
         ("cu_q", c_void_p), ("cu_k", c_void_p), ("head_gate", c_void_p), ("k_len", c_void_p),
         ("accumulate", c_int32), ("drop_seed", C.c_uint32), ("drop_thresh", C.c_uint32), ("drop_scale", c_float),
+        ("kernel", c_int32), ("_pad0", c_int32),
     ]
 
 

@@ -273,7 +273,17 @@ class InternVLAN1Agent:
                     if so.output_latent is _PENDING:
                         pending.append((k, so))
                 if pending:
-                    lat = model.generate_latents(seqs, pv, grid, rows=[k for k, _ in pending], **extra)
+                    try:
+                        lat = model.generate_latents(seqs, pv, grid, rows=[k for k, _ in pending], **extra)
+                    except _FATAL:
+                        raise
+                    except Exception as ex:  # noqa: BLE001 - the envs waiting for latents fail TOGETHER and take the reference's path
+                        # (reset, one retry, then STOP); nobody keeps the _PENDING sentinel a later System-1 call would consume
+                        for k, so in pending:
+                            e, o, _ = items[k]
+                            e.s2_output = S2Output(idx=e.episode_step, is_infering=False)
+                            failed.append((e, o, ex))
+                        pending = []
                     for j, (_, so) in enumerate(pending):
                         so.output_latent = lat[j:j + 1]
         if not failed:

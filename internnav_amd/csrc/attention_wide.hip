@@ -45,7 +45,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16* a0, const bf16* a1) {
 // rescale is skipped while no row of the wave moves)
 constexpr float DEFER_THR = 6.0f;
 
-template <int D, int NW, bool DEFER, int VAR = 0>
+template <int D, int NW, bool DEFER>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     using C = WideCfg<D>;
     constexpr int NT = NW * 64, KVB = C::KVB, KLD = C::KLD, VLD = C::VLD, NDT = C::NDT, NKS = C::NKS;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     for (int ib = 0; ib < nblk; ++ib) {
         const int kv0 = kv_begin + ib * KVB, buf = ib & 1;
         const bool more = ib + 1 < nblk;
-        if (more && !(VAR & 1)) fetch(kv0 + KVB);
+        if (more) fetch(kv0 + KVB);
         if (wave_live && kv0 < wave_kv_end) {
             const bf16* Kb = Ks + buf * C::K_ELEMS;
             const bf16* Vb = Vs + buf * C::V_ELEMS;
@@ -189,16 +189,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
                                 kf[(g + 1) & 1][j][t] = *reinterpret_cast<const bf16x8*>(kbase + t * 32 * KLD + (2 * g + 2 + j) * 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         if (2 * g + j < NKS) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[g & 1][j][t], qf[2 * g + j], s[t], 0, 0, 0);
-                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (VAR & 1) { if (more) fetch(kv0 + KVB); }
             // V^T fragments of the first 16-key slice (all d tiles): requested now, consumed after the softmax
             bf16x8 vf[2][NDT];
 #pragma unroll
@@ -271,10 +268,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s4 & 1][dt], pf[s4], acc[dt], 0, 0, 0);
-                if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -306,10 +301,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     }
 }
 
-template <int D, int NW, bool DEFER, int VAR = 0>
+template <int D, int NW, bool DEFER>
 int launch_wide(const AttnArgs& p, hipStream_t stream) {
     using C = WideCfg<D>;
-    auto kern = attn_fwd_wide_kernel<D, NW, DEFER, VAR>;
+    auto kern = attn_fwd_wide_kernel<D, NW, DEFER>;
     static bool attr_done = false;
     if (!attr_done) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
@@ -322,29 +317,15 @@ int launch_wide(const AttnArgs& p, hipStream_t stream) {
 }
 
 template <int D>
-int launch_wide_d(const AttnArgs& p, hipStream_t stream, int nw, bool defer) {
-    if (nw == 8) return defer ? launch_wide<D, 8, true>(p, stream) : launch_wide<D, 8, false>(p, stream);
-    if (const char* e = getenv("INA_ATTN_VAR"); e && defer) {   // (experiments were run with the deferred maximum)   // schedule experiments: 1 = K/V prefetch issued after Q.K^T, 2 = s_setprio around the MFMA groups
-        switch (atoi(e)) {
-            case 1: return launch_wide<D, 4, true, 1>(p, stream);
-            case 2: return launch_wide<D, 4, true, 2>(p, stream);
-            case 3: return launch_wide<D, 4, true, 3>(p, stream);
-            default: break;
-        }
-    }
+int launch_wide_d(const AttnArgs& p, hipStream_t stream, bool defer) {
     return defer ? launch_wide<D, 4, true>(p, stream) : launch_wide<D, 4, false>(p, stream);
 }
 
 }  // namespace
 
-bool ina_attention_wide_eligible(const AttnArgs& p) {
-    // experiment switches are read per call (tests and tools flip them inside one process)
-    const char* e = getenv("INA_ATTN_WIDE");     // unset: d 128 / d 80 (LLM prefill, Qwen ViT); "1": d 64 as well; "0": never
-    if (e && e[0] == '0') return false;
-    // d 64 (DINOv2, 257 tokens) stays on the 16-row kernel by default: 41.9 vs 67.1 us per launch there, but the NavDP heads behind it are
-    // checked at the north-star tolerance with no margin (mean |err| 9.4e-4 vs 1e-3) and ten clipped DDPM steps amplify ANY change of
-    // rounding order: with the numerically equivalent wide kernel (same mean error to 4 digits on the op) the fixture lands at 1.003e-3
-    if (p.D != 128 && p.D != 80 && !(p.D == 64 && e && e[0] == '1')) return false;
+bool ina_attention_wide_contract(const AttnArgs& p) {
+    // what the kernel can run at all (ina_attn_args.kernel = 2 is rejected outside of it)
+    if (p.D != 128 && p.D != 80 && p.D != 64) return false;
     if (p.accumulate || p.head_gate || p.drop_thresh) return false;
     if (p.Lq < 128 || p.Lk < 128 || p.scale <= 0.f) return false;
     // whole-row 16-byte output stores
@@ -354,15 +335,19 @@ bool ina_attention_wide_eligible(const AttnArgs& p) {
     return true;
 }
 
+bool ina_attention_wide_eligible(const AttnArgs& p) {
+    // the automatic rule (ina_attn_args.kernel = 0): every long dense shape inside the kernel's contract - LLM prefill (d 128), Qwen ViT
+    // full-attention blocks (d 80) and, since round 4, DINOv2 (d 64, 257 tokens: 42 vs 67 us per launch; adopted behind the 64-env
+    // distributional parity test of the NavDP heads, tests/test_b64_distribution_gpu.py)
+    return ina_attention_wide_contract(p);
+}
+
 int ina_launch_attention_wide(const AttnArgs& p, hipStream_t stream) {
-    const char* e_nw = getenv("INA_ATTN_WIDE_NW");
-    const char* e_df = getenv("INA_ATTN_DEFER");
-    const int nw = (e_nw && atoi(e_nw) == 8) ? 8 : 4;
-    const bool defer = e_df && e_df[0] == '1';   // default: exact running maximum (the largest P of a row is exactly 1, as in the 16-row kernel)
+    const bool defer = p.kernel == 3;   // TEMPORARY (round-4 A/B): 3 = deferred running maximum
     switch (p.D) {
-        case 128: return launch_wide_d<128>(p, stream, nw, defer);
-        case 80: return launch_wide_d<80>(p, stream, nw, defer);
-        case 64: return launch_wide_d<64>(p, stream, nw, defer);
+        case 128: return launch_wide_d<128>(p, stream, defer);
+        case 80: return launch_wide_d<80>(p, stream, defer);
+        case 64: return launch_wide_d<64>(p, stream, defer);
         default: ina_set_error("attention (wide): unsupported head dim %d", p.D); return -2;
     }
 }

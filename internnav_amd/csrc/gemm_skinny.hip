@@ -291,23 +291,8 @@ void launch_skinny_fused(const GemmArgs& p, hipStream_t stream) {
     int nw = tiles >= 4096 ? 1 : tiles >= 2048 ? 2 : tiles >= 1024 ? 4 : 8;   // (16 waves on the K = 18944 down projection: no gain)
     while (nw > 1 && nw > ksteps) nw >>= 1;
 #define INA_SKF(NW_, NC_, D_) hipLaunchKernelGGL((gemm_skinny_fused_kernel<MF, NT16, NW_, NC_, D_>), dim3((tiles + NC_ - 1) / NC_), dim3(NW_ * NC_ * 64), 0, stream, p)
-    // experiment (round 3, INA_SKINNY_DEEP=1): twice the register ring for the single-fragment shapes - more bytes in flight per resident
-    // wave for the decode chain that shares the GPU with System-1 (it gets a fraction of the wave slots there)
-    static int deep = -1, small = -1;
-    if (deep < 0) deep = (getenv("INA_SKINNY_DEEP") && atoi(getenv("INA_SKINNY_DEEP")) > 0) ? 1 : 0;
-    // experiment (INA_SKINNY_SMALL=1): 4-wave column groups with the 2-deep ring everywhere - workgroups that fit into what a retiring
-    // System-1 workgroup frees on a CU (an 8-wave, ~150-register workgroup has to wait for two of them)
-    if (small < 0) small = (getenv("INA_SKINNY_SMALL") && atoi(getenv("INA_SKINNY_SMALL")) > 0) ? 1 : 0;
-    if (small && nw == 8) { INA_SKF(4, 1, 2); return; }
-    if constexpr (MF == 1) {
-        if (deep) {
-            if (nw == 1) INA_SKF(1, 4, 4);
-            else if (nw == 2) INA_SKF(2, 2, 4);
-            else if (nw == 4) INA_SKF(4, 1, 4);
-            else INA_SKF(8, 1, (NT16 == 1 ? 8 : 4));
-            return;
-        }
-    }
+    // (round 3 measured and dropped: twice the register ring for the single-fragment shapes, and 4-wave column groups everywhere - neutral
+    //  alone, -10 % inside the step where the chain shares the CUs with System-1: profiles/r03e / r03g_bench_*_experiments.log)
     if (nw == 1) INA_SKF(1, 4, 2);
     else if (nw == 2) INA_SKF(2, 2, 2);
     else if (nw == 4) INA_SKF(4, 1, 2);
@@ -552,14 +537,12 @@ int ina_launch_gemm_skinny_prenorm(const GemmArgs& p, hipStream_t stream) {
     InaProfScope prof(INA_PROF_GEMM_SKINNY, 2.0 * p.M * p.N * p.K, asz * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
     // every workgroup repeats the (cheap, L2-served) normalisation, so the column groups are packed NC per workgroup where one group
     // alone would be a 4-wave workgroup; the group width follows the fused kernel's rule (a few thousand waves per launch)
-    static int deep = -1;
-    if (deep < 0) deep = (getenv("INA_SKINNY_DEEP") && atoi(getenv("INA_SKINNY_DEEP")) > 0) ? 1 : 0;
     if (p.glu) {
         const int tiles = (p.N + 31) / 32;
-        if (tiles >= 1024) return deep ? launch_skinny_prenorm<2, 4, 2, 4>(p, stream, tiles) : launch_skinny_prenorm<2, 4, 2, 2>(p, stream, tiles);
+        if (tiles >= 1024) return launch_skinny_prenorm<2, 4, 2, 2>(p, stream, tiles);
         return launch_skinny_prenorm<2, 8, 1, 2>(p, stream, tiles);
     }
     const int tiles = (p.N + 15) / 16;
     if (tiles >= 1024) return launch_skinny_prenorm<1, 4, 2, 2>(p, stream, tiles);
-    return deep ? launch_skinny_prenorm<1, 8, 1, 8>(p, stream, tiles) : launch_skinny_prenorm<1, 8, 1, 4>(p, stream, tiles);
+    return launch_skinny_prenorm<1, 8, 1, 4>(p, stream, tiles);
 }

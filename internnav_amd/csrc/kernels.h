@@ -49,7 +49,8 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // di
 int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming split-K path
 int ina_launch_gemm_skinny_fused(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming, workgroup owns its columns for all K, fused epilogue
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
-bool ina_attention_wide_eligible(const AttnArgs& p);                   // attention_wide.hip: long dense shapes (32 query rows per wave)
+bool ina_attention_wide_eligible(const AttnArgs& p);                   // attention_wide.hip: long dense shapes (32 query rows per wave) - the automatic rule
+bool ina_attention_wide_contract(const AttnArgs& p);                   // what that kernel can run at all
 int ina_launch_attention_wide(const AttnArgs& p, hipStream_t stream);
 int ina_launch_norm(const NormArgs& p, hipStream_t stream);
 int ina_launch_patchify(const PatchifyArgs& p, hipStream_t stream);

@@ -80,31 +80,40 @@ def pin_host_threads(local_rank: int, local_world: int) -> int:
 
 def self_spawn_command(script: str, argv: Sequence[str], n_ranks: int, port: int = 0) -> List[str]:
     """the command that re-launches `script argv` as one process per GPU of this node: what `python bench.py --gpus N` runs when it was
-    started WITHOUT a launcher (no WORLD_SIZE in the environment). The reference's evaluation scripts do the same - they start one
-    process per GPU themselves (scripts/eval/bash/eval_dual_system.sh:4-12, internnav/utils/dist.py:193-243). Rendezvous on 127.0.0.1."""
-    import socket
+    started WITHOUT a launcher. The reference's evaluation scripts do the same - they start one process per GPU themselves
+    (scripts/eval/bash/eval_dual_system.sh:4-12, internnav/utils/dist.py:193-243). Rendezvous on 127.0.0.1: by default the launcher's own
+    `--standalone` mode picks a free port at bind time (a port probed here and closed again could be taken before the ranks bind it,
+    ADVICE r3); an explicit `port` > 0 uses --master-port."""
     import sys
 
-    if port <= 0:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), script, *argv]
+    if port > 0:
+        rdzv = ["--master-addr", "127.0.0.1", "--master-port", str(port)]
+    else:
+        rdzv = ["--standalone", "--local-addr", "127.0.0.1"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", *rdzv, script, *argv]
+
+
+def under_launcher(env=None) -> bool:
+    """is this process a rank started by torchrun / torch.distributed.run (or an equivalent launcher)? WORLD_SIZE alone does not say so -
+    containers and schedulers export WORLD_SIZE=1 for plain jobs - a launcher also sets the rank (RANK / LOCAL_RANK) or its
+    run id."""
+    env = os.environ if env is None else env
+    return "WORLD_SIZE" in env and any(k in env for k in ("RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"))
 
 
 def maybe_self_spawn(script: str, n_gpus: int) -> None:
     """`python <script> --gpus N` with N > 1 and no launcher environment: re-exec through torch.distributed.run (one rank per GPU) and
-    exit with its return code. Under a launcher (WORLD_SIZE set) it only checks that the launcher and --gpus agree."""
+    exit with its return code. Under a launcher (`under_launcher()`) it only checks that the launcher and --gpus agree."""
     import subprocess
     import sys
 
-    world = os.environ.get("WORLD_SIZE")
-    if world is not None:
+    if under_launcher():
+        world = os.environ["WORLD_SIZE"]
         if int(world) != n_gpus:
             raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks")
         return
     if n_gpus <= 1:
         return
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = {k: v for k, v in os.environ.items() if k != "WORLD_SIZE"}      # a scheduler's WORLD_SIZE=1 must not reach the ranks' launcher
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     raise SystemExit(subprocess.call(self_spawn_command(script, sys.argv[1:], n_gpus), env=env))

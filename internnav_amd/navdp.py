@@ -36,8 +36,10 @@ from .vit_s import DinoV2Encoder, VitWorkspace
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 # DAT_RGBD_Patch_Backbone holds its constants in bf16 (input_dtype="bf16" default, navdp_backbone.py:119-127)
-IMAGENET_MEAN_BF16 = (0.484375, 0.45703125, 0.40625)
-IMAGENET_STD_BF16 = (0.2294921875, 0.2236328125, 0.224609375)
+# (round 4: the two tuples were typed in by hand and had TWO wrong entries - mean G 0.45703125, std R 0.2294921875 - which alone put the
+# N1 NavDP head further from fp32 than bf16-autocast PyTorch; they are now derived from the fp32 constants by the same cast the reference does)
+IMAGENET_MEAN_BF16 = tuple(float(torch.tensor(v, dtype=torch.float32).to(torch.bfloat16)) for v in IMAGENET_MEAN)   # (0.484375, 0.455078125, 0.40625)
+IMAGENET_STD_BF16 = tuple(float(torch.tensor(v, dtype=torch.float32).to(torch.bfloat16)) for v in IMAGENET_STD)     # (0.228515625, 0.2236328125, 0.224609375)
 
 
 def ddpm_tables(num_train_timesteps: int):

@@ -126,6 +126,7 @@ class QwenVLEngine:
         # slices of the same buffers and cache slots and the results are the same; the tails of one half's GEMM launches (tile
         # quantisation over 256 CUs) are filled by the other half's workgroups (119.6 -> 115.5 ms at 7 prompts, profiles/r03q_*)
         self.split_prefill = True
+        self.split_serial = False     # True: the two half micro-batches of split_prefill on ONE stream (per-launch event timing, bench.py)
         self._side = None
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
@@ -336,6 +337,10 @@ class QwenVLEngine:
             raise CapacityError(f"System-2 batch of {B} x {S} tokens exceeds the engine's max_seqs={self.B_max} / max_seq_len={self.S_max}")
         pl = np.broadcast_to(np.asarray(prefix_len, dtype=np.int64).reshape(-1), (B,)).copy()
         assert int(pl.min()) >= 0 and int(pl.max()) < S, f"prefix_len={pl.tolist()} must leave at least one token of the {S}-token prompts to run"
+        # the planned decode / latent passes read every sequence's first token at row S_run - 1 of its rectangle: only uniform prefixes put
+        # the last real token there (ragged prefixes decode through the eager `decode()`, which carries per-sequence row indices) - ADVICE r3
+        assert (n_decode == 0 and not with_latents) or int(pl.min()) == int(pl.max()), \
+            f"plan(n_decode={n_decode}, with_latents={with_latents}) needs ONE prefix length for all sequences, got {pl.tolist()}: use prefill() + decode()"
         grids = [tuple(int(v) for v in g) for g in (image_grid_thw.tolist() if image_grid_thw is not None else [])]
         grids_all = grids
         Sr = S - int(pl.min())                                    # tokens per sequence this call runs (rectangle width)
@@ -454,8 +459,11 @@ class QwenVLEngine:
             # both halves' GEMMs run beside each other: tiles are picked without the quantisation charge (ops.shared_tail; decoder chain of
             # 3 + 3 envs 61.8 vs 64.2 ms, 4 + 3 envs 73.4 vs 74.5 ms, vision chain 28.0 vs 28.7 ms: profiles/r03x_native_chain_partitions.log)
             with ops.shared_tail():
-                with torch.cuda.stream(self._side):
+                if self.split_serial:        # profiling: the SAME launches (half batches, shared-tail tile selection) back to back on one stream
                     half(P["split"][1])
+                else:
+                    with torch.cuda.stream(self._side):
+                        half(P["split"][1])
                 half(P["split"][0])
             main.wait_stream(self._side)
             return

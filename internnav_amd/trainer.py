@@ -228,7 +228,8 @@ class InternVLAN1SftTrainer:
     def checkpoint(self) -> dict:
         """resume point: master weights, Adam moments (ZeRO-2: all-gathered from their owner ranks - a COLLECTIVE, every rank calls it),
         optimiser / schedule / mask counters and the state of this rank's noise / time-step generators. Weights, moments and counters
-        are the same on every rank; `rng` is per rank (each rank saves its own file, or rank 0's file + fresh streams elsewhere)."""
+        are the same on every rank; `rng` is per rank (each rank saves its own file; a rank that loads ANOTHER rank's file re-seeds its streams
+        from (seed, rank, step_idx) - fresh draws, never a replay of the steps before the checkpoint)."""
         sharded = (self.P.m_lo, self.P.m_hi) != (0, self.P.numel)
         return dict(store=self.P.checkpoint(self._gather_flat if sharded else None), step_idx=self.step_idx, micro_idx=self.micro_idx,
                     system1=self.system1, rng=dict(rank=self.rank, dev=self.gen_dev.get_state().cpu(), cpu=self.gen_cpu.get_state()))
@@ -244,9 +245,16 @@ class InternVLAN1SftTrainer:
             raise ValueError(f"checkpoint of a {ck['system1']} head, trainer built for {self.system1}")
         self.P.load_checkpoint(ck["store"])
         self.step_idx, self.micro_idx = int(ck["step_idx"]), int(ck["micro_idx"])
-        if "rng" in ck and int(ck["rng"]["rank"]) == self.rank:          # another rank's file: keep this rank's own streams
+        if "rng" in ck and int(ck["rng"]["rank"]) == self.rank:
             self.gen_dev.set_state(ck["rng"]["dev"])
             self.gen_cpu.set_state(ck["rng"]["cpu"])
+        else:
+            # another rank's file (the "rank 0 writes" flow): this rank's own generator state was not saved, and the constructor-seeded
+            # streams would REPLAY the draws of steps 0 .. step_idx - 1. Start fresh streams keyed by (seed, rank, step_idx):
+            # never the draws of an earlier step, the same on every resume from this checkpoint.
+            s_ = _splitmix64(_splitmix64(_splitmix64(self.seed) ^ (self.rank + 1)) ^ (self.step_idx + 1))
+            self.gen_dev.manual_seed(s_ & 0x7FFFFFFFFFFFFFFF)
+            self.gen_cpu.manual_seed((s_ >> 1) & 0x7FFFFFFFFFFFFFFF)
         self.engine.latent_q.copy_(self.P.w16(LQ).view(self.engine.latent_q.shape))
 
     def training_step(self, batch: dict, noise=None, t_index=None) -> torch.Tensor:

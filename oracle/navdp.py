@@ -26,7 +26,7 @@ IMAGENET_MEAN = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
 IMAGENET_STD = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
 # DAT_RGBD_Patch_Backbone creates its constants with dtype=input_dtype, "bf16" by default and never overridden by
 # build_navdp (navdp_backbone.py:119-127, internvla_n1_arch.py:13): the reference therefore normalises with the
-# bf16-ROUNDED mean/std (0.484375, 0.45703125, 0.40625 / 0.2294921875, 0.2236328125, 0.224609375).
+# bf16-ROUNDED mean/std (0.484375, 0.455078125, 0.40625 / 0.228515625, 0.2236328125, 0.224609375).
 IMAGENET_MEAN_BF16 = IMAGENET_MEAN.to(torch.bfloat16).float()
 IMAGENET_STD_BF16 = IMAGENET_STD.to(torch.bfloat16).float()
 

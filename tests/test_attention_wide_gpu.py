@@ -3,8 +3,6 @@ on the long dense shapes (LLM prefill, ViT full-attention blocks, DINOv2): every
 Lq != Lk = cached prefix, kv_start, per-sequence k_len, varlen cu_q / cu_k), ragged tails, strided views of a fused qkv buffer, both
 workgroup sizes and both running-max policies. Tolerance: the bf16 rounding of P and O (the 16-row kernel's own bound, 1.5e-2
 absolute on N(0,1) inputs); the two kernels are also compared with each other."""
-import os
-
 import pytest
 import torch
 
@@ -24,23 +22,6 @@ def ops(built_lib):
     from internnav_amd import ops
 
     return ops
-
-
-class _env:
-    def __init__(self, **kw):
-        self.kw = kw
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        for k, v in self.kw.items():
-            os.environ[k] = str(v)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def _ref(q, k, v, scale, causal=False, kv_start=0, k_len=None):
@@ -88,20 +69,19 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("nw,defer", [(4, 1), (4, 0), (8, 1)])
 @pytest.mark.parametrize("B,Lq,Lk,H,Hkv,D,causal,kv_start", CASES)
-def test_wide_attention_vs_fp32_formula_and_16row_kernel(ops, B, Lq, Lk, H, Hkv, D, causal, kv_start, nw, defer):
+def test_wide_attention_vs_fp32_formula_and_16row_kernel(ops, B, Lq, Lk, H, Hkv, D, causal, kv_start):
     g = torch.Generator().manual_seed(B * 1000 + Lq + Lk + D)
     q, k, v = _rand((B, Lq, H, D), g), _rand((B, Lk, Hkv, D), g), _rand((B, Lk, Hkv, D), g)
     scale = D ** -0.5
     ref = _ref(q, k, v, scale, causal, kv_start)
-    with _env(INA_ATTN_WIDE=0):
-        old = ops.attention(q, k, v, scale=scale, causal=causal, kv_start=kv_start)
-    with _env(INA_ATTN_WIDE=1, INA_ATTN_WIDE_NW=nw, INA_ATTN_DEFER=defer):
-        new = ops.attention(q, k, v, scale=scale, causal=causal, kv_start=kv_start)
+    old = ops.attention(q, k, v, scale=scale, causal=causal, kv_start=kv_start, kernel=1)
+    new = ops.attention(q, k, v, scale=scale, causal=causal, kv_start=kv_start, kernel=2)
+    auto = ops.attention(q, k, v, scale=scale, causal=causal, kv_start=kv_start)
     torch.cuda.synchronize()
+    assert torch.equal(auto, new), "the automatic rule runs the 32-rows-per-wave kernel on every long dense shape"
     e_old = _check(old, ref, what="16-row kernel")
-    e_new = _check(new, ref, what=f"wide kernel nw={nw} defer={defer}")
+    e_new = _check(new, ref, what="wide kernel")
     assert e_new <= 1.35 * e_old + 1e-5, (e_new, e_old)
     assert (new.float() - old.float()).abs().max().item() <= 3e-2
 
@@ -116,10 +96,9 @@ def test_wide_attention_peaked_rows_and_growing_maximum(ops):
     k = (k.float() * ramp).to(torch.bfloat16)
     scale = D ** -0.5
     ref = _ref(q, k, v, scale, True)
-    for defer in (1, 0):
-        with _env(INA_ATTN_WIDE=1, INA_ATTN_DEFER=defer):
-            out = ops.attention(q, k, v, scale=scale, causal=True)
-        _check(out, ref, atol=2e-2, what=f"peaked rows, defer={defer}")
+    for kern in (2, 1):
+        out = ops.attention(q, k, v, scale=scale, causal=True, kernel=kern)
+        _check(out, ref, atol=2e-2, what=f"peaked rows, kernel={kern}")
 
 
 def test_wide_attention_ragged_k_len_batch(ops):

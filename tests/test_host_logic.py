@@ -282,7 +282,15 @@ def test_bench_accounting_is_consistent():
     f1 = flops.nextdit_s1_flops_per_env(s)["total"]
     assert abs(f2 / 1e12 - 16.46) < 0.1 and abs(f1 / 1e12 - 0.53) < 0.02          # 16.46 / 0.53 TFLOP
     assert abs((f1 + f2 / 10) / 1e12 - 2.18) < 0.03                                # policy step 2.18 TFLOP per env
-    B, C = 64, bench.N1Dual.CADENCE
+    assert abs((f2 + 2 * f1) / 8 / 1e12 - 2.19) < 0.03                             # reference cadence: (1 S2 + 2 S1) per 8 actions
+    # the harness shape (num_history 8 + current frame, then the look-down turn with the un-resized frame): S and FLOPs grow as the prompt
+    from internnav_amd.preprocess import smart_resize
+    hb, wb = smart_resize(480, 640)
+    assert (hb // 14, wb // 14) == (34, 46)                                         # 1564 patches = 391 tokens
+    S9 = 34 + 64 + 9 * 198 + 30
+    f9 = flops.s2_call_flops(S9 + 16 + 393 + 8, [(1, 28, 28)] * 9 + [(1, 34, 46)], 8, q)["total"]
+    assert 2.2 * f2 < f9 < 3.2 * f2
+    B, C = 64, 10
     mb = [B // C + (1 if j < B % C else 0) for j in range(C)]
     assert sum(mb) == B and max(mb) - min(mb) <= 1
     starts = np.concatenate([[0], np.cumsum(mb)])
@@ -319,6 +327,10 @@ def test_self_spawn_relaunches_one_process_per_gpu(tmp_path):
     cmd = self_spawn_command("bench.py", ["--gpus", "4", "--steps", "5"], 4, port=29999)
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "5"]
+    auto = self_spawn_command("bench.py", ["--gpus", "4"], 4)            # default: the launcher binds its own free port (no probe-then-close race)
+    assert "--standalone" in auto and auto[auto.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in auto
+    from internnav_amd.dist import under_launcher
+    assert not under_launcher({"WORLD_SIZE": "1"}) and under_launcher({"WORLD_SIZE": "2", "RANK": "0"}) and not under_launcher({})
     script = tmp_path / "mini_bench.py"
     script.write_text(
         "import os, sys\n"
@@ -333,6 +345,10 @@ def test_self_spawn_relaunches_one_process_per_gpu(tmp_path):
     assert sorted(l for l in out.stdout.splitlines() if l.startswith("RANK")) == ["RANK 0 of 2", "RANK 1 of 2"]
     out = subprocess.run([sys.executable, str(script), "--gpus", "1"], capture_output=True, text=True, env=env, timeout=120)
     assert out.stdout.strip() == "RANK none of none"                       # single GPU: no launcher involved
+    # a scheduler's WORLD_SIZE=1 without a rank is NOT a launcher: --gpus 2 still starts its own two ranks
+    out = subprocess.run([sys.executable, str(script), "--gpus", "2"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="1"), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert sorted(l for l in out.stdout.splitlines() if l.startswith("RANK")) == ["RANK 0 of 2", "RANK 1 of 2"]
     bad = subprocess.run([sys.executable, str(script), "--gpus", "4"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
 

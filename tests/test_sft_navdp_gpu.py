@@ -64,20 +64,22 @@ def test_navdp_sft_loss_and_gradients(built_lib):
         e, y = _rel(got, ref), _rel(g16[k], ref)
         errs.append(e)
         yards.append(y)
-        if e > max(3e-2, 1.25 * y):
+        if e > 1.25 * y + 1e-3:
             bad.append((k, e, y))
     print(f"{len(errs)} parameter gradients: engine mean {sum(errs) / len(errs):.3e}, bf16 PyTorch mean {sum(yards) / len(yards):.3e}")
-    # Unlike the NextDiT branch (engine 0.7x of the bf16-PyTorch error) this 16-layer decoder on random weights has nearly sample-independent
-    # activations, so rounding errors add coherently over the rows; measured: residual stream after layer 15 engine 4.4e-3 vs autocast 3.7e-3,
-    # prediction 1.24e-2 vs 8.3e-3, gradients 1.2e-2 vs 3.5e-3 relative (tools/sft_check_navdp*.py). Bound: 3 % per tensor, 1.5 % on average.
+    # Round 4: with the bf16 ImageNet constants of DAT_RGBD_Patch_Backbone corrected (two hand-typed entries were wrong: the RGB tokens sat 2x
+    # further from fp32 than bf16 PyTorch's, and all 16 decoder layers re-read them) and fp32 post-LN streams in the former, this branch is
+    # where the NextDiT branch is: closer to fp32 than bf16-autocast PyTorch (CPU replica of the tape: gradients 5.2e-3 vs 6.6e-3 on average,
+    # worst single tensor 1.10x its yardstick). Bound: never above 1.25x the yardstick per tensor, not above it on average.
     assert not bad, bad[:10]
-    assert sum(errs) / len(errs) <= 1.5e-2
+    assert sum(errs) / len(errs) <= sum(yards) / len(yards)
 
 
 def test_navdp_sft_per_layer_drift_table(built_lib):
     """Where the navdp_async branch sits against its yardstick, layer by layer: the residual stream of the 16-layer
     decoder after every layer and its GRADIENT on the way back, engine vs fp32 oracle next to bf16-autocast PyTorch vs the same oracle.
-    Written to gpurun_out/sft_navdp_drift.txt. Asserted: the forward stream stays within 1.35x of the yardstick at every layer."""
+    Written to gpurun_out/sft_navdp_drift.txt. Asserted (round 4): at EVERY layer the engine is not further from fp32 than bf16-autocast
+    PyTorch, forward stream and stream gradient alike (measured 0.67-0.77x / 0.75-0.84x)."""
     import os
     from pathlib import Path
 
@@ -121,12 +123,12 @@ def test_navdp_sft_per_layer_drift_table(built_lib):
     fwd, bwd = dict(head.taps), dict(head.grad_taps)
     lines = ["# navdp_async SFT: decoder residual stream per layer, engine vs fp32 oracle | bf16-autocast PyTorch vs fp32 oracle (relative L2)",
              "# layer | forward: engine  autocast  ratio | gradient of the stream: engine  autocast  ratio"]
-    worst_f = 0.0
+    worst_f = worst_b = 0.0
     for i in range(cfg["temporal_depth"]):
         n = f"layer{i}"
         ef, yf = _rel(fwd[n].cpu().view_as(r32[n][0]), r32[n][0]), _rel(r16[n][0], r32[n][0])
         eb, yb = _rel(bwd[n].cpu().view_as(r32[n][1]), r32[n][1]), _rel(r16[n][1], r32[n][1])
-        worst_f = max(worst_f, ef / yf)
+        worst_f, worst_b = max(worst_f, ef / yf), max(worst_b, eb / yb)
         lines.append(f"{n:8s} {ef:.3e} {yf:.3e} {ef / yf:5.2f} | {eb:.3e} {yb:.3e} {eb / yb:5.2f}")
     out = Path(os.environ.get("GRAFT_REPO_ROOT", Path(__file__).resolve().parent.parent)) / "gpurun_out"
     try:
@@ -135,4 +137,4 @@ def test_navdp_sft_per_layer_drift_table(built_lib):
     except OSError:
         pass
     print("\n".join(lines))
-    assert worst_f <= 1.35, worst_f
+    assert worst_f <= 1.0 and worst_b <= 1.0, (worst_f, worst_b)

@@ -178,7 +178,7 @@ def _zero2_ckpt_worker(rank, world, port, q, tmp):
         tr = object.__new__(InternVLAN1SftTrainer)
         tr.P, tr.world, tr.rank, tr.pg, tr.zero2, tr.device, tr.system1 = P, world, rank, None, True, torch.device("cpu"), "nextdit_async"
         tr.total_steps, tr.lr, tr.min_lr, tr.warmup_steps, tr.wd, tr.max_norm, tr.betas, tr.eps = 100, 1e-2, 1e-3, 0, 0.01, 1.0, (0.9, 0.999), 1e-8
-        tr.grad_norm, tr.step_idx, tr.micro_idx = torch.zeros(1), 0, 0
+        tr.grad_norm, tr.step_idx, tr.micro_idx, tr.seed = torch.zeros(1), 0, 0, 0
         tr.gen_dev, tr.gen_cpu = torch.Generator().manual_seed(rank), torch.Generator().manual_seed(rank + 50)
 
         class _E:
@@ -214,8 +214,20 @@ def _zero2_ckpt_worker(rank, world, port, q, tmp):
     c.load_checkpoint(os.path.join(tmp, "ck_rank0.pt") if rank == 1 else path)      # rank 1 resumes from RANK 0's file
     for k in range(2, 4):
         step(c, k)
+    # rng streams after a resume: a rank that loaded ITS OWN file continues its stream (next draw == the uninterrupted trainer's next draw);
+    # a rank that loaded another rank's file starts a FRESH stream keyed by (seed, rank, step) - not a replay of the draws from step 0
+    # (what a constructor-seeded generator would produce) and the same again on a second resume from that file
+    fresh = make(7)
+    first_ever = torch.rand(4, generator=fresh.gen_cpu)
+    nxt = torch.rand(4, generator=c.gen_cpu)
+    if rank == 0:
+        rng_ok = torch.equal(nxt, torch.rand(4, generator=b.gen_cpu))
+    else:
+        d = make(9)
+        d.load_checkpoint(os.path.join(tmp, "ck_rank0.pt"))
+        rng_ok = (not torch.equal(nxt, first_ever)) and torch.equal(nxt, torch.rand(4, generator=d.gen_cpu))
     q.put((rank, float((a.P.p32 - c.P.p32).abs().max()), bool(torch.equal(a.P.m, c.P.m) and torch.equal(a.P.v, c.P.v)), owned_by_1 > 0,
-           abs(in_file - float(full_m.abs().sum())) <= 1e-4 * in_file, c.step_idx, c.P.step_count))
+           abs(in_file - float(full_m.abs().sum())) <= 1e-4 * in_file, c.step_idx, c.P.step_count, bool(rng_ok)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -238,5 +250,6 @@ def test_zero2_checkpoint_resume_world2_gloo(tmp_path):
     for p in procs:
         p.join(timeout=60)
     assert len(res) == 2
-    for rank, diff, same_moments, other_shard_nonzero, file_complete, step_idx, step_count in res:
+    for rank, diff, same_moments, other_shard_nonzero, file_complete, step_idx, step_count, rng_ok in res:
         assert diff == 0.0 and same_moments and other_shard_nonzero and file_complete and step_idx == 4 and step_count == 4
+        assert rng_ok, f"rank {rank}: generator streams after the resume"

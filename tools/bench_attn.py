@@ -28,29 +28,21 @@ def dense(name, B, L, H, Hkv, D, causal):
     k = torch.randn(B, L, Hkv, D, device=dev).to(torch.bfloat16)
     v = torch.randn(B, L, Hkv, D, device=dev).to(torch.bfloat16)
     o = torch.empty_like(q)
-    us = timeit(lambda: ops.attention(q, k, v, causal=causal, out=o))
+    us = timeit(lambda: ops.attention(q, k, v, causal=causal, out=o, kernel=KERNEL))
     fl = 4.0 * B * H * L * L * D * (0.5 if causal else 1.0)
     print(f"{name:34s} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
 
 
-import os  # noqa: E402
+KERNEL = 0
 
-for cfg in ({"INA_ATTN_WIDE": "0"}, {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1"},
-            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "0"},
-            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "8", "INA_ATTN_DEFER": "1"},
-            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1", "INA_ATTN_VAR": "1"},
-            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1", "INA_ATTN_VAR": "2"},
-            {"INA_ATTN_WIDE": "1", "INA_ATTN_WIDE_NW": "4", "INA_ATTN_DEFER": "1", "INA_ATTN_VAR": "3"}):
-    os.environ.pop("INA_ATTN_VAR", None)
-    os.environ.update(cfg)
-    print("==", " ".join(f"{k}={v}" for k, v in cfg.items()), "(0 = 16-row kernel, 1 = 32-rows-per-wave kernel)")
+for KERNEL in (1, 2):
+    print("== ina_attn_args.kernel =", KERNEL, "(1 = 16-rows-per-wave kernel, 2 = 32-rows-per-wave kernel)")
     dense("LLM prefill 7x920 28/4 x128 causal", 7, 920, 28, 4, 128, True)
     dense("LLM prefill 6x920 28/4 x128 causal", 6, 920, 28, 4, 128, True)
     dense("7x920 28/4 x128 NOT causal", 7, 920, 28, 4, 128, False)
     dense("ViT full 28x784 16 x80", 28, 784, 16, 16, 80, False)
     dense("DINOv2 128x257 6 x64", 128, 257, 6, 6, 64, False)
-for k in ("INA_ATTN_WIDE", "INA_ATTN_WIDE_NW", "INA_ATTN_DEFER", "INA_ATTN_VAR"):
-    os.environ.pop(k, None)
+KERNEL = 0
 # ViT windows: 64-token windows packed on one axis
 Np, H, D = 21952, 16, 80
 qkv = torch.randn(Np, 3, H, D, device=dev).to(torch.bfloat16)

@@ -2,14 +2,13 @@
 (64 / 57 / 7 envs), the decode || System-1 overlap, D2H + host post-processing."""
 import sys, time
 from pathlib import Path
-from types import SimpleNamespace
 
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench  # noqa: E402
 
-a = SimpleNamespace(envs=64, no_overlap=False, no_graph=False, overlap_at="decode")
+a = bench.default_args()
 dev = torch.device("cuda:0")
 wl = bench.N1Dual(a, dev, 0)
 wl.capture()
