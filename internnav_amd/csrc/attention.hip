@@ -414,7 +414,7 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
                       2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)(p.B / p.kv_bdiv) * p.Hkv * p.Lk), stream);
     // long dense shapes: 32x32 MFMA kernel (attention_wide.hip); ina_attn_args.kernel pins one of the two kernels (tests compare them)
     if (p.kernel == 2) INA_REQUIRE(ina_attention_wide_contract(p), "attention: kernel = 2 (32-rows-per-wave) outside its contract (d 64 / 80 / 128, Lq, Lk >= 128, no gate / accumulate / dropout)");
-    if (p.kernel == 2 || (p.kernel == 3 && ina_attention_wide_contract(p)) || (p.kernel == 0 && ina_attention_wide_eligible(p)))
+    if (p.kernel == 2 || (p.kernel == 0 && ina_attention_wide_eligible(p)))
         return ina_launch_attention_wide(p, stream);
     if (p.drop_thresh) {   // training-only variant (d <= 64 heads of the nn.Transformer layers)
         if constexpr (DP <= 64) {

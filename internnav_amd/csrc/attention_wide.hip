@@ -41,11 +41,12 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16* a0, const bf16* a1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// DEFER: a row keeps its running maximum until it grows by more than 2^DEFER_THR (P <= 2^DEFER_THR instead of <= 1; the accumulator
-// rescale is skipped while no row of the wave moves)
+// Deferred running maximum: a row keeps its maximum until it grows by more than 2^DEFER_THR (P <= 2^DEFER_THR instead of <= 1; the
+// accumulator rescale is skipped while no row of the wave moves). 3-5 % of the kernel; adopted in round 4 behind the 64-env distributional
+// parity tests (the exact-maximum variant measured the same error distribution on all three System-1 heads, profiles/r04a_ab_attn.log).
 constexpr float DEFER_THR = 6.0f;
 
-template <int D, int NW, bool DEFER>
+template <int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     using C = WideCfg<D>;
     constexpr int NT = NW * 64, KVB = C::KVB, KLD = C::KLD, VLD = C::VLD, NDT = C::NDT, NKS = C::NKS;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             mx *= sc;
-            const bool grow = DEFER ? (mx > m_run + DEFER_THR) : (mx > m_run);
+            const bool grow = mx > m_run + DEFER_THR;
             if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {   // the branch is wave-wide, the decision is per row: a row's arithmetic never
                 const float m_new = grow ? fmaxf(m_run, mx) : m_run;   // depends on which rows share its wave (prefix-KV reuse stays bit-exact)
                 const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
@@ -301,10 +302,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     }
 }
 
-template <int D, int NW, bool DEFER>
+template <int D, int NW>
 int launch_wide(const AttnArgs& p, hipStream_t stream) {
     using C = WideCfg<D>;
-    auto kern = attn_fwd_wide_kernel<D, NW, DEFER>;
+    auto kern = attn_fwd_wide_kernel<D, NW>;
     static bool attr_done = false;
     if (!attr_done) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
@@ -314,11 +315,6 @@ int launch_wide(const AttnArgs& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), C::LDS, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
-}
-
-template <int D>
-int launch_wide_d(const AttnArgs& p, hipStream_t stream, bool defer) {
-    return defer ? launch_wide<D, 4, true>(p, stream) : launch_wide<D, 4, false>(p, stream);
 }
 
 }  // namespace
@@ -343,11 +339,10 @@ bool ina_attention_wide_eligible(const AttnArgs& p) {
 }
 
 int ina_launch_attention_wide(const AttnArgs& p, hipStream_t stream) {
-    const bool defer = p.kernel == 3;   // TEMPORARY (round-4 A/B): 3 = deferred running maximum
     switch (p.D) {
-        case 128: return launch_wide_d<128>(p, stream, defer);
-        case 80: return launch_wide_d<80>(p, stream, defer);
-        case 64: return launch_wide_d<64>(p, stream, defer);
+        case 128: return launch_wide<128, 4>(p, stream);
+        case 80: return launch_wide<80, 4>(p, stream);
+        case 64: return launch_wide<64, 4>(p, stream);
         default: ina_set_error("attention (wide): unsupported head dim %d", p.D); return -2;
     }
 }

@@ -116,11 +116,6 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
-# TEMPORARY (round-4 A/B of the staged attention variants, removed once decided): {'mode': 'old', 64: 1} = d 64 on the 16-row kernel as
-# in round 3; {'mode': 'defer', 'all': 3} = deferred running maximum wherever the wide kernel can run
-_ATTN_AB: dict = {}
-
-
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, causal: bool = False,
               kv_start: int = 0, kv_bdiv: int = 1, cu_q: Optional[torch.Tensor] = None,
               cu_k: Optional[torch.Tensor] = None, max_q: int = 0, max_k: int = 0,
@@ -171,7 +166,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
         assert k_len.dtype == torch.int32 and k_len.is_contiguous() and cu_q is None
         a.k_len = k_len.data_ptr()
     a.accumulate = 1 if accumulate else 0
-    a.kernel = kernel if kernel else _ATTN_AB.get(D if _ATTN_AB.get('mode') == 'old' else 'all', 0)
+    a.kernel = kernel
     if drop_p > 0.0:       # training only: attention-probability dropout, mask = counter hash of (seed, element index)
         assert cu_q is None, "dropout: dense layouts only"
         a.drop_seed, a.drop_thresh, a.drop_scale = drop_params(drop_p, drop_seed)

@@ -3,11 +3,14 @@
 Ten sampler steps (DDPM with clipping, flow matching) amplify last-bit differences, so a MAX over a handful of envs says little. The yardstick
 is the precision the reference itself runs at: tests/golden/s1_b64_yardstick.pt (oracle/make_golden_b64.py, CPU) holds for every env of the
 seeded 64-env batch the fp32 oracle output (one env per call, as the reference executes) and the mean / 99th-percentile / max |error| of the SAME
-oracle under bf16 autocast against it. The engine's per-env errors are compared with that distribution:
-  * median over the envs of (engine mean|err| / yardstick mean|err|) <= 1.0 - the engine is not further from fp32 than bf16 PyTorch,
-  * no env's mean|err| above 1.25x its own yardstick, and the same two bounds on the 99th percentile (1.0 / 1.5),
-  * every env's mean|err| inside the north-star 1e-3 scaled by the output range where the yardstick itself is (bf16 PyTorch is not, for the
-    NextDiT head: its median is 2e-3).
+oracle under bf16 autocast against it. The engine's per-env errors are compared with that distribution (mean |err| and 99th-percentile
+|err| per env):
+  * paired, env by env: the median AND the 90th percentile over the envs of (engine / yardstick) are <= 1.0 - on (at least) nine envs of
+    ten the engine is not further from fp32 than bf16 PyTorch is on the same env; no env above 2x (a broken env, not sampler chaos:
+    single envs land anywhere in 0.3 .. 1.6x under ANY change of summation order, profiles/r04a_ab_attn.log);
+  * as distributions: the engine's 50th / 75th / 90th percentile over the envs does not exceed the yardstick's, its worst env not 1.25x
+    the yardstick's worst env.
+Measured (r04a): medians 0.53-0.65, 90th percentiles 0.70-0.92, quantile ratios 0.52-0.70.
 Batch size changes the GEMM tile selection, so B = 64 is a different code path from the B = 2 fixtures. The per-env table goes to
 gpurun_out/s1_b64_distribution.txt."""
 import os
@@ -54,12 +57,16 @@ def _report(name, mine, yard):
     return r
 
 
-def _assert_distribution(r, worst_mean=1.25, worst_p99=1.5):
-    med = r.median(0).values
-    assert med[0].item() <= 1.0, f"median (engine / bf16 PyTorch) of the per-env mean|err| = {med[0].item():.3f} > 1"
-    assert med[1].item() <= 1.0, f"median ratio of the per-env 99th-percentile |err| = {med[1].item():.3f} > 1"
-    assert r[:, 0].max().item() <= worst_mean, f"an env's mean|err| is {r[:, 0].max().item():.3f}x its bf16-PyTorch yardstick"
-    assert r[:, 1].max().item() <= worst_p99, f"an env's 99th-percentile |err| is {r[:, 1].max().item():.3f}x its bf16-PyTorch yardstick"
+def _assert_distribution(r, mine, yard):
+    for c, what in ((0, "mean|err|"), (1, "99th-percentile |err|")):
+        med, p90 = r[:, c].median().item(), torch.quantile(r[:, c], 0.9).item()
+        assert med <= 1.0, f"median over the envs of engine / bf16 PyTorch, per-env {what}: {med:.3f} > 1"
+        assert p90 <= 1.0, f"90th percentile over the envs of engine / bf16 PyTorch, per-env {what}: {p90:.3f} > 1"
+        assert r[:, c].max().item() <= 2.0, f"an env's {what} is {r[:, c].max().item():.3f}x its bf16-PyTorch yardstick"
+        for q in (0.5, 0.75, 0.9):
+            e, y = torch.quantile(mine[:, c], q).item(), torch.quantile(yard[:, c], q).item()
+            assert e <= y, f"{int(q * 100)}th percentile of the per-env {what}: engine {e:.3e} > bf16 PyTorch {y:.3e}"
+        assert mine[:, c].max().item() <= 1.25 * yard[:, c].max().item(), f"worst env, {what}: {mine[:, c].max().item():.3e} vs {yard[:, c].max().item():.3e}"
 
 
 def test_navdpnet_b64_distribution(built_lib, gold):
@@ -77,8 +84,8 @@ def test_navdpnet_b64_distribution(built_lib, gold):
     fin = net.sample[: B * S * T].view(B, S, T, 3)
     mine = _per_env(fin, g["samples"])
     r = _report("NavDPNet B=64 denoised samples", mine, g["yard"])
-    _assert_distribution(r)
-    assert mine[:, 0].max().item() < 1e-3 * max(1.0, (g["yard"][:, 0].max() / 1e-3).item())
+    _assert_distribution(r, mine, g["yard"])
+    assert mine[:, 0].median().item() < 1e-3            # north-star tolerance on waypoint increments in [-1, 1] (the yardstick's median: 1.09e-3)
     # critic values and the top-8 ranking (navdp_policy.py:172-185): the selected SET equals the oracle's wherever its margin exceeds twice our error
     cr = net.critic[: B * S].view(B, S).float().cpu()
     same = 0
@@ -108,7 +115,7 @@ def test_nextdit_b64_distribution(built_lib, gold):
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), inp["images"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV))
     mine = _per_env(out.view(B, *g["latents"].shape[1:]), g["latents"])
     r = _report("NextDiT B=64 trajectory latents", mine, g["yard"])
-    _assert_distribution(r)
+    _assert_distribution(r, mine, g["yard"])
     scale = max(1.0, g["latents"].abs().max().item())
     assert mine[:, 0].median().item() < 1e-3 * scale      # O(4) latents: 2.5e-4 relative
 
@@ -126,4 +133,5 @@ def test_n1_navdp_head_b64_distribution(built_lib, gold):
                                              inp["x_init"].to(DEV), inp["step_noise"].to(DEV))
     mine = _per_env(out, g["trajectories"])
     r = _report("N1 NavDP head B=64 trajectories", mine, g["yard"])
-    _assert_distribution(r)
+    _assert_distribution(r, mine, g["yard"])
+    assert mine[:, 0].max().item() < 1e-3               # every env inside the north-star tolerance (measured: median 5.1e-4, worst 9.3e-4)
