@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default 64; 7 for --workload s2_only)")
-    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "s2_only", "navdp_s1", "unet1d_s1", "sft"],
+    ap.add_argument("--workload", default="n1_dual", choices=["n1_dual", "s2_only", "navdp_s1", "unet1d_s1", "sft", "host_stub"],
                     help="n1_dual = the BASELINE metric's configuration (default); s2_only = config #3 (System-2 calls/s); navdp_s1 = config #2; "
-                         "unet1d_s1 = the diffusion-policy UNet head; sft = config #5 (the SFT step, bench_sft.py: its own flags pass through)")
+                         "unet1d_s1 = the diffusion-policy UNet head; sft = config #5 (the SFT step, bench_sft.py: its own flags pass through); "
+                         "host_stub = no GPU: the multi-rank logic (self-spawn, pinning, action all-gather over gloo) around the real per-step host work")
     ap.add_argument("--cadence", choices=["nominal", "reference"], default="nominal",
                     help="n1_dual: nominal = 1 S2 : 10 S1 per env (the BASELINE metric, default); reference = the agent's own schedule, (1 S2 + 2 S1) per 8 "
                          "actions and env (SURVEY.md 8d, internvla_n1_agent.py:210-241)")
@@ -239,6 +240,43 @@ class UNet1DS1:
         return {"value": round(1.0 / dt, 4), "unit": "policy steps/s", "cores": cores, "cpu": _cpu_model(), "kind": "port",
                 "seconds": {"fp32": round(t32, 2), "bf16_autocast": round(t16, 2)},
                 "sample": "1 env x 1 policy step (32 samples x 10 DDIM steps of the UNet), torch CPU; 1 warm-up + median of 3 runs each for fp32 and bf16-autocast"}
+
+
+class HostStub:
+    """`--workload host_stub` (no GPU, backend gloo): the rank logic of this file - self-spawned ranks, core pinning, the per-step all-gather of
+    the [envs, 4] int32 action table with its content checks, max-over-ranks timing, rank 0 alone in the post-run section while the others wait
+    at the barrier - around the REAL per-step host work of the n1_dual workload: `traj_to_actions` of 64 trajectories [32, 32, 3] per rank
+    (vln_utils.py:36-136, what the reference does per env and step). It answers the question a 1-GPU box cannot: do eight ranks' Python
+    post-processing loops limit the step on one host? The engine time of a step is NOT simulated: `ms_per_step` here is
+    the host floor under the GPU time (2.9 ms at one rank on the GPU box; the side-stream envs' share runs under the GPU tail anyway)."""
+
+    def __init__(self, a, dev, rank):
+        from internnav_amd.policy import traj_to_actions
+
+        self.traj_to_actions, self.B = traj_to_actions, a.envs
+        self.name, self.unit = f"host_stub_b{a.envs}", "policy steps/s"
+        g = torch.Generator().manual_seed(1000 * rank + 7)
+        # random-walk-like trajectories of the System-1 output shape (x4-scaled waypoint increments, 32 samples x 32 steps)
+        self.traj = torch.randn(8, self.B, 32, 32, 3, generator=g) * 0.5 + torch.tensor([0.6, 0.0, 0.0])
+        self.actions = torch.zeros(self.B, 4, dtype=torch.int32)
+        self.action_shape = (self.B, 4)
+        self.f_alg = 0.0
+        self.desc = {"policy": "none (host stub): traj_to_actions of 64 x [32, 32, 3] trajectories per rank and step + the action all-gather over gloo"}
+
+    def capture(self):
+        pass
+
+    def step(self, i):
+        t = self.traj[i % self.traj.shape[0]]
+        acts = np.zeros((self.B, 4), dtype=np.int32)
+        for b in range(self.B):
+            al = [x for x in self.traj_to_actions(t[b]) if x != 0][:4]
+            acts[b, :len(al)] = al
+        self.actions.copy_(torch.from_numpy(acts))
+        return self.actions
+
+    def step_output_for_check(self):
+        return self.actions
 
 
 class N1Dual:
@@ -815,25 +853,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    host_stub = a.workload == "host_stub"
     from internnav_amd import runtime
 
-    arch = runtime.require_gfx950()
+    if host_stub:
+        dev, arch = torch.device("cpu"), "cpu (host stub, gloo)"
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        arch = runtime.require_gfx950()
     dist = None
+    pinned = None
     if world > 1:
         import torch.distributed as dist
 
         from internnav_amd.dist import pin_host_threads
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-        pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # own slice of the host cores per rank
-    wl = {"n1_dual": N1Dual, "s2_only": N1Dual, "navdp_s1": NavDPS1, "unet1d_s1": UNet1DS1}[a.workload](a, dev, rank)
+        if host_stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        pinned = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # own slice of the host cores per rank
+    wl = {"n1_dual": N1Dual, "s2_only": N1Dual, "navdp_s1": NavDPS1, "unet1d_s1": UNet1DS1, "host_stub": HostStub}[a.workload](a, dev, rank)
     if not a.no_graph:
         wl.capture()
     gathered = torch.empty((world * wl.action_shape[0],) + tuple(wl.action_shape[1:]), device=dev,
-                           dtype=torch.int32 if a.workload in ("n1_dual", "s2_only") else torch.float32) if world > 1 else None
+                           dtype=torch.int32 if a.workload in ("n1_dual", "s2_only", "host_stub") else torch.float32) if world > 1 else None
 
     def step(i):
         out = wl.step(i)
@@ -841,10 +887,12 @@ def main():
             dist.all_gather_into_tensor(gathered, out)  # per-env action outputs to every rank (RCCL over xGMI)
 
     def sync():
-        torch.cuda.synchronize()
+        if not host_stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not host_stub:
+                torch.cuda.synchronize()
 
     overlap_check = None
     if getattr(wl, "overlap", False):
@@ -861,7 +909,7 @@ def main():
         # the exchanged actions are really everybody's: this rank's slice equals its own last output, every slice is a valid action table
         mine = wl.step_output_for_check()
         assert torch.equal(gathered[rank * wl.B:(rank + 1) * wl.B], mine), "all_gather: own slice differs from the local actions"
-        if a.workload in ("n1_dual", "s2_only"):
+        if a.workload in ("n1_dual", "s2_only", "host_stub"):
             assert int(gathered.min()) >= 0 and int(gathered.max()) <= 3, "all_gather: action ids outside {0..3}"
         chk = torch.stack([gathered[r * wl.B:(r + 1) * wl.B].double().sum() for r in range(world)])
         ref = chk.clone()
@@ -872,7 +920,16 @@ def main():
         dt = float(t.item())
     value = world * wl.B * a.steps / dt
 
-    if rank == 0:
+    if rank == 0 and host_stub:
+        # rank 0 alone in the post-run section (the GPU workloads run their instrumented pass and the CPU baseline here) while the others wait
+        time.sleep(0.2)
+        print(json.dumps({"metric": "policy steps/sec/node", "value": round(value, 2), "unit": "policy steps/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "int32", "data": "synthetic trajectories", "rccl_ranks": 0, "gloo_ranks": world,
+                          "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}", "device": arch,
+                                          "host_cores_per_rank": pinned, "host_cores": len(os.sched_getaffinity(0)) if pinned is None else None}, **wl.desc),
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    elif rank == 0:
         calib = calibration_gemm(dev)
         # ---- roofline: one instrumented eager pass, HIP events around every launch on the launch stream
         runtime.prof_enable(True)

@@ -240,6 +240,9 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
             if (cfg == 18 && p.R && p.out_dtype == INA_DT_F32 && p.K <= 4096) cfg = 33;
         }
     }
+    if (cfg >= 34 && cfg <= 37)
+        INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34-37 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
+                    "no bias / scale / residual, act none or SiLU-GLU (M=%d N=%d K=%d)", p.M, p.N, p.K);
     kernel = cfg;
     return 0;
 }
@@ -262,6 +265,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
         case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 34: case 35: case 36: case 37: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

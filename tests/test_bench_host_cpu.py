@@ -67,3 +67,30 @@ def test_cadence_schedules_cover_every_env_as_the_reference_agent_does():
     # System-2 only: everybody, every step
     P_, s2, side = _schedule("s2_only", 7)
     assert s2 == [list(range(7))] and side == [[]]
+
+
+def test_bench_rank_logic_world8_gloo_host_stub():
+    """`python bench.py --gpus 8 --workload host_stub` on CPU: the file's multi-rank path end to end without a GPU -
+    self-spawn of 8 ranks through torch.distributed.run on 127.0.0.1, per-rank core pinning, the per-step all-gather of the [64, 4] int32
+    action table with its content asserts (own slice, valid ids, same bytes on every rank), max-over-ranks timing, rank 0 alone in the
+    post-run section - around the real per-step host work (64 x traj_to_actions per rank). One JSON line, whole-job value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8", "--workload", "host_stub", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["gloo_ranks"] == 8 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp8" and d["config"]["envs_per_gpu"] == 64
+    # whole-job aggregate: 8 ranks x 64 envs x steps / max-over-ranks time
+    assert abs(d["value"] - 8 * 64 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    print(f"8 ranks x 64 traj_to_actions per step on {len(os.sched_getaffinity(0))} host cores: {d['ms_per_step']:.1f} ms per step "
+          f"({d['config']['host_cores_per_rank']} core(s) per rank)")

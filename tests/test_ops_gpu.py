@@ -694,3 +694,48 @@ def test_rope_with_fused_kv_append_equals_rope_then_gather(ops):
     assert torch.equal(cache_a, cache_b)
     assert torch.equal(a[:, : nh * D], b[:, : nh * D])                     # rotated queries
     assert torch.equal(b[:, nh * D:], qkv[:, nh * D:])                      # k / v columns untouched in the fused form
+
+
+@pytest.mark.parametrize("cfg", [34, 35, 36, 37])
+@pytest.mark.parametrize("M,N,glu", [(32, 128, False), (7168, 1536, False), (8224, 2048, True), (4128, 256, True), (65536, 1536, False)])
+def test_gemm_rowpanel_k384(ops, cfg, M, N, glu):
+    """row-panel kernels of the d = 384 heads (csrc/gemm_rowpanel.hip: activations as register-resident MFMA fragments, W streamed through an
+    LDS ring, 32x32x16 MFMAs): against the fp32 product of the bf16 operands and against the tiled kernel they replace, on row counts with a
+    partial last workgroup (M % 256 != 0) and on strided views of wider buffers (the engine's fused projection / activation buffers)."""
+    g = torch.Generator().manual_seed(M + N + cfg)
+    K = 384
+    xw = _rand((M, K + 64), g)                  # row-strided A
+    x = xw[:, :K]
+    w = _rand((N, K), g, scale=K ** -0.5)
+    n_out = N // 2 if glu else N
+    outw = torch.zeros(M, n_out + 8, dtype=torch.bfloat16, device=_dev())
+    out = outw[:, :n_out]
+    if glu:
+        ops.linear(x, w, act="silu", glu=True, out=out, force_cfg=cfg)
+        tiled = ops.linear(x, w, act="silu", glu=True, force_cfg=22)
+        wg = w.view(N // 32, 2, 16, K)[:, 0].reshape(N // 2, K)
+        wu = w.view(N // 32, 2, 16, K)[:, 1].reshape(N // 2, K)
+        ref = torch.nn.functional.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t())
+    else:
+        ops.linear(x, w, out=out, force_cfg=cfg)
+        tiled = ops.linear(x, w, force_cfg=22)
+        ref = x.float() @ w.float().t()
+    torch.cuda.synchronize()
+    _close(out, ref)
+    assert float(outw[:, n_out:].abs().max()) == 0.0, "columns beyond the output were written"
+    # same bf16 result as the tiled kernel up to the rounding of a different K summation order (16- vs 32-wide MFMA steps)
+    d = (out.float() - tiled.float()).abs()
+    assert d.max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item()) and (d > 0).float().mean().item() < 0.2
+
+
+def test_gemm_rowpanel_rejects_what_it_does_not_compute(ops):
+    g = torch.Generator().manual_seed(3)
+    x, w = _rand((64, 384), g), _rand((256, 384), g)
+    bias = torch.zeros(256, device=_dev())
+    for kw in (dict(bias=bias), dict(out_dtype=torch.float32), dict(act="gelu")):
+        with pytest.raises(Exception):
+            ops.linear(x, w, force_cfg=34, **kw)
+    with pytest.raises(Exception):
+        ops.linear(_rand((48, 384), g)[:40], w, force_cfg=35)            # M % 32 != 0
+    with pytest.raises(Exception):
+        ops.linear(_rand((64, 512), g), _rand((256, 512), g), force_cfg=34)   # K != 384

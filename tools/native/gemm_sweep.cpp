@@ -55,6 +55,20 @@ __global__ void count_diff(const uint32_t* a, const uint32_t* b, size_t n32, uns
     if (d) atomicAdd(out, d);
 }
 
+// bf16 outputs that differ in bits (a kernel with another K summation order): max |a - b| and max |a| over the elements
+__global__ void max_diff_bf16(const uint16_t* a, const uint16_t* b, size_t n, unsigned int* out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float d = 0.f, m = 0.f;
+    for (; i < n; i += stride) {
+        const float x = __uint_as_float((uint32_t)a[i] << 16), y = __uint_as_float((uint32_t)b[i] << 16);
+        d = fmaxf(d, fabsf(x - y));
+        m = fmaxf(m, fabsf(x));
+    }
+    atomicMax(out, __float_as_uint(d));          // non-negative floats order like their bit patterns
+    atomicMax(out + 1, __float_as_uint(m));
+}
+
 struct Buf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -178,6 +192,15 @@ int main(int argc, char** argv) {
                 }
                 printf("  cfg%d/g%d %7.1f us %6.1f TF%s", cfg, gm, us, tf(s, us), first ? "" : (d ? " DIFF" : " ="));
                 if (d) printf("(%llu)", d);
+                if (d && !res) {     // bf16 outputs: how far apart (kernels with a different K summation order differ in the last bits)
+                    unsigned int mm[2] = {0, 0};
+                    HIP_OK(hipMemsetAsync(cnt.p, 0, 8, 0));
+                    hipLaunchKernelGGL(max_diff_bf16, dim3(2048), dim3(256), 0, 0, (const uint16_t*)C0.p, (const uint16_t*)C1.p, out_bytes / 2, (unsigned int*)cnt.p);
+                    HIP_OK(hipMemcpy(mm, cnt.p, 8, hipMemcpyDeviceToHost));
+                    float fd, fm;
+                    memcpy(&fd, &mm[0], 4); memcpy(&fm, &mm[1], 4);
+                    printf("[max|d| %.3g of max %.3g]", fd, fm);
+                }
                 first = 0;
             }
             printf("\n");
