@@ -214,6 +214,14 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
         // short K and a wide output (the d = 384 heads' fused q|k|v|q2 / SwiGLU projections, K = 384): 48 KiB single-buffer tiles with 85
         // instead of 64 FLOP per operand byte, 3 workgroups per CU: +14-15 % (740-816 vs 632-704 TF/s, profiles/r02m_gemm_s1_tile_sweep.log)
         if (p.K <= 512 && p.N >= 1024 && p.M >= 4096) cfg = p.N >= 1536 ? 26 : 27;
+        // K = 384, wide output, many rows, plain or SwiGLU epilogue (the fused q|k|v|q2 and SwiGLU projections of a NextDiT block over >= 16 envs):
+        // row-panel kernels - activations as register-resident MFMA fragments, only W streams through LDS (gemm_rowpanel.hip). Bit-equal
+        // to the tiled kernels. Isolated they are within +-10 % of cfg 26 (0.75-0.86 PF/s, profiles/r04b_native_rowpanel.log); inside the
+        // System-1 call, where the tiled kernel's operands start cold, the call of 64 envs goes 84.2 -> 75.0 ms (r04f_s1_variants.log).
+        // Below ~16 k rows their one-workgroup-per-256-rows grid leaves the chip empty (7168 rows: 72 vs 17 us).
+        // The bias + activation epilogue of those kernels exists (force_cfg 34 / 35) but is NOT selected: the biased q|k|v / GELU-FFN
+        // projections of the NavDP decoder (49152 x 1152 / 1536) lose on it - NavDPNet call of 64 envs 186.5 vs 146.0 ms (r04g_navdp_variants.log).
+        if (p.M >= 16384 && !p.bias && (p.glu || p.act == INA_ACT_NONE) && ina_gemm_rowpanel_contract(p)) cfg = p.glu ? 35 : 34;
         if (p.K >= 768 && p.N > 512) {   // narrow outputs (N = 384 heads): 128x128 measured 6-15 % ahead of 256x128 at K = 1024 / 1536
             // force_cfg = -1 (INA_GEMM_AUTO_SHARED): auto selection for a launch that runs BESIDE another stream's GEMMs (the two half
             // micro-batches of the System-2 prefill): the CUs its last round leaves idle are taken by the other stream's workgroups, so
@@ -242,7 +250,7 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     }
     if (cfg >= 34 && cfg <= 37)
         INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34-37 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
-                    "no bias / scale / residual, act none or SiLU-GLU (M=%d N=%d K=%d)", p.M, p.N, p.K);
+                    "no scales / residual, bias + activation or SiLU-GLU (M=%d N=%d K=%d)", p.M, p.N, p.K);
     kernel = cfg;
     return 0;
 }
@@ -266,6 +274,9 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
         case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         case 34: case 35: case 36: case 37: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
+#ifdef INA_RP_EXPERIMENTS
+        case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: return ina_launch_gemm_rowpanel(p, stream, cfg);
+#endif
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

@@ -66,8 +66,11 @@ def test_vision_block_gemms(select, rows, plain, shared):
 
 def test_d384_heads_and_odd_shapes(select):
     for rows in (65536, 58368, 7168):            # 64 / 57 / 7 envs x 32 samples x 32 tokens
-        assert select(rows, 1536, 384) == 26      # fused q|k|v|q2: 128 x 256 single buffer, 3 workgroups / CU
-        assert select(rows, 2048, 384, **GLU) == 26
+        big = rows >= 16384                        # round 4: the row-panel kernels (34 / 35, gemm_rowpanel.hip) from 16 envs x 1024 rows on
+        assert select(rows, 1536, 384) == (34 if big else 26)      # fused q|k|v|q2; below: 128 x 256 single buffer, 3 workgroups / CU
+        assert select(rows, 2048, 384, ldc=1024, **GLU) == (35 if big else 26)
+        assert select(rows, 1536, 384, bias=0x3000, act=1) == 26   # bias + activation (NavDP decoder FFN): measured slower on the row-panel kernel, stays tiled
+        assert select(rows, 1536, 384, colscale=0x3000) == 26      # a LayerScale is outside the row-panel contract: tiled kernel
         assert select(rows, 384, 384, **RES) == 22    # N = 384 with the fp32-residual epilogue: 128 x 128 single buffer, 4 workgroups / CU
         assert select(rows, 384, 1024, **RES) == 22
     assert select(21952, 1280, 1176) == 1         # patch embed: K % 64 != 0 -> register-staged kernel

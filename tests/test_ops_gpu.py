@@ -732,10 +732,28 @@ def test_gemm_rowpanel_rejects_what_it_does_not_compute(ops):
     g = torch.Generator().manual_seed(3)
     x, w = _rand((64, 384), g), _rand((256, 384), g)
     bias = torch.zeros(256, device=_dev())
-    for kw in (dict(bias=bias), dict(out_dtype=torch.float32), dict(act="gelu")):
+    res = torch.zeros(64, 256, device=_dev())
+    for kw in (dict(out_dtype=torch.float32), dict(colscale=bias), dict(residual=res, out_dtype=torch.float32), dict(bias=bias, act="silu", glu=True)):
         with pytest.raises(Exception):
             ops.linear(x, w, force_cfg=34, **kw)
     with pytest.raises(Exception):
         ops.linear(_rand((48, 384), g)[:40], w, force_cfg=35)            # M % 32 != 0
     with pytest.raises(Exception):
         ops.linear(_rand((64, 512), g), _rand((256, 512), g), force_cfg=34)   # K != 384
+
+
+@pytest.mark.parametrize("cfg", [34, 35])
+@pytest.mark.parametrize("M,N,act", [(49152, 1152, None), (49152, 1536, "gelu"), (2080, 1024, "relu"), (64, 128, "gelu_tanh")])
+def test_gemm_rowpanel_bias_activation_epilogue(ops, cfg, M, N, act):
+    """the biased projections of the nn.Transformer layers at d = 384 (NavDP decoder q|k|v N = 1152, FFN N = 1536 + GELU) on the row-panel
+    kernels: bias from an LDS copy, activation in registers; bit-equal to the tiled kernel's epilogue (same K order, same fp32 epilogue math)."""
+    g = torch.Generator().manual_seed(M + N)
+    x, w = _rand((M, 384), g), _rand((N, 384), g, scale=384 ** -0.5)
+    bias = torch.randn(N, generator=g).to(_dev())
+    out = ops.linear(x, w, bias=bias, act=act, force_cfg=cfg)
+    tiled = ops.linear(x, w, bias=bias, act=act, force_cfg=22)
+    y = x.float() @ w.float().t() + bias
+    ref = {None: lambda t: t, "gelu": torch.nn.functional.gelu, "relu": torch.relu, "gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh")}[act](y)
+    _close(out, ref)
+    d = (out.float() - tiled.float()).abs()
+    assert d.max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item()) and (d > 0).float().mean().item() < 0.05
