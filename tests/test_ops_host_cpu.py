@@ -122,4 +122,4 @@ def test_rowpanel_contract_through_gemm_select(built_lib):
     assert sel(65536, 1536, 384, 34) == 34 and sel(7168, 2048, 384, 35, glu=1, act=4, ldc=1024) == 35
     assert sel(65536, 1536, 512, 34) is None and sel(65536, 1500, 384, 34) is None and sel(100, 1536, 384, 35) is None
     assert sel(65536, 1536, 384, 34, out_dtype=1) is None and sel(65536, 2048, 384, 34, glu=1, act=0) is None and sel(65536, 2048, 384, 34, glu=1, act=4, bias=0x3000) is None
-    assert sel(49152, 1152, 384, 34, bias=0x3000) == 34 and sel(49152, 1536, 384, 35, bias=0x3000, act=1) == 35 and sel(49152, 1152, 384, 0, bias=0x3000) == 26
+    assert sel(49152, 1152, 384, 34, bias=0x3000) == 34 and sel(49152, 1536, 384, 35, bias=0x3000, act=1) == 35 and sel(49152, 1152, 384, 0, bias=0x3000) == 27
