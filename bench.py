@@ -951,10 +951,11 @@ def main():
             "frac_gemm_class_blend": round(blend / PEAK_BF16_TFLOPS, 4),
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_tflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e12, 4),
+            "algorithmic_mbytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1) / 1e6, 1),      # operands + output once (2MK + 2NK + out)
             "traffic": pmc_traffic(a.workload),
             "gemm_class_blend": {"what": "all tiled MFMA GEMM launches of the instrumented pass (every tile config)", "achieved": round(blend, 1),
                                  "frac": round(blend / PEAK_BF16_TFLOPS, 4)},
-            "per_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["flops"] / 1e12, 3),
+            "per_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["flops"] / 1e12, 3), "gbyte": round(v.get("bytes", 0.0) / 1e9, 2),
                                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)} for k, v in per_kernel.items()},
             "instrumented_pass": {"what": extra if isinstance(extra, str) else "one engine call over all envs",
                                   "gemm_launches": gm["launches"], "gemm_avg_launch_us": round(gm["ms"] * 1e3 / max(gm["launches"], 1), 2),

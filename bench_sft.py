@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=10, help="images in the System-2 prompt (8 history + current + look-down)")
     ap.add_argument("--zero2", action="store_true", help="reduce-scatter + sharded update + all-gather instead of all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph-s1", action="store_true", help="System-1 loss + backward as eager launches (round-3 path) instead of one hipGraph replay")
     return ap.parse_args()
 
 
@@ -58,7 +59,7 @@ def build(a, dev, rank):
     eng = QwenVLEngine(weights, qcfg, dev, max_seqs=B, max_seq_len=(S + qcfg["n_query"] + 63) // 64 * 64, max_patches=B * F * per)
     sd_s = {k: v.float() for k, v in synthetic.materialize(synthetic.n1_nextdit_spec(), 0).items()}
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2)
+    tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1)
     tr.step_idx = 10          # past the warm-up: non-zero learning rate
     g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
     lim = qcfg["image_token_id"] - 16

@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
@@ -131,6 +131,8 @@ typedef struct ina_attn_args {
                              * contract: d 64 / 80 / 128, Lq and Lk >= 128, no head gate / accumulate / dropout). Same result up to the bf16
                              * rounding of P and O; parity tests pin both and compare them. */
     int32_t _pad0;
+    const uint32_t* drop_salt; /* training, optional: one device word ADDED to drop_seed when the kernel starts - a launch sequence captured in a
+                                * hipGraph draws fresh masks on every replay (the host bumps the word between replays); NULL = drop_seed alone */
 } ina_attn_args;
 int ina_attention_bf16(const ina_attn_args* args, void* stream);
 
@@ -490,6 +492,7 @@ typedef struct ina_ew_args {
     int32_t s_div, s_f, tab_mod, act, accumulate; /* accumulate: Y += */
     uint32_t drop_seed, drop_thresh;
     float drop_scale;
+    const uint32_t* drop_salt; /* optional device word added to drop_seed (see ina_attn_args.drop_salt) */
 } ina_ew_args;
 int ina_ew(const ina_ew_args* args, void* stream);
 

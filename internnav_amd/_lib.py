@@ -41,7 +41,7 @@ class AttnArgs(C.Structure):
         ("scale", c_float),
         ("cu_q", c_void_p), ("cu_k", c_void_p), ("head_gate", c_void_p), ("k_len", c_void_p),
         ("accumulate", c_int32), ("drop_seed", C.c_uint32), ("drop_thresh", C.c_uint32), ("drop_scale", c_float),
-        ("kernel", c_int32), ("_pad0", c_int32),
+        ("kernel", c_int32), ("_pad0", c_int32), ("drop_salt", c_void_p),
     ]
 
 
@@ -217,7 +217,7 @@ class EwArgs(C.Structure):
                 ("a_dt", c_int32), ("b_dt", c_int32), ("d_dt", c_int32), ("s_dt", c_int32), ("y_dt", c_int32), ("y2_dt", c_int32),
                 ("lda", c_int32), ("ldb", c_int32), ("ldd", c_int32), ("lds", c_int32), ("ldy", c_int32), ("ldy2", c_int32),
                 ("s_div", c_int32), ("s_f", c_int32), ("tab_mod", c_int32), ("act", c_int32), ("accumulate", c_int32),
-                ("drop_seed", C.c_uint32), ("drop_thresh", C.c_uint32), ("drop_scale", c_float)]
+                ("drop_seed", C.c_uint32), ("drop_thresh", C.c_uint32), ("drop_scale", c_float), ("drop_salt", c_void_p)]
 
 
 class ColsumArgs(C.Structure):

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs p) {
             for (int t = 0; t < NST; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    s[t][r] = ina_hash(p.drop_seed, row + kv0 + t * 16 + g * 4 + r) >= p.drop_thresh ? s[t][r] * p.drop_scale : 0.f;
+                    s[t][r] = ina_hash(p.drop_seed + (p.drop_salt ? *p.drop_salt : 0u), row + kv0 + t * 16 + g * 4 + r) >= p.drop_thresh ? s[t][r] * p.drop_scale : 0.f;
         }
         // ---- O^T += V^T . P^T
 #pragma unroll

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
                     const float pr = ok ? exp2f(s[t][r] * sc - lse2) : 0.f;
                     float dpm = dp[t][r];
                     if (p.drop_thresh)   // dropout on P: dL/dP = mask / (1 - p) * (dO . v)
-                        dpm = ina_hash(p.drop_seed, ((uint64_t)((size_t)b * p.H + h) * p.Lq + q_abs) * p.Lk + kv) >= p.drop_thresh ? dpm * p.drop_scale : 0.f;
+                        dpm = ina_hash(p.drop_seed + (p.drop_salt ? *p.drop_salt : 0u), ((uint64_t)((size_t)b * p.H + h) * p.Lq + q_abs) * p.Lk + kv) >= p.drop_thresh ? dpm * p.drop_scale : 0.f;
                     s[t][r] = pr * (dpm - dl) * p.scale;   // dS
                 }
             }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_kernel(AttnBwdArgs a) {
                     const bool ok = live && q < len_q && (!p.causal || k_abs <= q + causal_shift);
                     const float pr = ok ? exp2f(s[t][r] * sc - st[ql]) : 0.f;
                     float m = 1.f;
-                    if (p.drop_thresh) m = ina_hash(p.drop_seed, ((uint64_t)((size_t)b * p.H + h) * p.Lq + q) * p.Lk + k_abs) >= p.drop_thresh ? p.drop_scale : 0.f;
+                    if (p.drop_thresh) m = ina_hash(p.drop_seed + (p.drop_salt ? *p.drop_salt : 0u), ((uint64_t)((size_t)b * p.H + h) * p.Lq + q) * p.Lk + k_abs) >= p.drop_thresh ? p.drop_scale : 0.f;
                     dp[t][r] = pr * (dp[t][r] * m - st[CB + ql]) * p.scale;   // dS
                     s[t][r] = pr * m;                                          // dropped P (what multiplied V in the forward pass)
                 }

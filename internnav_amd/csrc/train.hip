@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ew_kernel(EwArgs p) {
                 break;
             }
             case INA_EW_DROPOUT:
-                y = ina_hash(p.drop_seed, (uint64_t)r * p.C + c) >= p.drop_thresh ? ldf(p.A, p.a_dt, (size_t)r * p.lda + c) * p.drop_scale : 0.f;
+                y = ina_hash(p.drop_seed + (p.drop_salt ? *p.drop_salt : 0u), (uint64_t)r * p.C + c) >= p.drop_thresh ? ldf(p.A, p.a_dt, (size_t)r * p.lda + c) * p.drop_scale : 0.f;
                 break;
             default: break;
         }
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void ew_vec_kernel(EwArgs p) {
             }
             case INA_EW_DROPOUT:
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = ina_hash(p.drop_seed, (uint64_t)r * p.C + c + j) >= p.drop_thresh ? av[j] * p.drop_scale : 0.f;
+                for (int j = 0; j < 4; ++j) y[j] = ina_hash(p.drop_seed + (p.drop_salt ? *p.drop_salt : 0u), (uint64_t)r * p.C + c + j) >= p.drop_thresh ? av[j] * p.drop_scale : 0.f;
                 break;
             default: break;
         }

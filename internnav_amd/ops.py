@@ -121,7 +121,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
               cu_k: Optional[torch.Tensor] = None, max_q: int = 0, max_k: int = 0,
               head_gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               accumulate: bool = False, k_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
-              kernel: int = 0) -> torch.Tensor:
+              kernel: int = 0, drop_salt: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T * scale [+ masks]) v.   kernel: 0 = automatic, 1 = the 16-rows-per-wave kernel, 2 = the 32-rows-per-wave kernel
     (ina_attn_args.kernel; the parity tests compare the two).
 
@@ -170,6 +170,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
     if drop_p > 0.0:       # training only: attention-probability dropout, mask = counter hash of (seed, element index)
         assert cu_q is None, "dropout: dense layouts only"
         a.drop_seed, a.drop_thresh, a.drop_scale = drop_params(drop_p, drop_seed)
+        if drop_salt is not None:          # one int32 device word added to the seed at kernel start (fresh masks per replay of a captured launch sequence)
+            assert drop_salt.dtype == torch.int32 and drop_salt.numel() == 1 and drop_salt.is_cuda
+            a.drop_salt = drop_salt.data_ptr()
     _lib.check(_lib.lib().ina_attention_bf16(C.byref(a), _stream()), "attention_bf16")
     return out
 

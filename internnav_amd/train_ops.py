@@ -23,7 +23,7 @@ def _2d(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def _ew(op, A, B=None, D=None, S=None, s_div=1, s_f=0, tab=None, act=0, out=None, out2=None, out_dtype=None, accumulate=False, drop=None):
+def _ew(op, A, B=None, D=None, S=None, s_div=1, s_f=0, tab=None, act=0, out=None, out2=None, out_dtype=None, accumulate=False, drop=None, drop_salt=None):
     A = _2d(A)
     rows, Cd = A.shape
     if out is None:
@@ -56,6 +56,8 @@ def _ew(op, A, B=None, D=None, S=None, s_div=1, s_f=0, tab=None, act=0, out=None
     a.accumulate = 1 if accumulate else 0
     if drop is not None:
         a.drop_seed, a.drop_thresh, a.drop_scale = drop
+        if drop_salt is not None:
+            a.drop_salt = _salt_ptr(drop_salt)
     _lib.check(_lib.lib().ina_ew(C.byref(a), _stream()), "ew")
     return out
 
@@ -74,12 +76,18 @@ def act_bwd(x, dy, act, out=None, out_dtype=None, accumulate=False):
     return _ew(EW_ACT_BWD, x, B=dy, act=ACT[act], out=out, out_dtype=out_dtype or dy.dtype, accumulate=accumulate)
 
 
-def dropout(x, p: float, seed: int, out=None, out_dtype=None):
+def _salt_ptr(salt: torch.Tensor) -> int:
+    """device word added to a dropout seed when the kernel starts (ina_*_args.drop_salt): int32 [1] on the launch device"""
+    assert salt.dtype == torch.int32 and salt.numel() == 1 and salt.is_cuda, "drop_salt: one int32 device word"
+    return salt.data_ptr()
+
+
+def dropout(x, p: float, seed: int, out=None, out_dtype=None, salt=None):
     """nn.Dropout in train mode with the library's counter-based mask (element index = r * C + c of the [rows, C] tensor); applying
     it to dy with the same (p, seed) is the backward."""
     from .ops import drop_params
 
-    return _ew(EW_DROPOUT, x, out=out, out_dtype=out_dtype, drop=drop_params(p, seed))
+    return _ew(EW_DROPOUT, x, out=out, out_dtype=out_dtype, drop=drop_params(p, seed), drop_salt=salt)
 
 
 def glu_fwd(a, b, out=None):
@@ -295,7 +303,7 @@ def gemm_nn(x, w, out=None, out_dtype=torch.float32, splits: Optional[int] = Non
 
 
 def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=1, dq=None, dk=None, dv=None, kv_row0=0, need_dkv=True,
-                  nsplit: Optional[int] = None, drop_p: float = 0.0, drop_seed: int = 0):
+                  nsplit: Optional[int] = None, drop_p: float = 0.0, drop_seed: int = 0, drop_salt=None):
     """backward of ops.attention (dense): q/o/do [B, Lq, H, D], k/v [Bk, Lk, Hkv, D] (last dim contiguous, other strides free).
     Returns (dq [B,Lq,H,D], dk, dv [B, Lk - kv_row0, H, D]) - dk / dv are per QUERY head (sum GQA groups outside)."""
     assert q.dtype == k.dtype == v.dtype == o.dtype == do.dtype == torch.bfloat16
@@ -328,6 +336,8 @@ def attention_bwd(q, k, v, o, do, scale=None, causal=False, k_len=None, kv_bdiv=
         from .ops import drop_params
 
         f.drop_seed, f.drop_thresh, f.drop_scale = drop_params(drop_p, drop_seed)
+        if drop_salt is not None:
+            f.drop_salt = _salt_ptr(drop_salt)
         nsplit = 1
     if nsplit is None:      # few query rows against a long key axis: spread the keys over the chip
         nsplit = min(32, (Lk + 127) // 128) if (Lq <= 32 and Lk >= 512) else 1

@@ -58,10 +58,16 @@ class InternVLAN1SftTrainer:
     def __init__(self, engine: QwenVLEngine, s1_state_dict: Dict[str, torch.Tensor], device, total_steps: int = 1000, lr: float = 1e-4,
                  min_lr: float = 1e-5, warmup_ratio: float = 0.003, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False, system1: str = "nextdit_async",
-                 s1_cfg: Optional[dict] = None, dropout: float = 0.1, seed: int = 0):
+                 s1_cfg: Optional[dict] = None, dropout: float = 0.1, seed: int = 0, graph_s1: bool = False):
         """system1: 'nextdit_async' (flow-matching loss on the NextDiT head) or 'navdp_async' (epsilon loss on the NavDP head; `s1_cfg` =
-        its hyper-parameters, synthetic.N1_NAVDP_CFG; the batch then also carries `traj_depths` [B, T, 224, 224] in metres)."""
+        its hyper-parameters, synthetic.N1_NAVDP_CFG; the batch then also carries `traj_depths` [B, T, 224, 224] in metres).
+        graph_s1: the System-1 loss + backward of a micro-batch (a few thousand fixed-shape launches of the tape, launch-bound when issued
+        one by one) is captured into a hipGraph per batch geometry and replayed; dropout masks stay fresh through a device-side seed word
+        (`ina_*_args.drop_salt`) that is rewritten before every replay."""
         self.engine, self.device = engine, torch.device(device)
+        self.graph_s1 = bool(graph_s1)
+        self._s1_graphs: Dict[tuple, tuple] = {}
+        self._salt = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device.type == "cuda" else None
         nq, H = engine.latent_q.shape
         sd = dict(s1_state_dict)
         sd[LQ] = sd.get(LQ, engine.latent_q.float().view(1, nq, H).cpu())
@@ -149,18 +155,72 @@ class InternVLAN1SftTrainer:
         Tn = batch["traj_images"].shape[1]
         if noise is None:            # internvla_n1.py:261-264 / navdp.py:163-175 (the reference draws inside forward)
             noise = torch.randn(B * Tn, *batch["traj_poses"].shape[2:], device=dev, generator=self.gen_dev)
-        if self.system1 == "nextdit_async":
-            if t_index is None:
+        if t_index is None:
+            if self.system1 == "nextdit_async":
                 t_index = (torch.rand(B * Tn, generator=self.gen_cpu) * 1000).long()
+            else:
+                t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,), generator=self.gen_cpu)
+        if self.graph_s1:
+            loss, dh = self._s1_graphed(hq, batch, noise, t_index, loss_scale)
+        elif self.system1 == "nextdit_async":
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index,
                                                 loss_scale=loss_scale, seed=self._mask_seed())
         else:
-            if t_index is None:
-                t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,), generator=self.gen_cpu)
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_depths"].to(dev), batch["traj_poses"],
                                                 batch["video_frame_num"], noise, t_index, loss_scale=loss_scale, seed=self._mask_seed())
         self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
         return loss
+
+    def _s1_graphed(self, hq: torch.Tensor, batch: dict, noise: torch.Tensor, t_index: torch.Tensor, loss_scale: float):
+        """System-1 loss + backward as ONE hipGraph replay. The tape's launch sequence depends on the batch geometry only, so it is captured
+        once per (shapes, loss_scale) over static device buffers; a step copies its inputs into them, writes this micro-step's mask seed
+        into the device word the mask kernels add to their (baked) site seeds, and replays. Gradients accumulate into the flat store exactly
+        as in the eager path (the warm-up runs of the capture are undone)."""
+        from .runtime import GraphedCall
+
+        dev, nav = self.device, self.system1 == "navdp_async"
+        names = ["traj_images", "traj_poses"] + (["traj_depths"] if nav else [])
+        key = (tuple(hq.shape), tuple(noise.shape), float(loss_scale)) + tuple(tuple(batch[n].shape) for n in names)
+        ent = self._s1_graphs.get(key)
+        if ent is None:
+            st = {n: torch.empty(batch[n].shape, dtype=torch.float32, device=dev) for n in names}
+            st["hq"] = torch.empty_like(hq)
+            st["noise"] = torch.empty(noise.shape, dtype=torch.float32, device=dev)
+            st["t"] = torch.empty(t_index.shape, dtype=torch.int64, device=dev)
+            st["vfn"] = torch.empty(batch["video_frame_num"].shape, dtype=torch.int64, device=dev)
+
+            def stage():
+                st["hq"].copy_(hq)
+                st["noise"].copy_(noise)
+                st["t"].copy_(t_index)
+                st["vfn"].copy_(torch.as_tensor(batch["video_frame_num"]))
+                for n in names:
+                    st[n].copy_(batch[n])
+            stage()
+
+            def run():
+                if nav:
+                    return self.head.loss_and_grads(st["hq"], st["traj_images"], st["traj_depths"], st["traj_poses"], st["vfn"], st["noise"], st["t"],
+                                                    loss_scale=loss_scale, seed=0, salt=self._salt)
+                return self.head.loss_and_grads(st["hq"], st["traj_images"], st["traj_poses"], st["vfn"], st["noise"], st["t"],
+                                                loss_scale=loss_scale, seed=0, salt=self._salt)
+            keep = self.P.g32.clone()                    # the capture's warm-up runs execute the tape for real: undo their accumulation
+            g = GraphedCall(run, {}, warmup=1)
+            self.P.g32.copy_(keep)
+            del keep
+            ent = (g, st, stage)
+            self._s1_graphs[key] = ent
+        else:
+            g, st, _ = ent
+            st["hq"].copy_(hq)
+            st["noise"].copy_(noise)
+            st["t"].copy_(t_index)
+            st["vfn"].copy_(torch.as_tensor(batch["video_frame_num"]))
+            for n in names:
+                st[n].copy_(batch[n])
+        self._salt.fill_(self._mask_seed())
+        loss, dh = g()
+        return loss, dh
 
     def _mask_seed(self) -> int:
         """dropout-mask seed of this micro-step: (seed, rank, micro_idx) hashed together (a linear mix collides across ranks / steps)."""

@@ -181,7 +181,7 @@ def mse_masked(pred, target, mask, T, loss_scale=1.0, want_grad=True):
     return loss, (2.0 * m * e / denom * loss_scale if want_grad else None)
 
 
-def dropout(x, p, seed, out=None, out_dtype=None):
+def dropout(x, p, seed, out=None, out_dtype=None, salt=None):
     assert COUNT_ONLY, "the CPU stand-in covers the eval-mode graph (dropout = 0)"
     return _store(out, x.float(), out_dtype or x.dtype)
 

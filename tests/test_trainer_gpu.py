@@ -104,3 +104,50 @@ def test_navdp_async_training_step_runs(built_lib):
     tr.reduce_gradients()
     tr.optimizer_step()
     assert not torch.equal(before, eng.latent_q) and float(tr.P.g32.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("system1", ["nextdit_async", "navdp_async"])
+def test_graphed_system1_step_equals_eager_and_redraws_masks(built_lib, system1):
+    """`graph_s1=True`: the System-1 loss + backward as ONE hipGraph replay per micro-batch. Without dropout the replayed
+    launch sequence is the eager one - same loss, same gradients (up to the atomics' summation order), on the first use (capture) and on later replays with new inputs,
+    and across gradient accumulation. With dropout the captured seeds are constants, the masks must still change from step to step: the kernels
+    add a device word (`drop_salt`) that the trainer rewrites before every replay - two replays on the same inputs give different losses,
+    and a replay with the word set back reproduces the first."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+    from internnav_amd.trainer import InternVLAN1SftTrainer
+
+    cfg = W.QWEN_TEST_CFG
+    B, T = 2, 2
+    sd_q = W.qwen_state_dict(seed=11, cfg=cfg)
+    nav = system1 == "navdp_async"
+    sd_s = {k: v.float() for k, v in S.materialize(S.n1_navdp_spec() if nav else S.n1_nextdit_spec(), 3).items()}
+    batch, noise, t_index, inp = _batch(cfg, B, T)
+    batch2, noise2, t_index2, _ = _batch(cfg, B, T, seed=4)
+    if nav:
+        batch["traj_depths"] = torch.rand(B, T, 224, 224) * 5.0
+        batch2["traj_depths"] = torch.rand(B, T, 224, 224) * 4.0
+        t_index, t_index2 = torch.tensor([3, 7, 11, 19]), torch.tensor([1, 2, 15, 8])
+    kw = dict(total_steps=100, system1=system1, s1_cfg=S.N1_NAVDP_CFG if nav else None)
+    eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+    eager = InternVLAN1SftTrainer(eng, sd_s, DEV, dropout=0.0, **kw)
+    graph = InternVLAN1SftTrainer(eng, sd_s, DEV, dropout=0.0, graph_s1=True, **kw)
+    for k, (b_, n_, t_) in enumerate(((batch, noise, t_index), (batch2, noise2, t_index2), (batch, noise, t_index))):
+        le = eager.forward_backward(b_, n_.to(DEV), t_, loss_scale=0.5)
+        lg = graph.forward_backward(b_, n_.to(DEV), t_, loss_scale=0.5)
+        assert torch.equal(le, lg), (k, le.item(), lg.item())
+        # (the attention backward sums dQ over key splits with fp32 atomics: two runs of the SAME launch sequence agree to ~1e-5 relative, not bit for bit)
+        d = (eager.P.g32 - graph.P.g32).norm().item() / eager.P.g32.norm().item()
+        assert d < 1e-4, f"micro-step {k}: accumulated gradients differ by {d:.3e}"        # (accumulates over the three)
+    assert len(graph._s1_graphs) == 1
+    # dropout: fresh masks per replay through the device-side seed word
+    drop = InternVLAN1SftTrainer(eng, sd_s, DEV, dropout=0.1, graph_s1=True, **kw)
+    l1 = drop.forward_backward(batch, noise.to(DEV), t_index).item()
+    g1 = drop.P.g32.clone()
+    drop.P.g32.zero_()
+    l2 = drop.forward_backward(batch, noise.to(DEV), t_index).item()
+    assert l1 != l2, "two replays drew the same dropout masks"
+    drop.P.g32.zero_()
+    drop.micro_idx = 0                                   # same micro-step counter -> same seed word -> the first step again
+    l3 = drop.forward_backward(batch, noise.to(DEV), t_index).item()
+    assert abs(l3 - l1) <= 1e-6 * abs(l1) and (drop.P.g32 - g1).norm().item() <= 1e-4 * g1.norm().item()
