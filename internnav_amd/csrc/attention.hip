@@ -379,17 +379,207 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(AttnArgs p, con
     if (lane + 64 < p.D) O[lane + 64] = (bf16)(o1 * inv);
 }
 
+// One-launch variant for key axes of up to DEC_FUSED_MAX_CHUNKS chunks (Lk <= 1024: every decode / latent-query pass of the 4-frame prompt):
+// ONE 4-wave workgroup per (sequence, KV head, row tile). Wave w walks the chunks w, w + 4, ... with a running (max, sum, O) in registers -
+// the chunk body is the split kernel's, on a wave-private LDS image, the next chunk's K / V pieces requested before the current one is
+// multiplied - then the four partials meet in LDS and the workgroup writes the normalised rows itself. 28 workgroups and one launch per
+// layer instead of 420 + 196 one-wave workgroups in two launches: what the decode chain needs while it shares the CUs with System-1
+// (a launch advances when a System-1 workgroup retires, profiles/r03d_step_breakdown.log).
+constexpr int DEC_FUSED_WAVES = 4, DEC_FUSED_MAX_CHUNKS = 16;
+
+template <int DP, int DV>
+__global__ __launch_bounds__(DEC_FUSED_WAVES * 64) void attn_decode_fused_kernel(AttnArgs p, int nsplit, int rtiles) {
+    constexpr int KVB = 64, KS_LD = DP + 8, VT_LD = KVB + 8, KCPR = DP / 8, VCPR = DV / 8, NKK = DP / 32, NST = KVB / 16, NSB = KVB / 32, NDT = DV / 16;
+    constexpr int PER_WAVE = KVB * KS_LD + DV * VT_LD;          // bf16 elements of one wave's K image + V^T image
+    constexpr int PLD = DV + 2;                                 // partial row: DV x O, m, l (f32)
+    static_assert(16 * PLD * 4 <= KVB * KS_LD * 2, "the partial of a wave fits its K image");
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, lq = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bf16* Ks = reinterpret_cast<bf16*>(dec_smem) + wave * PER_WAVE;
+    bf16* Vt = Ks + KVB * KS_LD;
+    const int kh = blockIdx.x / rtiles, rt = blockIdx.x % rtiles, b = blockIdx.y;
+    const int G = p.H / p.Hkv;
+    const int R = rt * 16 + lq;                    // packed row of this lane
+    const bool live = R < G * p.Lq;
+    const int head = kh * G + (live ? R / p.Lq : 0), qpos = live ? R % p.Lq : 0;
+    int len_k = p.Lk;
+    if (p.k_len) len_k = min(p.k_len[b], p.Lk);
+    const bf16* __restrict__ Q = reinterpret_cast<const bf16*>(p.Q) + (size_t)b * p.q_bs + (size_t)qpos * p.q_rs + (size_t)head * p.q_hs;
+    const bf16* __restrict__ K = reinterpret_cast<const bf16*>(p.K) + (size_t)b * p.k_bs + (size_t)kh * p.k_hs;
+    const bf16* __restrict__ V = reinterpret_cast<const bf16*>(p.V) + (size_t)b * p.v_bs + (size_t)kh * p.v_hs;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc_o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) acc_o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int d = kk * 32 + g * 8;
+        qf[kk] = (live && d < p.D) ? *reinterpret_cast<const bf16x8*>(Q + d) : zero8;
+    }
+    constexpr int NKI = KVB * KCPR / 64, NVI = KVB * VCPR / 64;
+    static_assert((KVB * KCPR) % 64 == 0 && (KVB * VCPR) % 64 == 0, "chunk pieces must divide evenly over the wave");
+    bf16x8 kreg[NKI], vreg[NVI];
+    auto fetch = [&](int kv0) {
+#pragma unroll
+        for (int u = 0; u < NKI; ++u) {
+            const int q = lane + u * 64, row = q / KCPR, c = q % KCPR, kv = kv0 + row;
+            kreg[u] = (kv < len_k && c * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(K + (size_t)kv * p.k_rs + c * 8) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = lane + u * 64, row = q / VCPR, c = q % VCPR, kv = kv0 + row;
+            vreg[u] = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
+        }
+    };
+    const float sc = p.scale * 1.4426950408889634f;
+    const int causal_shift = len_k - p.Lq;
+    int split = wave;
+    if (split * DEC_CHUNK < len_k) fetch(split * DEC_CHUNK);
+    for (; split * DEC_CHUNK < len_k; split += DEC_FUSED_WAVES) {
+        const int kv0 = split * DEC_CHUNK;
+        // registers -> this wave's LDS images (the reads of the previous chunk were consumed by its MFMAs: the LDS queue of a wave is in order)
+#pragma unroll
+        for (int u = 0; u < NKI; ++u) {
+            const int q = lane + u * 64, row = q / KCPR, c = q % KCPR;
+            *reinterpret_cast<bf16x8*>(&Ks[row * KS_LD + c * 8]) = kreg[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = lane + u * 64, row = q / VCPR, c = q % VCPR;
+            const int pos = vt_pos(row);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(c * 8 + i) * VT_LD + ((pos + 8 * c) & (KVB - 1))] = vreg[u][i];   // rotated rows: see vt_pos
+        }
+        if ((split + DEC_FUSED_WAVES) * DEC_CHUNK < len_k) fetch((split + DEC_FUSED_WAVES) * DEC_CHUNK);      // next chunk in flight under this one's math
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        f32x4 s[NST];
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(t * 16 + lq) * KS_LD + kk * 32 + g * 8]);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kv = kv0 + t * 16 + g * 4 + r;
+                const bool ok = live && (kv < len_k) && (!p.causal || kv <= qpos + causal_shift);
+                const float v = ok ? s[t][r] * sc : -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(s[t][r] - m_use);
+                s[t][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NDT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[nt][r] *= alpha;
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+            bf16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (bf16)s[2 * sb][r];
+                pf[4 + r] = (bf16)s[2 * sb + 1][r];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NDT; ++nt) {
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(nt * 16 + lq) * VT_LD + ((sb * 32 + g * 8 + 8 * ((nt * 16 + lq) >> 3)) & (KVB - 1))]);
+                acc_o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, acc_o[nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the four partials meet in LDS (each in its wave's K image): row lq -> [DV] un-normalised O (exp2 domain), m, l
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float* part = reinterpret_cast<float*>(Ks);
+#pragma unroll
+    for (int nt = 0; nt < NDT; ++nt) *reinterpret_cast<f32x4*>(part + lq * PLD + nt * 16 + g * 4) = acc_o[nt];
+    if (g == 0) { part[lq * PLD + DV] = m_run; part[lq * PLD + DV + 1] = l_run; }
+    __syncthreads();
+    // 256 threads: row tid / 16, DV / 16 consecutive columns each
+    {
+        constexpr int CPT = DV / 16;
+        const int row = tid >> 4, c0 = (tid & 15) * CPT;
+        const int Rr = rt * 16 + row;
+        if (Rr < G * p.Lq) {
+            const float* pw[DEC_FUSED_WAVES];
+            float ms[DEC_FUSED_WAVES], m = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < DEC_FUSED_WAVES; ++w) {
+                pw[w] = reinterpret_cast<const float*>(reinterpret_cast<const bf16*>(dec_smem) + w * PER_WAVE) + row * PLD;
+                ms[w] = pw[w][DV];
+                m = fmaxf(m, ms[w]);
+            }
+            const float m_use = (m == -INFINITY) ? 0.f : m;
+            float l = 0.f, o[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) o[c] = 0.f;
+#pragma unroll
+            for (int w = 0; w < DEC_FUSED_WAVES; ++w) {
+                const float wl = (ms[w] == -INFINITY) ? 0.f : exp2f(ms[w] - m_use);
+                l += pw[w][DV + 1] * wl;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) o[c] += pw[w][c0 + c] * wl;
+            }
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            const int hd = kh * G + Rr / p.Lq, qp = Rr % p.Lq;
+            bf16* O = reinterpret_cast<bf16*>(p.O) + (size_t)b * p.o_bs + (size_t)qp * p.o_rs + (size_t)hd * p.o_hs;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (c0 + c < p.D) O[c0 + c] = (bf16)(o[c] * inv);
+        }
+    }
+}
+
 template <int DP, int DV>
 int launch_decode(const AttnArgs& p, hipStream_t stream) {
     const int G = p.H / p.Hkv;
     const int rtiles = (G * p.Lq + 15) / 16;
     const int nsplit = (p.Lk + DEC_CHUNK - 1) / DEC_CHUNK;
-    const size_t bytes = (size_t)p.B * p.Hkv * rtiles * nsplit * 16 * (DV + 2) * sizeof(float);
-    float* ws = nullptr;
-    if (int rc = ina_workspace(1, bytes, stream, &ws)) return rc;
     const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)p.Lk;
     InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
                       2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)p.B * p.Hkv * p.Lk), stream);
+    if (nsplit <= DEC_FUSED_MAX_CHUNKS && p.kernel != 1) {      // (ina_attn_args.kernel = 1 pins the two-launch split + combine pair: parity tests compare)
+        constexpr size_t LDS = (size_t)DEC_FUSED_WAVES * (64 * (DP + 8) + DV * (64 + 8)) * sizeof(bf16);
+        auto kern = attn_decode_fused_kernel<DP, DV>;
+        static bool attr_done = false;
+        if (!attr_done) {
+            INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(p.Hkv * rtiles, p.B), dim3(DEC_FUSED_WAVES * 64), LDS, stream, p, nsplit, rtiles);
+        INA_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    const size_t bytes = (size_t)p.B * p.Hkv * rtiles * nsplit * 16 * (DV + 2) * sizeof(float);
+    float* ws = nullptr;
+    if (int rc = ina_workspace(1, bytes, stream, &ws)) return rc;
     hipLaunchKernelGGL((attn_decode_split_kernel<DP, DV>), dim3(nsplit, p.Hkv * rtiles, p.B), dim3(64), 0, stream, p, ws, nsplit, rtiles);
     hipLaunchKernelGGL((attn_decode_combine_kernel<DV>), dim3(G * p.Lq, p.Hkv, p.B), dim3(64), 0, stream, p, ws, nsplit, rtiles);
     INA_HIP_CHECK(hipGetLastError());

@@ -478,7 +478,7 @@ def test_gemm_skinny_fused_input_rmsnorm(ops, M, N, K, glu, xdt):
 DECODE = [
     # B, Lq, Lk, H, Hkv, D, causal
     (7, 1, 927, 28, 4, 128, True), (7, 5, 932, 28, 4, 128, True), (3, 1, 300, 28, 4, 128, False), (2, 2, 513, 8, 8, 64, True),
-    (4, 1, 1024, 16, 16, 80, True), (1, 6, 256, 28, 4, 128, True),
+    (4, 1, 1024, 16, 16, 80, True), (1, 6, 256, 28, 4, 128, True), (2, 1, 1100, 28, 4, 128, True), (2, 5, 2340, 28, 4, 128, True),     # beyond 1024 keys: the split path either way
 ]
 
 
@@ -486,8 +486,12 @@ DECODE = [
 def test_attention_decode_gqa_split_kv(ops, B, Lq, Lk, H, Hkv, D, causal):
     g = torch.Generator().manual_seed(B * 100 + Lq + Lk)
     q, k, v = _rand((B, Lq, H, D), g), _rand((B, Lk, Hkv, D), g), _rand((B, Lk, Hkv, D), g)
-    out = ops.attention(q, k, v, causal=causal)
-    _close(out, _ref_attn(q, k, v, D ** -0.5, causal), atol=1.5e-2)
+    out = ops.attention(q, k, v, causal=causal)                 # Lk <= 1024: the one-launch kernel (4 waves walk the chunks, partials meet in LDS)
+    ref = _ref_attn(q, k, v, D ** -0.5, causal)
+    _close(out, ref, atol=1.5e-2)
+    two = ops.attention(q, k, v, causal=causal, kernel=1)       # the split + combine pair it replaces
+    _close(two, ref, atol=1.5e-2)
+    assert (out.float() - two.float()).abs().max().item() <= 1.6e-2        # same chunks, another merge order: bf16 rounding of the outputs
     # per-sequence key lengths (ragged answers): keys beyond k_len[b] are ignored, causal offset follows k_len
     lens = torch.tensor([Lk - 3 * (i % 4) for i in range(B)], dtype=torch.int32)
     out2 = ops.attention(q, k, v, causal=causal, k_len=lens.to(_dev()))
@@ -652,7 +656,7 @@ def test_workspace_growth_never_frees_a_buffer_a_graph_has_seen(ops):
     k, v = _rand((B, Lk, Hkv, D), g), _rand((B, Lk, Hkv, D), g)
     out = torch.zeros(B, 1, H, D, dtype=torch.bfloat16, device=_dev())
     klen = torch.full((B,), Lk, dtype=torch.int32, device=_dev())
-    ops.attention(q, k, v, causal=True, out=out, k_len=klen)                     # eager once: the slot's scratch exists before capture
+    ops.attention(q, k, v, causal=True, out=out, k_len=klen, kernel=1)           # eager once: the slot's scratch exists before capture (kernel = 1: the split + combine pair, the one-launch kernel needs no scratch)
     ref = out.clone()
     retired0 = lib.ina_workspace_retired()
     graph = torch.cuda.CUDAGraph()
@@ -660,7 +664,7 @@ def test_workspace_growth_never_frees_a_buffer_a_graph_has_seen(ops):
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         with torch.cuda.graph(graph, stream=s):
-            ops.attention(q, k, v, causal=True, out=out, k_len=klen)
+            ops.attention(q, k, v, causal=True, out=out, k_len=klen, kernel=1)
     torch.cuda.current_stream().wait_stream(s)
     # a much larger decode-attention launch under the same slot: needs > 32 MiB of flash-decoding partials -> the slot grows
     B2, Lk2 = 48, 8192
