@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int D>
+template <int D, int RING = 2>
 struct WideCfg {
     static constexpr int KVB = 64;
     static constexpr int KLD = D + 8;                 // K row stride (elements): 16 rows of one 16-byte column hit 16 different bank quads
@@ -30,7 +30,7 @@ struct WideCfg {
     static constexpr int VLD = (D <= 96) ? 96 : 160;  // V row stride = 64 B (mod 256 B): the 4 rows of one transpose read tile the 64 banks
     static constexpr int NKS = D / 16;
     static constexpr int K_ELEMS = KVB * KLD, V_ELEMS = KVB * VLD;
-    static constexpr size_t LDS = (size_t)2 * (K_ELEMS + V_ELEMS) * sizeof(bf16);
+    static constexpr size_t LDS = (size_t)RING * (K_ELEMS + V_ELEMS) * sizeof(bf16);   // RING = 1: single-block calls (window attention)
 };
 
 __device__ __forceinline__ bf16x8 tr_pair(const bf16* a0, const bf16* a1) {
@@ -46,9 +46,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const bf16* a0, const bf16* a1) {
 // parity tests (the exact-maximum variant measured the same error distribution on all three System-1 heads, profiles/r04a_ab_attn.log).
 constexpr float DEFER_THR = 6.0f;
 
-template <int D, int NW>
+template <int D, int NW, int RING = 2>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
-    using C = WideCfg<D>;
+    using C = WideCfg<D, RING>;
     constexpr int NT = NW * 64, KVB = C::KVB, KLD = C::KLD, VLD = C::VLD, NDT = C::NDT, NKS = C::NKS;
     constexpr int QT = NW * 32;
     constexpr int KCH = D / 8;                        // 16-byte pieces per K / V row
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     static_assert((size_t)QT * OLD * sizeof(bf16) <= C::LDS, "output staging must fit in the K / V ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16* Ks = reinterpret_cast<bf16*>(smem_raw);
-    bf16* Vs = Ks + 2 * C::K_ELEMS;
+    bf16* Vs = Ks + RING * C::K_ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     const int tr_off = (4 * hi + ((lane & 15) >> 2)) * VLD + ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
 
     for (int ib = 0; ib < nblk; ++ib) {
-        const int kv0 = kv_begin + ib * KVB, buf = ib & 1;
-        const bool more = ib + 1 < nblk;
+        const int kv0 = kv_begin + ib * KVB, buf = (RING == 2) ? (ib & 1) : 0;   // RING = 1: the launcher guarantees nblk <= 1
+        const bool more = (RING == 2) && ib + 1 < nblk;
         if (more) fetch(kv0 + KVB);
         if (wave_live && kv0 < wave_kv_end) {
             const bf16* Kb = Ks + buf * C::K_ELEMS;
@@ -274,7 +274,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (more) publish(buf ^ 1);
+        if constexpr (RING == 2) {
+            if (more) publish(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -302,10 +304,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_wide_kernel(AttnArgs p) {
     }
 }
 
-template <int D, int NW>
+template <int D, int NW, int RING = 2>
 int launch_wide(const AttnArgs& p, hipStream_t stream) {
-    using C = WideCfg<D>;
-    auto kern = attn_fwd_wide_kernel<D, NW>;
+    using C = WideCfg<D, RING>;
+    auto kern = attn_fwd_wide_kernel<D, NW, RING>;
     static bool attr_done = false;
     if (!attr_done) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS));
@@ -319,11 +321,19 @@ int launch_wide(const AttnArgs& p, hipStream_t stream) {
 
 }  // namespace
 
+// Window attention of the Qwen2.5-VL vision tower (28 of its 32 blocks): packed sequences of at most 64 tokens, every (window, head) is ONE
+// K / V block. Two waves per workgroup (64 query rows), a single-buffer image (23.5 KiB at d 80 instead of 47): no ring to fill, twice the
+// workgroups per CU for a call that is pure HBM traffic (q | k | v in, o out).
+static bool window_shape(const AttnArgs& p) {
+    return p.cu_q && p.cu_k && p.Lq <= 64 && p.Lk <= 64 && !p.causal && p.kv_start == 0 && !p.k_len && p.kv_bdiv == 1 && p.D == 80;
+}
+
 bool ina_attention_wide_contract(const AttnArgs& p) {
     // what the kernel can run at all (ina_attn_args.kernel = 2 is rejected outside of it)
     if (p.D != 128 && p.D != 80 && p.D != 64) return false;
     if (p.accumulate || p.head_gate || p.drop_thresh) return false;
-    if (p.Lq < 128 || p.Lk < 128 || p.scale <= 0.f) return false;
+    if (p.scale <= 0.f) return false;
+    if ((p.Lq < 128 || p.Lk < 128) && !window_shape(p)) return false;
     // whole-row 16-byte output stores
     if (p.o_rs % 8 || p.o_hs % 8 || p.o_bs % 8 || ((uintptr_t)p.O % 16)) return false;
     // 32-bit byte offsets inside one (batch, head) K / V plane
@@ -334,11 +344,12 @@ bool ina_attention_wide_contract(const AttnArgs& p) {
 bool ina_attention_wide_eligible(const AttnArgs& p) {
     // the automatic rule (ina_attn_args.kernel = 0): every long dense shape inside the kernel's contract - LLM prefill (d 128), Qwen ViT
     // full-attention blocks (d 80) and, since round 4, DINOv2 (d 64, 257 tokens: 42 vs 67 us per launch; adopted behind the 64-env
-    // distributional parity test of the NavDP heads, tests/test_b64_distribution_gpu.py)
+    // distributional parity test of the NavDP heads, tests/test_b64_distribution_gpu.py) and the Qwen ViT windows
     return ina_attention_wide_contract(p);
 }
 
 int ina_launch_attention_wide(const AttnArgs& p, hipStream_t stream) {
+    if (window_shape(p)) return launch_wide<80, 2, 1>(p, stream);
     switch (p.D) {
         case 128: return launch_wide<128, 4>(p, stream);
         case 80: return launch_wide<80, 4>(p, stream);

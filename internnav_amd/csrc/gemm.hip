@@ -168,7 +168,7 @@ int launch_cfg(const GemmArgs& p, hipStream_t stream) {
 
 // Validation + kernel selection of one GEMM call, without launching anything (host arithmetic only: also reachable as ina_gemm_select so
 // that the selection can be inspected / tested without a GPU). `kernel`: 1-8 register-staged tiles (gemm_bf16_nt_kernel), 11-29 / 33
-// LDS-DMA tiles (gemm_glds.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 31 = split-K weight streaming, 32 = fused
+// LDS-DMA tiles (gemm_glds.hip), 38 / 39 the four-wave 256 x 256 tile (gemm_w4.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 31 = split-K weight streaming, 32 = fused
 // weight streaming (gemm_skinny.hip).
 int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     p = p_in;
@@ -246,8 +246,17 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
             // vision chain of the two prefill halves 26.9 vs 28.1-28.3 ms; decoder chain and the d = 384 heads unchanged
             // (profiles/r03z_native_chain_16wave.log). Same tile geometry and K order: bit-equal (r03z_native_gemm_16wave.log).
             if (cfg == 18 && p.R && p.out_dtype == INA_DT_F32 && p.K <= 4096) cfg = 33;
+            // 256 x 256 tile, no residual, wide output, K = 2048 .. 4096 (the decoder's q|k|v and gate|up projections, K = 3584): the FOUR-wave
+            // kernel (cfg 39, gemm_w4.hip: wave tile 128 x 128, hand-threaded MFMA / LDS-read / DMA stream). Isolated +2-6 % (1.23-1.26 vs
+            // 1.18-1.22 PF/s, profiles/r04l_native_w4.log); decoder chain of the two prefill halves 71.1 -> 70.2 ms, joint 73.2 -> 72.0
+            // (r04m_native_w4_chain.log). Bit-equal (same K order). It loses where the epilogue or the prologue weighs more: fp32-residual
+            // outputs (o / down: -3 ... -14 %), K = 1280 (vision blocks: -4 ... -6 %) - those stay on cfg 18 / 33.
+            if (cfg == 18 && !p.R && p.K >= 2048 && p.K <= 4096 && p.N >= 4096 && p.M >= 2048 && ina_gemm_w4_contract(p)) cfg = 39;
         }
     }
+    if (cfg == 38 || cfg == 39)
+        INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 38 / 39 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
+                    "(M=%d N=%d K=%d ldc=%d)", p.M, p.N, p.K, p.ldc);
     if (cfg >= 34 && cfg <= 37)
         INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34-37 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
                     "no scales / residual, bias + activation or SiLU-GLU (M=%d N=%d K=%d)", p.M, p.N, p.K);
@@ -272,7 +281,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: case 38: case 39: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         case 34: case 35: case 36: case 37: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
 #ifdef INA_RP_EXPERIMENTS
         case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: return ina_launch_gemm_rowpanel(p, stream, cfg);

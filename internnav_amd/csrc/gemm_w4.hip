@@ -1,0 +1,237 @@
+// 256 x 256 bf16 MFMA GEMM tile on FOUR waves (wave tile 128 x 128) with LDS-DMA staging - tile config 38 of ina_gemm_bf16.
+// Same stage layout, source-side XOR swizzle, K order and fused epilogue as the 8-wave kernels of gemm_glds.hip (bit-equal results).
+//
+// Why four waves: a 32-wide K slice costs a 128 x 128 wave tile 16 ds_read_b128 for 64 MFMAs - 64 KiB of LDS reads per workgroup and
+// slice instead of the 96 KiB of the 8-wave tiles (128 x 64 wave tiles), which together with the 32 KiB of DMA writes keep the
+// 128 B / clk LDS port busy for as long as the MFMAs of the slice take. The price: 64 accumulator fragments = all 256 AGPRs of a
+// one-wave-per-SIMD kernel, no partner wave on the SIMD to ping-pong with, and a register allocator that cannot place the tuples (the
+// builtin form of this loop spills and moves ~400 accumulator registers through VGPRs per K stage). So the K loop is written as a
+// fixed instruction stream: every MFMA is an asm statement with its accumulator TIED in an AGPR tuple ("+a") and its operands in VGPRs,
+// every fragment read an asm ds_read_b128 with an immediate offset, the waits are explicit. The overlap is inside the wave: while the
+// 64 MFMAs of slice s issue, the 16 reads of slice s + 1 (second fragment set) and - in the second slice of a stage - the wave's 16 DMA
+// instructions of stage t + 2 are threaded between them (one non-MFMA instruction after every MFMA but each third).
+// One s_barrier per 64-wide K stage, between its two slices: before it every wave holds the second slice's fragments in registers (the
+// buffer is free) and its share of stage t + 1 has landed; after it the DMA refills the buffer and slice 0 of stage t + 1 is read.
+#include <utility>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace {
+
+template <int BM, int BN, int WM, int WN, int NS>
+struct GldsCfg {
+    static constexpr int NW = WM * WN, NT = NW * 64, BK = 64;
+    static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static constexpr int A_INST = BM / 8 / NW, B_INST = BN / 8 / NW;   // 1 KiB wave-instructions per wave per stage
+    static constexpr size_t LDS_BYTES = size_t(NS) * (BM + BN) * BK * sizeof(bf16);
+};
+
+__device__ __forceinline__ void glds16(const bf16* src, uint32_t lds_byte_addr) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)(uintptr_t)lds_byte_addr, 16, 0, 0);
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+__device__ __forceinline__ void mfma_tied(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+// f(IC<0>{}), f(IC<1>{}), ... f(IC<N - 1>{}): a fully unrolled loop whose index is a constant expression inside f (asm immediates, array slots)
+template <class F, int... I>
+__device__ __forceinline__ void for_seq_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void for_seq(F&& f) {
+    for_seq_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// VAR 0: the wave's DMA instructions of a stage are issued in one clump right after the barrier; VAR 1: they are threaded between the MFMAs of
+// the stage's second slice (after MFMAs 1, 4, 7, ...), the last two stages (which request nothing) run in a second copy of the loop body.
+template <int BM, int VAR>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
+    constexpr int BN = 256;
+    using C = GldsCfg<BM, BN, 2, 2, 2>;                    // BM 256: TM = TN = 128, FM = FN = 8, 8 + 8 DMA wave-instructions per wave and stage
+    constexpr int FM = C::FM, NMF = FM * 8, NRD = FM + 8, NDMA = C::A_INST + C::B_INST;
+    constexpr uint32_t A_STAGE = BM * 128u, B_STAGE = BN * 128u, B_BASE = 2u * A_STAGE;   // bytes
+    static_assert(3 * (NRD - 1) + 2 < NMF && 3 * (NDMA - 1) + 1 < NMF, "the reads / DMA instructions of a slice are threaded between its MFMAs");
+    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tm, tn;
+    if (p.group_m > 1) {
+        const int gsz = p.group_m * tiles_n, grp = id / gsz, first = grp * p.group_m;
+        const int gm = min(tiles_m - first, p.group_m), in = id - grp * gsz;
+        tm = first + in % gm;
+        tn = in / gm;
+    } else {
+        tm = id / tiles_n;
+        tn = id % tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (size_t)blockIdx.y * p.strideA;
+    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (size_t)blockIdx.y * p.strideW;
+
+    // DMA: slot s of a wave covers tile rows (wave * INST + s) * 8 .. + 7; lane -> (row, physical 16-byte chunk), logical chunk = physical ^ (row & 7)
+    const bf16* asrc[C::A_INST];
+    const bf16* bsrc[C::B_INST];
+    const int drow = lane >> 3, dcp = lane & 7;
+#pragma unroll
+    for (int s = 0; s < C::A_INST; ++s) {
+        const int row = (wave * C::A_INST + s) * 8 + drow;
+        asrc[s] = A + (size_t)min(m0 + row, p.M - 1) * p.lda + ((dcp ^ (row & 7)) << 3);
+    }
+#pragma unroll
+    for (int s = 0; s < C::B_INST; ++s) {
+        const int row = (wave * C::B_INST + s) * 8 + drow;
+        bsrc[s] = W + (size_t)min(n0 + row, p.N - 1) * p.ldw + ((dcp ^ (row & 7)) << 3);
+    }
+    uint32_t a_dma = lds0 + wave * C::A_INST * 1024u, b_dma = lds0 + B_BASE + wave * C::B_INST * 1024u;   // this wave's rows of the buffer to fill
+    auto dma_one = [&](auto Dc, uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
+        constexpr int D = decltype(Dc)::value;
+        if constexpr (D < C::A_INST) glds16(asrc[D] + k0, la + D * 1024u);
+        else glds16(bsrc[D - C::A_INST] + k0, lb + (D - C::A_INST) * 1024u);
+    };
+    auto dma_stage = [&](uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
+        for_seq<NDMA>([&](auto Dc) __attribute__((always_inline)) { dma_one(Dc, la, lb, k0); });
+    };
+
+    f32x4 acc[2][FM][4];                                   // [64-column half of the wave tile][row fragment][column fragment]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / 64;
+    const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+    // per-lane LDS byte addresses of fragment 0 of the wave tile in the CURRENT buffer, one per 32-wide slice (the swizzle is not additive in kk)
+    uint32_t a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const uint32_t chunk = (uint32_t)(((kk * 4 + g) ^ sw) << 4);
+        a_rd[kk] = lds0 + (uint32_t)(wm * C::TM + frow) * 128u + chunk;
+        b_rd[kk] = lds0 + B_BASE + (uint32_t)(wn * C::TN + frow) * 128u + chunk;
+    }
+    int da = (int)A_STAGE, db = (int)B_STAGE;              // current buffer -> the other one
+    bf16x8 fa[2][FM], fb[2][8];                            // two fragment sets: slice s multiplies out of one while slice s + 1 lands in the other
+
+    // read R (0 .. NRD - 1) of fragment set SET: b0 a0 b1 a1 ... (fragment q = rows q * 16 .. + 15 of the wave tile: + q * 2 KiB)
+    auto read_one = [&](auto Rc, auto Sc, uint32_t aa, uint32_t ba) __attribute__((always_inline)) {
+        constexpr int R = decltype(Rc)::value, SET = decltype(Sc)::value;
+        constexpr int NPAIR = 2 * FM;                      // reads 0 .. 2 FM - 1 alternate b / a, the rest (FM < 8) are b fragments
+        if constexpr (R < NPAIR && (R & 1)) lds_read16<(R >> 1) * 2048>(fa[SET][R >> 1], aa);
+        else {
+            constexpr int Q = R < NPAIR ? (R >> 1) : (R - FM);
+            lds_read16<Q * 2048>(fb[SET][Q], ba);
+        }
+    };
+    // one slice: the MFMAs of fragment set SET with the reads of the next slice (set SET ^ 1 <- addresses aa / ba) after MFMAs 2, 5, 8, ...
+    // and (DMA) this wave's DMA instructions of K offset k0 into its rows la / lb of a stage buffer after MFMAs 1, 4, 7, ...
+    auto slice = [&](auto Sc, auto DMAc, uint32_t aa, uint32_t ba, uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
+        constexpr int SET = decltype(Sc)::value;
+        constexpr bool DMA = decltype(DMAc)::value != 0;
+        for_seq<NMF>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value, i = I >> 3, j = I & 7;
+            mfma_tied(acc[j >> 2][i][j & 3], fb[SET][j], fa[SET][i]);
+            if constexpr (DMA && I % 3 == 1 && I / 3 < NDMA) dma_one(IC<I / 3>{}, la, lb, k0);
+            if constexpr (I % 3 == 2 && I / 3 < NRD) read_one(IC<I / 3>{}, IC<SET ^ 1>{}, aa, ba);
+        });
+    };
+
+    dma_stage(a_dma, b_dma, 0);
+    if (nk > 1) {
+        dma_stage(a_dma + A_STAGE, b_dma + B_STAGE, 64);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    for_seq<NRD>([&](auto Rc) __attribute__((always_inline)) { read_one(Rc, IC<0>{}, a_rd[0], b_rd[0]); });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // one K stage per iteration, ONE straight-line body per loop (a join of two MFMA paths makes the allocator shuffle the 256 accumulators)
+    auto stage_body = [&](auto DMAc, int t) __attribute__((always_inline)) {
+        slice(IC<0>{}, IC<0>{}, a_rd[1], b_rd[1], 0u, 0u, 0);        // slice 0 multiplies, slice 1 of this stage lands in set 1
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own share of stage t + 1 landed; the current buffer is not read any more
+        __builtin_amdgcn_s_barrier();
+        if constexpr (VAR == 0) {
+            if (t + 2 < nk) dma_stage(a_dma, b_dma, (t + 2) * 64);   // refill it with stage t + 2
+        }
+        // slice 1 multiplies, slice 0 of stage t + 1 (other buffer; stale LDS after the last stage) lands in set 0
+        slice(IC<1>{}, DMAc, a_rd[0] + da, b_rd[0] + db, a_dma, b_dma, (t + 2) * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        a_rd[0] += da; a_rd[1] += da; b_rd[0] += db; b_rd[1] += db;
+        a_dma += da; b_dma += db;
+        da = -da; db = -db;
+    };
+    int t = 0;
+    if constexpr (VAR == 1) {
+        for (; t + 2 < nk; ++t) stage_body(IC<1>{}, t);
+    }
+    for (; t < nk; ++t) stage_body(IC<0>{}, t);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs retire before the compiler-scheduled epilogue reads the accumulators
+    // LDS-transposed epilogue only (the launcher rejects outputs it cannot take): the direct register epilogue indexes the accumulator
+    // array in rolled loops, which moves it to scratch memory around every asm MFMA
+    __syncthreads();       // every wave is done with the stage buffers: the whole LDS becomes the per-wave transpose scratch
+    float* scratch = reinterpret_cast<float*>(smem_raw) + wave * FM * 1024;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        gemm_store_tile_staged<FM, 4, C::TM, 64, true>(p, acc[h], m0, n0, wm, wn * 2 + h, lane, scratch);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BM, int VAR>
+int launch_w4(const GemmArgs& p, hipStream_t stream) {
+    constexpr int BN = 256;
+    using C = GldsCfg<BM, BN, 2, 2, 2>;
+    static_assert(C::LDS_BYTES >= size_t(4) * C::FM * 4096, "the per-wave epilogue scratch must fit in the two stage buffers");
+    INA_REQUIRE(ina_gemm_w4_contract(p), "gemm(w4): tile configs 38 / 39 need K %% 64 == 0 and 16-byte aligned output (and residual) rows (K=%d ldc=%d)", p.K, p.ldc);
+    static bool attr_done = false;
+    auto kern = gemm_bf16_w4_kernel<BM, VAR>;
+    if (!attr_done) {
+        INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    GemmArgs q = p;
+    if (q.group_m == 0) q.group_m = ((p.N + BN - 1) / BN >= 24 && (p.M + BM - 1) / BM >= 8) ? 8 : 1;
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
+    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
+                      (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
+    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(C::NT), C::LDS_BYTES, stream, q);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+bool ina_gemm_w4_contract(const GemmArgs& p) {
+    // the kernel has the LDS-transposed epilogue only: whole 16-byte pieces of output (and residual) rows
+    const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
+    return p.K % 64 == 0 && ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
+           (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) && ((p.glu ? p.N / 2 : p.N) % 4 == 0);
+}
+
+int ina_launch_gemm_w4(const GemmArgs& p, hipStream_t stream, int cfg) {
+    switch (cfg) {
+        case 38: return launch_w4<256, 0>(p, stream);   // DMA clump after the barrier
+        case 39: return launch_w4<256, 1>(p, stream);   // DMA threaded between the MFMAs of the second slice
+        default: ina_set_error("gemm(w4): unknown tile config %d", cfg); return -2;
+    }
+}

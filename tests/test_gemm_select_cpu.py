@@ -35,14 +35,16 @@ def select(built_lib):
 
 @pytest.mark.parametrize("rows,plain,shared", [
     # rows of 7 / 6 prompts (joint prefill) and of 4 / 3 prompts (the halves of the two-stream prefill): q|k|v, o + residual, gate|up, down + residual
-    (6440, (18, 21, 18, 21), (18, 33, 18, 18)),
-    (5520, (18, 21, 18, 21), (18, 33, 18, 18)),
-    (3680, (21, 33, 18, 18), (18, 33, 18, 18)),
-    (2760, (18, 21, 18, 21), (18, 33, 18, 18)),
+    (6440, (39, 21, 39, 21), (39, 33, 39, 18)),
+    (5520, (39, 21, 39, 21), (39, 33, 39, 18)),
+    (3680, (21, 33, 39, 18), (39, 33, 39, 18)),
+    (2760, (39, 21, 39, 21), (39, 33, 39, 18)),
 ])
 def test_decoder_layer_gemms(select, rows, plain, shared):
     """plain: 192 x 256 tiles (21) where 256-row tiles quantise badly over the 256 CUs; shared tail: 256 x 256 everywhere (the other half's
-    workgroups fill the last round), the o projection (fp32 residual, K = 3584) on the 16-wave tile (33), the K = 18944 down projection not."""
+    workgroups fill the last round), the o projection (fp32 residual, K = 3584) on the 16-wave tile (33), the K = 18944 down projection not.
+    Round 4: wherever the 256 x 256 geometry is selected for q|k|v and gate|up (no residual, K = 3584, N >= 4096) it runs on the four-wave
+    kernel (39, gemm_w4.hip; profiles/r04l_native_w4.log, r04m_native_w4_chain.log)."""
     for mode, want in ((0, plain), (-1, shared)):
         got = (select(rows, QKV, H, force_cfg=mode), select(rows, H, H, force_cfg=mode, **RES),
                select(rows, 2 * I, H, force_cfg=mode, **GLU), select(rows, H, I, force_cfg=mode, **RES))
@@ -87,7 +89,12 @@ def test_weight_streaming_paths(select):
 
 
 def test_forced_configs_and_rejections(select):
-    assert select(6440, QKV, H, force_cfg=21) == 21 and select(6440, QKV, H, force_cfg=33) == 33
+    assert select(6440, QKV, H, force_cfg=21) == 21 and select(6440, QKV, H, force_cfg=33) == 33 and select(6440, QKV, H, force_cfg=18) == 18
+    # four-wave tile: forced anywhere inside its contract (16-byte aligned output rows), selected for wide no-residual K = 2048 .. 4096 GEMMs only
+    assert select(300, 264, 64, force_cfg=38) == 38 and select(6440, H, H, force_cfg=39, **RES) == 39
+    assert select(2047, QKV, H) != 39 and select(6440, 4096, 2048) == 39 and select(6440, 4096, 4160) == 18 and select(6440, 3584, H) != 39
+    bad = select(300, 260, 64, force_cfg=39)               # bf16 rows of 520 bytes
+    assert isinstance(bad, tuple) and "38 / 39" in bad[1]
     for bad in (select(100, 100, 63), select(7, QKV, H, force_cfg=30), select(100, 48, 64, glu=1), select(0, 4, 8),
                 select(100, 102, 64), select(17, QKV, H, norm_gamma=0x3000, a_dtype=1), select(100, 512, 64, force_cfg=31)):
         assert isinstance(bad, tuple) and bad[0] == "error" and bad[1].startswith("gemm")

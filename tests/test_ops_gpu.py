@@ -367,7 +367,7 @@ def test_bad_arguments_fail_loudly(ops):
         ops.attention(q, q, q)
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 33])
+@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 33, 38, 39])
 @pytest.mark.parametrize("M,N,K", [(300, 260, 320), (1000, 1280, 3456), (257, 4608, 3584), (130, 132, 64)])
 def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     """LDS-DMA staged kernels: ragged M/N edges (clamped rows), swizzled LDS, every epilogue term."""
@@ -380,7 +380,7 @@ def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     _close(out, ref, rtol=2e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (17, 5), (17, 0), (18, 8), (19, 3)])
+@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (17, 5), (17, 0), (18, 8), (19, 3), (39, 8), (38, 3)])
 def test_gemm_glds_grouped_tile_order(ops, cfg, group_m):
     """Grouped tile order (group_m row-tiles per group, ragged last group, auto rule at 0) is a pure re-ordering: same result as
     row-major, bit for bit, and equal to the fp32 reference."""
@@ -408,6 +408,37 @@ def test_gemm_shared_tail_selection_is_bit_equal(ops, M, N, K, glu):
         shared = ops.linear(x, w, **kw)
     assert torch.equal(plain, shared)
     assert torch.equal(plain, ops.linear(x, w, force_cfg=-1, **kw))
+
+
+@pytest.mark.parametrize("cfg", [38, 39])
+@pytest.mark.parametrize("M,N,K,mode", [(2760, 4608, 3584, "bias"), (2100, 4096, 3584, "glu"), (777, 1024, 448, "glu"), (1000, 1000, 192, "res"),
+                                        (300, 264, 64, "bias"), (515, 520, 128, "plain"), (2761, 3592, 320, "bf16res")])
+def test_gemm_four_wave_tile_is_bit_equal(ops, cfg, M, N, K, mode):
+    """gemm_w4.hip (tile configs 38 / 39: 256 x 256 on four waves of 128 x 128, asm-threaded K loop) accumulates K in the order of the
+    8-wave tiles: bit-equal to the ping-pong kernel (cfg 18) under every epilogue, with ragged edges and 1 / 2 / 3 / 5 / 7 / 56 K stages
+    (the loop requests two stages ahead: the last two stages take the path that requests nothing)."""
+    g = torch.Generator().manual_seed(M + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    kw = {}
+    if mode == "bias":
+        kw = dict(bias=torch.randn(N, generator=g).to(_dev()))
+    elif mode == "glu":
+        kw = dict(act="silu", glu=True)
+    elif mode == "res":
+        kw = dict(residual=torch.randn(M, N, generator=g).to(_dev()), out_dtype=torch.float32, act="gelu_tanh", bias=torch.randn(N, generator=g).to(_dev()))
+    elif mode == "bf16res":
+        kw = dict(residual=_rand((M, N), g))
+    ref = ops.linear(x, w, force_cfg=18, **kw)
+    out = ops.linear(x, w, force_cfg=cfg, **kw)
+    assert torch.equal(ref, out)
+    if mode in ("bias", "plain"):
+        _close(out, x.float() @ w.float().t() + (kw["bias"] if "bias" in kw else 0.0))
+
+
+def test_gemm_four_wave_tile_rejects_unaligned_rows(ops):
+    x, w = torch.zeros(300, 64, dtype=torch.bfloat16, device=_dev()), torch.zeros(260, 64, dtype=torch.bfloat16, device=_dev())
+    with pytest.raises(RuntimeError, match="38 / 39"):
+        ops.linear(x, w, force_cfg=39)          # bf16 rows of 520 bytes
 
 
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]

@@ -72,11 +72,14 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpy(d_cu, cu.data(), cu.size() * 4, hipMemcpyHostToDevice));
     HIP_OK(hipDeviceSynchronize());
 
-    struct Case { const char* name; int B, Lq, Lk, H, Hkv, D, causal, varlen; };
+    struct Case { const char* name; int B, Lq, Lk, H, Hkv, D, causal, varlen, kernel; };
     const Case cases[] = {{"LLM prefill      7 x 920, 28 / 4 heads x d128, causal", 7, 920, 920, 28, 4, 128, 1, 0},
                           {"LLM prefill half 4 x 920", 4, 920, 920, 28, 4, 128, 1, 0},
                           {"ViT full         28 x 784, 16 heads x d80", 28, 784, 784, 16, 16, 80, 0, 0},
-                          {"ViT windows      343 x 64 (varlen), 16 heads x d80", 343, 64, 64, 16, 16, 80, 0, 1},
+                          {"ViT windows      343 x 64 (varlen), 16 heads x d80, 16-row kernel", 343, 64, 64, 16, 16, 80, 0, 1, 1},
+                          {"ViT windows      343 x 64 (varlen), 32-row kernel (2 waves, 1 buffer)", 343, 64, 64, 16, 16, 80, 0, 1, 2},
+                          {"ViT windows half 196 x 64 (varlen), 16-row kernel", 196, 64, 64, 16, 16, 80, 0, 1, 1},
+                          {"ViT windows half 196 x 64 (varlen), 32-row kernel", 196, 64, 64, 16, 16, 80, 0, 1, 2},
                           {"DINOv2           128 x 257, 6 heads x d64", 128, 257, 257, 6, 6, 64, 0, 0},
                           {"decode           7 x (1 query, 927 keys), 28 / 4 x d128", 7, 1, 927, 28, 4, 128, 1, 0},
                           {"latent queries   7 x (5 queries, 933 keys)", 7, 5, 933, 28, 4, 128, 1, 0}};
@@ -86,13 +89,13 @@ int main(int argc, char** argv) {
         ina_attn_args a;
         memset(&a, 0, sizeof a);
         a.Q = Q; a.K = K; a.V = V; a.O = O;
-        a.H = c.H; a.Hkv = c.Hkv; a.D = c.D; a.causal = c.causal; a.kv_bdiv = 1;
+        a.H = c.H; a.Hkv = c.Hkv; a.D = c.D; a.causal = c.causal; a.kv_bdiv = 1; a.kernel = c.kernel;
         a.scale = 1.0f / sqrtf((float)c.D);
         size_t q_elems, kv_elems;
         if (c.varlen) {
             a.B = c.B; a.Lq = c.Lq; a.Lk = c.Lk; a.cu_q = d_cu; a.cu_k = d_cu;
             a.q_rs = (int64_t)c.H * c.D; a.q_hs = c.D; a.k_rs = (int64_t)c.Hkv * c.D; a.k_hs = c.D; a.v_rs = a.k_rs; a.v_hs = c.D; a.o_rs = a.q_rs; a.o_hs = c.D;
-            q_elems = (size_t)NTOK * c.H * c.D; kv_elems = (size_t)NTOK * c.Hkv * c.D;
+            q_elems = (size_t)c.B * WIN * c.H * c.D; kv_elems = (size_t)c.B * WIN * c.Hkv * c.D;
         } else {
             a.B = c.B; a.Lq = c.Lq; a.Lk = c.Lk;
             a.q_hs = c.D; a.q_rs = (int64_t)c.H * c.D; a.q_bs = a.q_rs * c.Lq;
@@ -117,7 +120,7 @@ int main(int argc, char** argv) {
         HIP_OK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
         const double keys = c.causal ? 0.5 * ((double)c.Lk + (double)(c.Lk - c.Lq) + 1.0) : (double)c.Lk;
-        const double flop = 4.0 * (c.varlen ? (double)NTOK : (double)c.B * c.Lq) * c.H * keys * c.D;
+        const double flop = 4.0 * (double)c.B * c.Lq * c.H * keys * c.D;
         const double bytes = 2.0 * (2.0 * q_elems + 2.0 * kv_elems);
         printf("%-62s %8.1f us  %6.1f TF/s  %5.2f TB/s  checksum %016llx\n", c.name, us, flop / us * 1e-6, bytes / us * 1e-6, v);
     }
