@@ -33,6 +33,11 @@ __device__ __forceinline__ void glds16(const bf16* src, uint32_t lds_byte_addr) 
                                      (void __attribute__((address_space(3)))*)(uintptr_t)lds_byte_addr, 16, 0, 0);
 }
 
+// the same DMA piece with a scalar base + 32-bit lane offset (no vector address arithmetic per piece); M0 = LDS byte address of the piece
+__device__ __forceinline__ void glds16_saddr(const void* base, uint32_t voff, uint32_t lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte_addr), "v"(voff), "s"(base) : "memory", "m0");
+}
+
 template <int OFF>
 __device__ __forceinline__ void lds_read16(bf16x8& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
@@ -55,8 +60,10 @@ __device__ __forceinline__ void for_seq(F&& f) {
     for_seq_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// VAR 0: the wave's DMA instructions of a stage are issued in one clump right after the barrier; VAR 1: they are threaded between the MFMAs of
-// the stage's second slice (after MFMAs 1, 4, 7, ...), the last two stages (which request nothing) run in a second copy of the loop body.
+// VAR 0 (cfg 38): the wave's DMA instructions of a stage are issued in one clump right after the barrier (compiler builtin). VAR 1 (cfg 39): they
+// are threaded between the MFMAs of the stage's second slice (after MFMAs 1, 4, 7, ...) as asm pieces with a scalar base + 32-bit lane offset
+// (no vector address add per piece: 1477 vs 1440 TF/s at 8192^3, decoder chain 70.4 vs 70.9 ms, profiles/r04n_native_w4_saddr*.log); the last two
+// stages (which request nothing) run in a second copy of the loop body.
 template <int BM, int VAR>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
     constexpr int BN = 256;
@@ -99,11 +106,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
         const int row = (wave * C::B_INST + s) * 8 + drow;
         bsrc[s] = W + (size_t)min(n0 + row, p.N - 1) * p.ldw + ((dcp ^ (row & 7)) << 3);
     }
+    uint32_t aoff[C::A_INST], boff[C::B_INST];            // VAR 1: byte offsets of the same sources from A / W (the launcher checks they fit in 32 bits)
+#pragma unroll
+    for (int s = 0; s < C::A_INST; ++s) aoff[s] = (uint32_t)(reinterpret_cast<const char*>(asrc[s]) - reinterpret_cast<const char*>(A));
+#pragma unroll
+    for (int s = 0; s < C::B_INST; ++s) boff[s] = (uint32_t)(reinterpret_cast<const char*>(bsrc[s]) - reinterpret_cast<const char*>(W));
     uint32_t a_dma = lds0 + wave * C::A_INST * 1024u, b_dma = lds0 + B_BASE + wave * C::B_INST * 1024u;   // this wave's rows of the buffer to fill
     auto dma_one = [&](auto Dc, uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
         constexpr int D = decltype(Dc)::value;
-        if constexpr (D < C::A_INST) glds16(asrc[D] + k0, la + D * 1024u);
-        else glds16(bsrc[D - C::A_INST] + k0, lb + (D - C::A_INST) * 1024u);
+        if constexpr (VAR == 1) {
+            if constexpr (D < C::A_INST) glds16_saddr(A + k0, aoff[D], __builtin_amdgcn_readfirstlane(la + D * 1024u));
+            else glds16_saddr(W + k0, boff[D - C::A_INST], __builtin_amdgcn_readfirstlane(lb + (D - C::A_INST) * 1024u));
+        } else {
+            if constexpr (D < C::A_INST) glds16(asrc[D] + k0, la + D * 1024u);
+            else glds16(bsrc[D - C::A_INST] + k0, lb + (D - C::A_INST) * 1024u);
+        }
     };
     auto dma_stage = [&](uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
         for_seq<NDMA>([&](auto Dc) __attribute__((always_inline)) { dma_one(Dc, la, lb, k0); });
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
         da = -da; db = -db;
     };
     int t = 0;
-    if constexpr (VAR == 1) {
+    if constexpr (VAR >= 1) {
         for (; t + 2 < nk; ++t) stage_body(IC<1>{}, t);
     }
     for (; t < nk; ++t) stage_body(IC<0>{}, t);
@@ -224,6 +241,7 @@ int launch_w4(const GemmArgs& p, hipStream_t stream) {
 bool ina_gemm_w4_contract(const GemmArgs& p) {
     // the kernel has the LDS-transposed epilogue only: whole 16-byte pieces of output (and residual) rows
     const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
+    if ((double)p.M * p.lda * 2.0 >= 4.0e9 || (double)p.N * p.ldw * 2.0 >= 4.0e9) return false;   // 32-bit byte offsets of the DMA sources inside A / W
     return p.K % 64 == 0 && ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
            (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) && ((p.glu ? p.N / 2 : p.N) % 4 == 0);
 }
@@ -231,7 +249,7 @@ bool ina_gemm_w4_contract(const GemmArgs& p) {
 int ina_launch_gemm_w4(const GemmArgs& p, hipStream_t stream, int cfg) {
     switch (cfg) {
         case 38: return launch_w4<256, 0>(p, stream);   // DMA clump after the barrier
-        case 39: return launch_w4<256, 1>(p, stream);   // DMA threaded between the MFMAs of the second slice
+        case 39: return launch_w4<256, 1>(p, stream);   // DMA pieces threaded between the MFMAs of the second slice (asm, scalar base + lane offset)
         default: ina_set_error("gemm(w4): unknown tile config %d", cfg); return -2;
     }
 }
