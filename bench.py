@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
     ap.add_argument("--fuse-rownorm", action="store_true",
                     help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
+    ap.add_argument("--no-s1-merge-images", action="store_true",
+                    help="n1_dual: encode the look-down frames of the System-2 envs in the small System-1 call behind the decode chain (round-3 schedule) "
+                         "instead of inside the side stream's batched encoder pass over all 64 envs")
     ap.add_argument("--no-raw-frames", action="store_true",
                     help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
     # (round-3 schedule experiments - stream priorities, System-1 started with the prefill, early look-down encoding, a split side-stream
@@ -95,7 +98,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, rest=[])
+                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -402,6 +405,8 @@ class N1Dual:
                      "s2_microbatches_per_period": self.mb, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
         self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
+        if not getattr(a, "no_s1_merge_images", False) and self.cadence == "nominal" and self.with_s1 and not getattr(a, "no_overlap", False) and not a.no_graph:
+            self.desc["s1_images"] = "look-down pairs of all 64 envs encoded in ONE pass inside the side-stream System-1 call; the call of the System-2 envs starts at the projected latents"
         self.vit_cache = bool(getattr(a, "vit_cache", False)) and self.raw
         self.prefix_kv = bool(getattr(a, "prefix_kv", False)) and self.raw
         assert not (self.vit_cache and self.prefix_kv), "--prefix-kv already covers frame 0 (its tokens are cached K/V): use one of the two"
@@ -462,18 +467,23 @@ class N1Dual:
             from internnav_amd.policy import _Prefixed
 
             self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
+            # the look-down pairs of the System-2 envs go through the side stream's encoder pass (DINOv2, MemoryEncoder, QFormer over all 64 envs at
+            # once) and only their 32 memory tokens travel to the small engine: the latency-bound encoder chain (~180 launches) leaves the main
+            # chain, 302.5 / 303.0 -> 305.6 policy steps/s on one box (profiles/r04o_bench_s1_variants.log; the row-norm epilogue in the small
+            # engine alone: 300.5, not adopted)
+            self.merge_images = not getattr(a, "no_s1_merge_images", False) and self.cadence == "nominal"
             self.side = torch.cuda.Stream(device=dev)
             nA = max(len(x) for x in side)
-            self.latA, self.imgA, self.xA = (torch.empty((nA,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-                                             for t in (self.latent_table, self.images_dp, self.x_init))
+            self.latA, self.imgA, self.xA = (torch.empty((nA + (mmax if t is self.images_dp else 0),) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                                             for t in (self.latent_table, self.images_dp, self.x_init))     # imgA: side envs | System-2 envs (merged encoder pass)
             self.latB, self.imgB, self.xB = (torch.empty((mmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
                                              for t in (self.latent_table, self.images_dp, self.x_init))
             self.idxA = [torch.tensor(x, device=dev, dtype=torch.long) for x in side]
             self.traj = torch.zeros(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
             self.hostA = torch.empty(nA, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
             self.hostB = torch.empty(mmax, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
-            self.gA, self.gB, self.gP, self.gD = {}, {}, {}, {}
-            self.ev = torch.cuda.Event()
+            self.gA, self.gB, self.gP, self.gD, self.gAimg = {}, {}, {}, {}, {}
+            self.ev, self.ev_img = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- ingest: raw frames -> engine inputs (inside the timed step)
     def _ingest_s2(self, lo, m, dst):
@@ -537,10 +547,19 @@ class N1Dual:
             q = self.model.qwen
             for j in range(self.PERIOD):
                 m, nA = self.mb[j], len(self.idxA_host[j])
+                mg = self.merge_images
+                if mg and (nA, m) not in self.gAimg:
+                    # one encoder pass over the look-down pairs of the side envs AND the System-2 envs; the latter's 32 memory tokens go to the small engine
+                    s1, sm = self.model.s1, self.s1_small
+
+                    def enc(nA=nA, m=m):
+                        s1.encode_images(nA + m, self.imgA[:nA + m])
+                        sm.z[: m * sm.Lz].view(m, sm.Lz, sm.L)[:, :32].copy_(s1.z[: (nA + m) * s1.Lz].view(nA + m, s1.Lz, s1.L)[nA:, :32])
+                    self.gAimg[(nA, m)] = runtime.GraphedCall(enc, {}, workspace_slot=1)
                 if nA not in self.gA:
-                    self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA]), {}, workspace_slot=1)
+                    self.gA[nA] = runtime.GraphedCall(lambda nA=nA: self.model.s1.generate_traj(self.latA[:nA], self.imgA[:nA], self.xA[:nA], images_encoded=mg), {}, workspace_slot=1)
                 if m not in self.gB:
-                    self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m]), {}, workspace_slot=2)
+                    self.gB[m] = runtime.GraphedCall(lambda m=m: self.s1_small.generate_traj(self.latB[:m], self.imgB[:m], self.xB[:m], images_encoded=mg), {}, workspace_slot=2)
                     s = self.s2[m]
                     self.gP[m] = runtime.GraphedCall(lambda s=s: q.run_prefill(s["P"], s["pv"]), {})
 
@@ -600,6 +619,8 @@ class N1Dual:
         # side stream: System-1 for the envs keeping their current plan's latents (earlier System-2 calls)
         torch.index_select(self.latent_table, 0, idx, out=self.latA[:nA])
         torch.index_select(self.images_dp, 0, idx, out=self.imgA[:nA])
+        if self.merge_images:
+            self.imgA[nA:nA + m].copy_(self.images_dp[lo:lo + m])
         torch.index_select(self.x_init, 0, idx, out=self.xA[:nA])
         # main stream: System-2 micro-batch (prefill alone: MFMA bound), then decode + latent queries || side-stream System-1
         s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
@@ -608,11 +629,17 @@ class N1Dual:
         self.ev.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev)
+            if self.merge_images:
+                self.gAimg[(nA, m)]()
+                self.ev_img.record(self.side)
             trajA = self.gA[nA]()
         self.gD[m]()
         self.latent_table[lo:lo + m].copy_(s["lat"])
         self.latB[:m].copy_(s["lat"])
-        self.imgB[:m].copy_(self.images_dp[lo:lo + m])
+        if self.merge_images:
+            main.wait_event(self.ev_img)         # the memory tokens of the System-2 envs (long done: the decode chain ran meanwhile)
+        else:
+            self.imgB[:m].copy_(self.images_dp[lo:lo + m])
         self.xB[:m].copy_(self.x_init[lo:lo + m])
         trajB = self.gB[m]()
         # host post-processing of the side-stream envs runs while the main stream is still busy with the System-2 decode passes and the
