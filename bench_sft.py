@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=10, help="images in the System-2 prompt (8 history + current + look-down)")
     ap.add_argument("--zero2", action="store_true", help="reduce-scatter + sharded update + all-gather instead of all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="frozen prefix (ViT + prefill) of every micro-batch inside its own step, on the main stream (round-3 / early round-4 schedule) "
+                         "instead of one step ahead on the prefetch stream (InternVLAN1SftTrainer.prefetch)")
     ap.add_argument("--no-graph-s1", action="store_true", help="System-1 loss + backward as eager launches (round-3 path) instead of one hipGraph replay")
     return ap.parse_args()
 
@@ -179,14 +182,23 @@ def main():
             torch.cuda.synchronize()
 
     losses = []
-    for _ in range(a.warmup):
-        tr.training_step(batch)
+    # two batch objects stand for consecutive micro-batches of a data loader (same synthetic content): with the prefetch pipeline the frozen
+    # prefix of micro-batch i + 1 runs on a second stream / engine twin while step i's System-1 loss, backward and optimiser launch run -
+    # every step still does one prefix, one loss / backward and one update
+    batches = [batch, dict(batch)]
+    pipe = not a.no_prefetch
+
+    def one(i):
+        return tr.training_step(batches[i % 2], next_batch=batches[(i + 1) % 2] if pipe else None)
+    for i in range(a.warmup):
+        one(i)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses.append(tr.training_step(batch))
+    for i in range(a.warmup, a.warmup + a.steps):
+        losses.append(one(i))
     sync()
     dt = time.perf_counter() - t0
+    tr.drop_prefetch()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,7 +228,8 @@ def main():
             "config": {"workload": f"sft_nextdit_async_b{info['B']}x{info['T']}", "micro_batch_per_gpu": info["B"], "subgoals_per_sample": info["T"],
                        "s2_prompt": f"{info['F']} frames x 784 patches + text, S={info['S']} + 4 <traj> tokens", "parallelism": f"dp{world}" + ("-zero2" if a.zero2 else ""),
                        "trainable_parameters": int(sum(int(np.prod(s)) for _, s in tr.P.index.values())), "optimizer": "fused AdamW + clip 1.0, cosine_with_min_lr", "dropout": 0.1,
-                       "launch": "eager", "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
+                       "launch": ("frozen prefix one step ahead on a prefetch stream (engine twin); " if pipe else "frozen prefix inside the step; ") +
+                                 ("System-1 loss + backward as one hipGraph replay" if not a.no_graph_s1 else "eager"), "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": dom["launches"],
                          "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "traffic": None,

@@ -209,6 +209,22 @@ class QwenVLEngine:
         assert axis.size == half
         self.axis_of = torch.from_numpy(axis).to(dev)
 
+    _BUFFERS = ("pv_perm", "xv", "hv", "attv", "qkvv", "ffv", "mh", "emb", "emb_tok", "v_cos", "v_sin", "x_in", "x", "h", "att", "qkv", "ff", "cos", "sin",
+                "hl", "xl", "logits", "next_tok")
+
+    def twin(self) -> "QwenVLEngine":
+        """a second engine over the SAME weight tensors (nothing is copied; `latent_q` stays one shared parameter) with its own activation
+        buffers and KV cache: two calls can then be in flight on two streams - the SFT trainer prefills the frozen prefix of micro-batch
+        i + 1 in the twin while micro-batch i's latent-query rows still read this engine's cache (trainer.prefetch)."""
+        import copy
+
+        t = copy.copy(self)
+        for n in self._BUFFERS:
+            setattr(t, n, torch.empty_like(getattr(self, n)))
+        t.layers = [dict(L, kv=torch.empty_like(L["kv"])) for L in self.layers]
+        t._side = None
+        return t
+
     # ------------------------------------------------------------------------------------------------ vision tower
     def plan_vision(self, grids: List[Tuple[int, int, int]]) -> dict:
         """host side of the vision tower for a list of image grids: window permutation, cu_seqlens, rope tables (uploaded once)."""

@@ -83,6 +83,10 @@ class InternVLAN1SftTrainer:
             raise NotImplementedError(f"SFT for system1={system1!r}: only the *_async heads of the released checkpoints are trained here")
         self.P = self.head.P
         self.lq = LatentQueryGrad(engine)
+        # prefetch pipeline (prefetch()): two engines over the same weights, the frozen prefix of the NEXT micro-batch runs in the idle one
+        self._engines, self._lqs, self._cur = [engine], [self.lq], 0
+        self._pf = None               # (batch object, engine slot, prefill state, completion event) of the prefix in flight
+        self._pf_stream = None
         self.total_steps, self.lr, self.min_lr = total_steps, lr, min_lr
         self.warmup_steps = math.ceil(total_steps * warmup_ratio)
         self.wd, self.max_norm, self.betas, self.eps = weight_decay, max_grad_norm, betas, eps
@@ -137,20 +141,15 @@ class InternVLAN1SftTrainer:
 
     # ---------------------------------------------------------------------------------------------------------------- one step
     def forward_backward(self, batch: dict, noise: Optional[torch.Tensor] = None, t_index: Optional[torch.Tensor] = None,
-                         loss_scale: float = 1.0) -> torch.Tensor:
+                         loss_scale: float = 1.0, state: Optional[dict] = None) -> torch.Tensor:
         """loss of the micro-batch; gradients are accumulated into the flat store. Gradient accumulation over k micro-batches = k calls with
         loss_scale = 1 / k (HF Trainer divides the loss by gradient_accumulation_steps before backward) and one optimizer_step()."""
         e, dev = self.engine, self.device
-        ids = batch["input_ids"]
-        t_s_pos = np.asarray(batch["t_s_pos"], dtype=np.int64)
-        B = ids.shape[0]
+        B = batch["input_ids"].shape[0]
         nq = e.latent_q.shape[0]
-        S0 = int(t_s_pos.max())
-        prefix = ids[:, :S0].clone()
-        for b in range(B):           # right-pad rows of shorter samples: the <traj> tokens / padding behind t_s_pos are not part of the prefix
-            prefix[b, t_s_pos[b]:] = 0
-        pv = batch["pixel_values"].to(dev, torch.bfloat16)
-        state = e.prefill(prefix, pv, batch["image_grid_thw"], seq_lens=t_s_pos)
+        if state is None:
+            state = self._acquire_prefix(batch)
+        e = self.engine
         hq = self.lq.forward(state)
         Tn = batch["traj_images"].shape[1]
         if noise is None:            # internvla_n1.py:261-264 / navdp.py:163-175 (the reference draws inside forward)
@@ -170,6 +169,62 @@ class InternVLAN1SftTrainer:
                                                 batch["video_frame_num"], noise, t_index, loss_scale=loss_scale, seed=self._mask_seed())
         self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
         return loss
+
+    def _prefix(self, e: QwenVLEngine, batch: dict) -> dict:
+        """frozen System-2 forward of the tokens before `t_s_pos` (ViT + ragged prefill) on engine e; the KV cache it leaves is the
+        activation checkpoint of the step. Depends on no trainable tensor (the <traj> rows are not part of the prefix)."""
+        ids = batch["input_ids"]
+        t_s_pos = np.asarray(batch["t_s_pos"], dtype=np.int64)
+        S0 = int(t_s_pos.max())
+        prefix = ids[:, :S0].clone()
+        for b in range(ids.shape[0]):   # right-pad rows of shorter samples: the <traj> tokens / padding behind t_s_pos are not part of the prefix
+            prefix[b, t_s_pos[b]:] = 0
+        pv = batch["pixel_values"].to(self.device, torch.bfloat16)
+        return e.prefill(prefix, pv, batch["image_grid_thw"], seq_lens=t_s_pos)
+
+    def _acquire_prefix(self, batch: dict) -> dict:
+        """prefill state of this micro-batch's frozen prefix: the prefetched one (the trainer then switches to the engine that holds its KV
+        cache, once the prefetch stream's work has landed) or a prefill on the current stream, now."""
+        if self._pf is not None and self._pf[0] is batch:
+            _, self._cur, state, ev = self._pf
+            self._pf = None
+            torch.cuda.current_stream().wait_event(ev)
+            self.engine, self.lq = self._engines[self._cur], self._lqs[self._cur]
+            return state
+        return self._prefix(self.engine, batch)
+
+    def prefetch(self, batch: dict):
+        """Start the frozen prefix of a FUTURE micro-batch now, on a second stream and in a second engine over the same weights
+        (QwenVLEngine.twin: own activations and KV cache). The prefix reads no trainable tensor, so it may run beside the System-1 loss /
+        backward, the latent-query rows and the optimiser launch of the current micro-batch (the MFMA-bound prefill fills the gaps of
+        those launch- and HBM-bound chains); `forward_backward(batch)` picks the result up when it is handed the same batch object.
+        Data-loader style use: `training_step(batch_i, next_batch=batch_i+1)`."""
+        from . import _lib
+
+        if self._pf is not None and self._pf[0] is batch:
+            return
+        if len(self._engines) == 1:
+            self._engines.append(self.engine.twin())
+            self._lqs.append(LatentQueryGrad(self._engines[1]))
+            self._pf_stream = torch.cuda.Stream(device=self.device)
+        slot = 1 - self._cur
+        main = torch.cuda.current_stream()
+        self._pf_stream.wait_stream(main)      # the idle engine's cache was last read by the previous step's latent-query backward
+        _lib.check(_lib.lib().ina_set_workspace_slot(3), "set_workspace_slot")      # library scratch of launches issued beside the main stream's
+        try:
+            with torch.cuda.stream(self._pf_stream):
+                state = self._prefix(self._engines[slot], batch)
+                ev = torch.cuda.Event()
+                ev.record(self._pf_stream)
+        finally:
+            _lib.check(_lib.lib().ina_set_workspace_slot(0), "set_workspace_slot")
+        self._pf = (batch, slot, state, ev)
+
+    def drop_prefetch(self):
+        """forget a prefix in flight (after waiting for it): the next forward_backward prefills on the current stream again."""
+        if self._pf is not None:
+            self._pf[3].synchronize()
+            self._pf = None
 
     def _s1_graphed(self, hq: torch.Tensor, batch: dict, noise: torch.Tensor, t_index: torch.Tensor, loss_scale: float):
         """System-1 loss + backward as ONE hipGraph replay. The tape's launch sequence depends on the batch geometry only, so it is captured
@@ -317,8 +372,13 @@ class InternVLAN1SftTrainer:
             self.gen_cpu.manual_seed((s_ >> 1) & 0x7FFFFFFFFFFFFFFF)
         self.engine.latent_q.copy_(self.P.w16(LQ).view(self.engine.latent_q.shape))
 
-    def training_step(self, batch: dict, noise=None, t_index=None) -> torch.Tensor:
-        loss = self.forward_backward(batch, noise, t_index)
+    def training_step(self, batch: dict, noise=None, t_index=None, next_batch: Optional[dict] = None) -> torch.Tensor:
+        """next_batch: the micro-batch of the following step, if the caller already has it (a data loader does): its frozen prefix is
+        started on the prefetch stream (prefetch()) as soon as this step's own prefix is in hand, before the rest of this step is issued."""
+        state = self._acquire_prefix(batch)
+        if next_batch is not None:
+            self.prefetch(next_batch)
+        loss = self.forward_backward(batch, noise, t_index, state=state)
         self.reduce_gradients()
         self.optimizer_step()
         return loss

@@ -353,6 +353,28 @@ def test_self_spawn_relaunches_one_process_per_gpu(tmp_path):
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
 
 
+def test_engine_twin_shares_weights_and_owns_buffers():
+    """QwenVLEngine.twin(): the second engine of the SFT prefetch pipeline - same weight tensors (no copy, one `latent_q` parameter), its own
+    activation buffers and KV cache, its own side stream slot."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+
+    cfg = dict(S.QWEN_TEST_CFG, v_depth=1, v_fullatt=(0,), t_layers=2)
+    eng = QwenVLEngine(S.qwen_state_dict(seed=1, cfg=cfg), cfg, "cpu", max_seqs=2, max_seq_len=256, max_patches=2 * 784)
+    tw = eng.twin()
+    assert tw.latent_q is eng.latent_q and tw.embed is eng.embed and tw.lm_head is eng.lm_head and tw.v_blocks is eng.v_blocks
+    for a, b in zip(eng.layers, tw.layers):
+        assert a["qkv_w"] is b["qkv_w"] and a["down_w"] is b["down_w"] and a["kv"].data_ptr() != b["kv"].data_ptr() and a["kv"].shape == b["kv"].shape
+    for n in QwenVLEngine._BUFFERS:
+        assert getattr(tw, n).data_ptr() != getattr(eng, n).data_ptr() and getattr(tw, n).shape == getattr(eng, n).shape, n
+    # every tensor attribute of the engine is either a declared buffer or shared
+    for n, v in vars(eng).items():
+        if isinstance(v, torch.Tensor) and n not in QwenVLEngine._BUFFERS:
+            assert getattr(tw, n) is v, n
+    inp = S.qwen_inputs(2, 1, seed=1, cfg=cfg, n_text=20, n_tail=8)
+    assert tw.plan(inp["input_ids"], inp["grid_thw"])["S_run"] == eng.plan(inp["input_ids"], inp["grid_thw"])["S_run"]
+
+
 def test_prefix_kv_plan_host_logic_on_cpu():
     """QwenVLEngine.plan(prefix_len=...) is integer work (which images are skipped, which rows run, position ids, cache rows, key lengths):
     checked here on a CPU-resident engine without any kernel launch. The arithmetic of the feature is tested on the GPU

@@ -151,3 +151,47 @@ def test_graphed_system1_step_equals_eager_and_redraws_masks(built_lib, system1)
     drop.micro_idx = 0                                   # same micro-step counter -> same seed word -> the first step again
     l3 = drop.forward_backward(batch, noise.to(DEV), t_index).item()
     assert abs(l3 - l1) <= 1e-6 * abs(l1) and (drop.P.g32 - g1).norm().item() <= 1e-3 * g1.norm().item()
+
+
+def test_prefetched_prefix_gives_the_same_steps(built_lib):
+    """InternVLAN1SftTrainer.prefetch: the frozen prefix of micro-batch i + 1 runs one step ahead on a second stream, in a twin engine over the
+    same weights, while step i's latent-query rows / System-1 loss / backward / optimiser launch run. Same kernels on the same inputs:
+    with the learning rate at 0 every step's loss equals the run that prefills inside each step (to the fp32 atomics of the attention
+    backward); with the real schedule the two trajectories stay together as closely as two runs of the SAME schedule do (Adam turns the
+    unordered-atomics noise of near-zero gradient entries into +-lr updates, so step >= 2 is compared at 2e-3)."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+    from internnav_amd.trainer import InternVLAN1SftTrainer
+
+    cfg = W.QWEN_TEST_CFG
+    B, T = 2, 2
+    sd_q = W.qwen_state_dict(seed=11, cfg=cfg)
+    sd_s = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
+    b0, noise, t_index, inp = _batch(cfg, B, T, seed=3)
+    b1 = _batch(cfg, B, T, seed=4)[0]
+    b1["input_ids"] = b1["input_ids"].clone()
+    b1["input_ids"][:, 5:20] = (b1["input_ids"][:, 5:20] + 7) % 1000          # a different prompt: the twin's cache must hold ITS prefix
+    batches = [b0, b1, dict(b0), dict(b1)]
+    for lr, tol in ((1e-30, 2e-6), (1e-4, 2e-3)):       # 1e-30: the fp32 master weights do not move
+        runs = []
+        for pipelined in (False, True):
+            eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+            tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100, dropout=0.0, lr=lr, min_lr=lr / 10)
+            tr.step_idx = 5
+            losses = []
+            for i in range(4):
+                nxt = batches[i + 1] if (pipelined and i + 1 < 4) else None
+                losses.append(tr.training_step(batches[i], noise, t_index, next_batch=nxt).item())
+            if pipelined:
+                assert len(tr._engines) == 2 and tr._engines[1].layers[0]["qkv_w"] is eng.layers[0]["qkv_w"]      # weights shared, not copied
+                assert tr._engines[1].layers[0]["kv"].data_ptr() != eng.layers[0]["kv"].data_ptr()
+                assert tr.engine is tr._engines[1] and tr._pf is None                                             # 4 steps: 0, 1, 0, 1
+            runs.append((losses, tr.P.p32.clone()))
+        (l_seq, p_seq), (l_pipe, p_pipe) = runs
+        print(f"lr {lr}: losses in-step prefix", l_seq, "prefetched", l_pipe, "weights rel diff", ((p_seq - p_pipe).norm() / p_seq.norm()).item())
+        assert l_seq[0] != l_seq[1]                                           # the two prompts do differ
+        assert abs(l_seq[0] - l_pipe[0]) <= 2e-6 * abs(l_seq[0])              # step 0 runs before anything was prefetched
+        for a, b in zip(l_seq, l_pipe):
+            assert abs(a - b) <= tol * abs(a)
+        if lr < 1e-20:
+            assert abs(l_seq[0] - l_seq[2]) <= 2e-6 * abs(l_seq[0]) and abs(l_pipe[1] - l_pipe[3]) <= 2e-6 * abs(l_pipe[1])   # same batch, same weights

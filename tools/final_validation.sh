@@ -18,6 +18,8 @@ timeout 600 python bench.py --no-cpu-baseline --prefix-kv > $R/gpurun_out/${TAG}
 timeout 600 python bench.py --workload navdp_s1 > $R/gpurun_out/${TAG}_bench_navdp_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload unet1d_s1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unet1d_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_sft.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --workload sft --steps 10 --warmup 2 --no-cpu-baseline --no-prefetch > $R/gpurun_out/${TAG}_bench_sft_noprefetch.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-s1-merge-images > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_merge_images.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --workload host_stub --gpus 8 --steps 20 > $R/gpurun_out/${TAG}_bench_host_stub_8ranks.json 2>> $R/gpurun_out/${TAG}_bench.err
 fi
 timeout 300 python tools/step_breakdown.py > $R/gpurun_out/${TAG}_step_breakdown.log 2>&1
@@ -46,6 +48,8 @@ fi
 cd $R
 if [ -x tools/native/chain_sweep ]; then
   timeout 90 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_rowpanel.txt > $R/gpurun_out/${TAG}_native_rowpanel.log 2>&1
+  timeout 90 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_w4.txt > $R/gpurun_out/${TAG}_native_w4.log 2>&1
+  timeout 90 tools/native/chain_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_w4_chain.txt spec > $R/gpurun_out/${TAG}_native_w4_chain.log 2>&1
   timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so all part > $R/gpurun_out/${TAG}_native_chain_partitions.log 2>&1
   timeout 20 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
   timeout 20 tools/native/attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_attn.log 2>&1
