@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 38 / 39 = gemm_bf16_w4_kernel<256, 0|1> (four-wave 256x256 tile), 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
@@ -92,6 +92,7 @@ int ina_gemm_bf16(const ina_gemm_args* args, void* stream);
 /* Which kernel ina_gemm_bf16 would run for these arguments - validation and tile selection only, nothing is launched and no GPU is needed
  * (the selection is host arithmetic on M / N / K, the epilogue and force_cfg): *kernel = 1-8 register-staged tiles, 11-29 / 33 LDS-DMA tiles
  * (18 = 256x256 ping-pong, 21 = 192x256 ping-pong, 22 / 26 / 27 single-buffer tiles of the d = 384 heads, 33 = 256x256 with 16 waves),
+ * 34-37 row-panel kernels (K = 384), 38 / 39 the 256x256 tile on four waves of 128x128 (39 is selected for wide no-residual K = 2048 .. 4096 GEMMs),
  * 30 = weight streaming with the fused input RMSNorm, 31 / 32 = weight streaming (M <= 64). Returns non-zero (and sets ina_last_error)
  * exactly when ina_gemm_bf16 would reject the arguments. */
 int ina_gemm_select(const ina_gemm_args* args, int* kernel);
@@ -128,7 +129,8 @@ typedef struct ina_attn_args {
     float drop_scale;
     int32_t kernel;         /* 0 = automatic (long dense shapes run the 32-rows-per-wave kernel of attention_wide.hip, everything else the
                              * 16-rows-per-wave kernel), 1 = the 16-rows-per-wave kernel, 2 = the 32-rows-per-wave kernel (an error outside its
-                             * contract: d 64 / 80 / 128, Lq and Lk >= 128, no head gate / accumulate / dropout). Same result up to the bf16
+                             * contract: d 64 / 80 / 128, Lq and Lk >= 128 - or packed d-80 sequences of <= 64 tokens, the Qwen ViT windows - no head gate /
+                             * accumulate / dropout). Same result up to the bf16
                              * rounding of P and O; parity tests pin both and compare them. */
     int32_t _pad0;
     const uint32_t* drop_salt; /* training, optional: one device word ADDED to drop_seed when the kernel starts - a launch sequence captured in a

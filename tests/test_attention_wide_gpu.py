@@ -127,3 +127,28 @@ def test_wide_attention_varlen_long_sequences_in_a_fused_qkv_buffer(ops):
         ref = _ref(q[None, o:o + n], k[None, o:o + n], v[None, o:o + n], D ** -0.5)[0]
         _check(out[o:o + n], ref, what=f"varlen sequence of {n}")
         o += n
+
+
+def test_window_attention_on_the_wide_kernel(ops):
+    """Qwen2.5-VL ViT windows (28 of 32 blocks): packed d-80 sequences of at most 64 tokens - 64, 32, 32 and 16 tokens at the ragged edges of a
+    28 x 28 grid - as strided views of the fused qkv buffer. Round 4: these run on the 32-rows-per-wave kernel with 2 waves and ONE K / V
+    buffer (kernel = 0 / 2); kernel = 1 pins the 16-rows-per-wave kernel. Both against the fp32 formula and against each other."""
+    g = torch.Generator().manual_seed(5)
+    H, D = 16, 80
+    lens = [64, 64, 32, 64, 16, 32, 64, 64, 7, 64, 33, 64]
+    T = sum(lens)
+    qkv = _rand((T, 3, H, D), g)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=_dev())
+    outs = {kern: ops.attention(q, k, v, cu_q=cu, cu_k=cu, max_q=64, max_k=64, kernel=kern) for kern in (0, 1, 2)}
+    assert torch.equal(outs[0], outs[2])                     # the automatic rule takes the wide kernel for this shape
+    o = 0
+    for n in lens:
+        ref = _ref(q[o:o + n][None], k[o:o + n][None], v[o:o + n][None], D ** -0.5)[0]
+        for kern in (1, 2):
+            _check(outs[kern][o:o + n], ref, what=f"window of {n} tokens, kernel {kern}")
+        o += n
+    assert (outs[1].float() - outs[2].float()).abs().max().item() < 3e-2
+    with pytest.raises(RuntimeError, match="kernel = 2"):     # the same packing at d = 64 is outside the wide kernel's contract
+        q64 = _rand((T, H, 64), g)
+        ops.attention(q64, q64, q64, cu_q=cu, cu_k=cu, max_q=64, max_k=64, kernel=2)
