@@ -853,15 +853,20 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, kernel=None):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
-    bench): average FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per GEMM launch of the same workload, or None if not collected."""
+    bench): average FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE per GEMM launch of the same workload, or None if not collected.
+    Entries may carry `by_kernel` (bench-line kernel name -> entry): the one of the kernel the line names is reported."""
     f = ROOT / "profiles" / "pmc_traffic.json"
     if not f.exists():
         return None
     t = json.loads(f.read_text()).get(workload)
     if not t:
         return None
+    if "by_kernel" in t:
+        t = t["by_kernel"].get(kernel)
+        if not t:
+            return None
     return {"bytes_per_launch": round((t["read_MB_per_launch_x2_corrected"] + t["write_MB_per_launch"]) * 1e6), "kernel": t["kernel"], "source": t["source"]}
 
 
@@ -979,7 +984,7 @@ def main():
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_tflop_per_launch": round(dom["flops"] / max(dom["launches"], 1) / 1e12, 4),
             "algorithmic_mbytes_per_launch": round(dom.get("bytes", 0.0) / max(dom["launches"], 1) / 1e6, 1),      # operands + output once (2MK + 2NK + out)
-            "traffic": pmc_traffic(a.workload),
+            "traffic": pmc_traffic(a.workload, dom_name),
             "gemm_class_blend": {"what": "all tiled MFMA GEMM launches of the instrumented pass (every tile config)", "achieved": round(blend, 1),
                                  "frac": round(blend / PEAK_BF16_TFLOPS, 4)},
             "per_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["flops"] / 1e12, 3), "gbyte": round(v.get("bytes", 0.0) / 1e9, 2),

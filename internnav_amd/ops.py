@@ -52,6 +52,8 @@ def _f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 def _as2d(x: torch.Tensor) -> torch.Tensor:
     assert x.stride(-1) == 1, "last dimension must be contiguous"
+    if x.dim() == 2:          # the common case: no new view object (every ops call runs on the host's launch-issue path)
+        return x
     return x.reshape(-1, x.shape[-1]) if x.is_contiguous() else x
 
 

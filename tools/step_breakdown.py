@@ -26,17 +26,25 @@ for m, s in wl.s2.items():
     print(f"S2 whole graph, {m} envs: {t(s['graph']):.1f} ms   prefill graph {t(wl.gP[m]):.1f} ms   decode+latents graph {t(wl.gD[m]):.1f} ms")
 print(f"S1 graph, 64 envs: {t(wl.s1_graph):.1f} ms")
 for nA, g in wl.gA.items():
-    print(f"S1 graph, {nA} envs: {t(g):.1f} ms")
+    print(f"S1 graph, {nA} envs{' (without the look-down encoder pass)' if wl.merge_images else ''}: {t(g):.1f} ms")
+for (nA, m_), g in wl.gAimg.items():
+    print(f"look-down encoder pass (DINOv2, MemoryEncoder, QFormer) over {nA} + {m_} envs: {t(g):.1f} ms")
 for m, g in wl.gB.items():
-    print(f"S1 graph (small engine), {m} envs: {t(g):.1f} ms")
+    print(f"S1 graph (small engine{', from the projected latents on' if wl.merge_images else ''}), {m} envs: {t(g):.1f} ms")
 m = max(wl.mb)
 nA = 64 - m
+
+
+def side_call():
+    if wl.merge_images:
+        wl.gAimg[(nA, m)]()
+    wl.gA[nA]()
 
 
 def both():
     wl.side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(wl.side):
-        wl.gA[nA]()
+        side_call()
     wl.gD[m]()
     torch.cuda.current_stream().wait_stream(wl.side)
 
@@ -47,7 +55,7 @@ print(f"decode+latents ({m} envs) || S1 ({nA} envs): {t(both):.1f} ms")
 def both3():
     wl.side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(wl.side):
-        wl.gA[nA]()
+        side_call()
     wl.gD[m]()
     wl.gB[m]()
     torch.cuda.current_stream().wait_stream(wl.side)
@@ -61,7 +69,7 @@ main = torch.cuda.current_stream()
 ev["start"].record(main)
 wl.side.wait_stream(main)
 with torch.cuda.stream(wl.side):
-    wl.gA[nA]()
+    side_call()
     ev["s1a"].record(wl.side)
 wl.gD[m]()
 ev["dec"].record(main)
