@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="frozen prefix (ViT + prefill) of every micro-batch inside its own step, on the main stream (round-3 / early round-4 schedule) "
                          "instead of one step ahead on the prefetch stream (InternVLAN1SftTrainer.prefetch)")
+    ap.add_argument("--prefetch-first", action="store_true", help="A/B: issue the next prefix before this step's own launches (first version of the pipeline)")
     ap.add_argument("--no-graph-s1", action="store_true", help="System-1 loss + backward as eager launches (round-3 path) instead of one hipGraph replay")
     return ap.parse_args()
 
@@ -64,6 +65,7 @@ def build(a, dev, rank):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1)
     tr.step_idx = 10          # past the warm-up: non-zero learning rate
+    tr.prefetch_first = bool(getattr(a, "prefetch_first", False))
     g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
     lim = qcfg["image_token_id"] - 16
     ids = torch.randint(0, lim, (B, S + qcfg["n_query"]), device=dev, generator=g)

@@ -87,6 +87,7 @@ class InternVLAN1SftTrainer:
         self._engines, self._lqs, self._cur = [engine], [self.lq], 0
         self._pf = None               # (batch object, engine slot, prefill state, completion event) of the prefix in flight
         self._pf_stream = None
+        self.prefetch_first = False   # A/B switch: issue the next prefix BEFORE this step's own launches (the first version of the pipeline)
         self.total_steps, self.lr, self.min_lr = total_steps, lr, min_lr
         self.warmup_steps = math.ceil(total_steps * warmup_ratio)
         self.wd, self.max_norm, self.betas, self.eps = weight_decay, max_grad_norm, betas, eps
@@ -144,6 +145,16 @@ class InternVLAN1SftTrainer:
                          loss_scale: float = 1.0, state: Optional[dict] = None) -> torch.Tensor:
         """loss of the micro-batch; gradients are accumulated into the flat store. Gradient accumulation over k micro-batches = k calls with
         loss_scale = 1 / k (HF Trainer divides the loss by gradient_accumulation_steps before backward) and one optimizer_step()."""
+        loss, dh = self._loss_and_dh(batch, noise, t_index, loss_scale, state)
+        self._lq_backward(dh)
+        return loss
+
+    def _lq_backward(self, dh: torch.Tensor):
+        nq = self.engine.latent_q.shape[0]
+        self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
+
+    def _loss_and_dh(self, batch: dict, noise, t_index, loss_scale: float, state: Optional[dict]):
+        """frozen prefix (prefetched or now) -> latent-query rows -> System-1 loss and gradients; returns (loss, d loss / d latent hidden states)."""
         e, dev = self.engine, self.device
         B = batch["input_ids"].shape[0]
         nq = e.latent_q.shape[0]
@@ -167,8 +178,7 @@ class InternVLAN1SftTrainer:
         else:
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_depths"].to(dev), batch["traj_poses"],
                                                 batch["video_frame_num"], noise, t_index, loss_scale=loss_scale, seed=self._mask_seed())
-        self.P.grad(LQ).view(nq, -1).add_(self.lq.backward(dh))
-        return loss
+        return loss, dh
 
     def _prefix(self, e: QwenVLEngine, batch: dict) -> dict:
         """frozen System-2 forward of the tokens before `t_s_pos` (ViT + ragged prefill) on engine e; the KV cache it leaves is the
@@ -193,7 +203,7 @@ class InternVLAN1SftTrainer:
             return state
         return self._prefix(self.engine, batch)
 
-    def prefetch(self, batch: dict):
+    def prefetch(self, batch: dict, after: Optional["torch.cuda.Event"] = None):
         """Start the frozen prefix of a FUTURE micro-batch now, on a second stream and in a second engine over the same weights
         (QwenVLEngine.twin: own activations and KV cache). The prefix reads no trainable tensor, so it may run beside the System-1 loss /
         backward, the latent-query rows and the optimiser launch of the current micro-batch (the MFMA-bound prefill fills the gaps of
@@ -209,7 +219,12 @@ class InternVLAN1SftTrainer:
             self._pf_stream = torch.cuda.Stream(device=self.device)
         slot = 1 - self._cur
         main = torch.cuda.current_stream()
-        self._pf_stream.wait_stream(main)      # the idle engine's cache was last read by the previous step's latent-query backward
+        # the idle engine's cache was last read by the previous step's latent-query backward: wait for the current stream up to here - or, when the
+        # caller has ALREADY issued part of this step (training_step), only up to the event it recorded before doing so
+        if after is not None:
+            self._pf_stream.wait_event(after)
+        else:
+            self._pf_stream.wait_stream(main)
         _lib.check(_lib.lib().ina_set_workspace_slot(3), "set_workspace_slot")      # library scratch of launches issued beside the main stream's
         try:
             with torch.cuda.stream(self._pf_stream):
@@ -374,11 +389,22 @@ class InternVLAN1SftTrainer:
 
     def training_step(self, batch: dict, noise=None, t_index=None, next_batch: Optional[dict] = None) -> torch.Tensor:
         """next_batch: the micro-batch of the following step, if the caller already has it (a data loader does): its frozen prefix is
-        started on the prefetch stream (prefetch()) as soon as this step's own prefix is in hand, before the rest of this step is issued."""
-        state = self._acquire_prefix(batch)
-        if next_batch is not None:
-            self.prefetch(next_batch)
-        loss = self.forward_backward(batch, noise, t_index, state=state)
+        started on the prefetch stream (prefetch()). Host issue order of a pipelined step: this step's latent-query rows and System-1 graph
+        first (≈ 50 ms of GPU work from ≈ 10 ms of host work), THEN the ≈ 1 100 eager launches of the next prefix (they only have to wait for
+        the state of the stream at the start of this step), then the latent-query backward and the update - so neither stream waits for the
+        host while the other's launches are being issued."""
+        if next_batch is None:
+            loss = self.forward_backward(batch, noise, t_index)
+        else:
+            start = torch.cuda.Event()
+            start.record(torch.cuda.current_stream())
+            state = self._acquire_prefix(batch)
+            if self.prefetch_first:
+                self.prefetch(next_batch)
+            loss, dh = self._loss_and_dh(batch, noise, t_index, 1.0, state)
+            if not self.prefetch_first:
+                self.prefetch(next_batch, after=start)
+            self._lq_backward(dh)
         self.reduce_gradients()
         self.optimizer_step()
         return loss

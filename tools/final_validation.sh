@@ -17,8 +17,8 @@ timeout 600 python bench.py --no-cpu-baseline --num-history 8 --lookdown --steps
 timeout 600 python bench.py --no-cpu-baseline --prefix-kv > $R/gpurun_out/${TAG}_bench_n1_dual_b64_prefixkv.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload navdp_s1 > $R/gpurun_out/${TAG}_bench_navdp_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload unet1d_s1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unet1d_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --workload sft --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_sft.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --workload sft --steps 10 --warmup 2 --no-cpu-baseline --no-prefetch > $R/gpurun_out/${TAG}_bench_sft_noprefetch.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_sft.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline --no-prefetch > $R/gpurun_out/${TAG}_bench_sft_noprefetch.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --no-s1-merge-images > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_merge_images.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --workload host_stub --gpus 8 --steps 20 > $R/gpurun_out/${TAG}_bench_host_stub_8ranks.json 2>> $R/gpurun_out/${TAG}_bench.err
 fi
