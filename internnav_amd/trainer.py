@@ -155,12 +155,10 @@ class InternVLAN1SftTrainer:
 
     def _loss_and_dh(self, batch: dict, noise, t_index, loss_scale: float, state: Optional[dict]):
         """frozen prefix (prefetched or now) -> latent-query rows -> System-1 loss and gradients; returns (loss, d loss / d latent hidden states)."""
-        e, dev = self.engine, self.device
+        dev = self.device
         B = batch["input_ids"].shape[0]
-        nq = e.latent_q.shape[0]
         if state is None:
-            state = self._acquire_prefix(batch)
-        e = self.engine
+            state = self._acquire_prefix(batch)      # may switch self.engine / self.lq to the twin that holds the prefetched prefix
         hq = self.lq.forward(state)
         Tn = batch["traj_images"].shape[1]
         if noise is None:            # internvla_n1.py:261-264 / navdp.py:163-175 (the reference draws inside forward)
