@@ -292,6 +292,61 @@ int main(int argc, char** argv) {
             if (line[0] == '#' || line[0] == '\n') { if (line[0] == '#') fputs(line, stdout); continue; }
             char cn[16];
             int ra, rb, c0, c1, c2, c3, reps = 3;
+            if (!strncmp(line, "mix", 3)) {
+                // `mix s1_rows s1_blocks decode_rows decode_passes [reps]`: the concurrent phase of the n1_dual step reduced to its GEMMs - the d = 384 chain of the
+                // System-1 call (s1_blocks x 4 tiled GEMMs over s1_rows rows) on one stream beside decode_passes weight-streaming passes of the decoder
+                // (28 x 4 GEMMs at M = decode_rows <= 64) on another: each chain alone, then both together with the end time of each stream
+                int sr, sb, dr, dp;
+                if (sscanf(line, "%*s %d %d %d %d %d", &sr, &sb, &dr, &dp, &reps) < 4) continue;
+                ChainDef cs = defs[2], cd = defs[0];
+                cs.layers = sb;
+                Inst xs = make_inst(cs, sr, 300), xd = make_inst(cd, dr, 400);
+                // the decoder passes stream DISTINCT weights per layer (14.1 GB per pass, as the engine does): one shared layer would sit in the Infinity Cache
+                static void* Wd[28][4];
+                if (!Wd[0][0])
+                    for (int l = 0; l < 28; ++l)
+                        for (int gi = 0; gi < 4; ++gi) Wd[l][gi] = dalloc((size_t)cd.g[gi].N * cd.g[gi].K * 2, 900 + 4 * l + gi, 0.03f);
+                const Policy au{{0, 0, 0, 0}, {0, 0, 0, 0}};
+                hipEvent_t es, ed;
+                HIP_OK(hipEventCreate(&es)); HIP_OK(hipEventCreate(&ed));
+                auto run = [&](bool with_s1, bool with_dec, double& t_s1, double& t_dec) {
+                    std::vector<double> a, b;
+                    for (int r = 0; r < reps; ++r) {
+                        HIP_OK(hipDeviceSynchronize());
+                        HIP_OK(hipEventRecord(e0, s1));
+                        HIP_OK(hipStreamWaitEvent(s2, e0, 0));
+                        // issue order: one decoder pass, then its share of the System-1 blocks (the host must not starve either stream)
+                        const int per = with_dec ? (cs.layers + dp - 1) / dp : cs.layers;
+                        int l1 = 0;
+                        for (int pass = 0; pass < (with_dec ? dp : 1); ++pass) {
+                            if (with_dec)
+                                for (int l = 0; l < cd.layers; ++l)
+                                    for (int gi = 0; gi < 4; ++gi) launch_one(cd, xd, Wd[l % 28], gi, au, s2);
+                            if (with_s1)
+                                for (int k = 0; k < per && l1 < cs.layers; ++k, ++l1)
+                                    for (int gi = 0; gi < 4; ++gi) launch_one(cs, xs, Wt[2], gi, au, s1);
+                        }
+                        HIP_OK(hipEventRecord(es, s1));
+                        HIP_OK(hipEventRecord(ed, s2));
+                        HIP_OK(hipEventSynchronize(es)); HIP_OK(hipEventSynchronize(ed));
+                        float ms1 = 0, ms2 = 0;
+                        HIP_OK(hipEventElapsedTime(&ms1, e0, es));
+                        HIP_OK(hipEventElapsedTime(&ms2, e0, ed));
+                        a.push_back(ms1); b.push_back(ms2);
+                    }
+                    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+                    t_s1 = a[a.size() / 2]; t_dec = b[b.size() / 2];
+                };
+                double s_alone, d_alone, s_both, d_both, dummy;
+                run(true, false, s_alone, dummy);
+                run(false, true, dummy, d_alone);
+                run(true, true, s_both, d_both);
+                printf("mix  System-1 GEMM chain %d rows x %d blocks alone %8.3f ms | decoder weight-streaming %d rows x %d passes alone %8.3f ms | together: System-1 ends %8.3f, "
+                       "decode ends %8.3f ms (sum alone %8.3f, max %8.3f)\n", sr, sb, s_alone, dr, dp, d_alone, s_both, d_both, s_alone + d_alone, std::max(s_alone, d_alone));
+                fflush(stdout);
+                free_inst(xs); free_inst(xd);
+                continue;
+            }
             if (sscanf(line, "%15s %d %d %d %d %d %d %d", cn, &ra, &rb, &c0, &c1, &c2, &c3, &reps) < 7) continue;
             const int d = !strcmp(cn, "llm") ? 0 : !strcmp(cn, "vit") ? 1 : 2;
             if (d != cur || ia.M != ra || ib.M != rb) {
