@@ -296,8 +296,16 @@ int main(int argc, char** argv) {
                 // `mix s1_rows s1_blocks decode_rows decode_passes [reps]`: the concurrent phase of the n1_dual step reduced to its GEMMs - the d = 384 chain of the
                 // System-1 call (s1_blocks x 4 tiled GEMMs over s1_rows rows) on one stream beside decode_passes weight-streaming passes of the decoder
                 // (28 x 4 GEMMs at M = decode_rows <= 64) on another: each chain alone, then both together with the end time of each stream
-                int sr, sb, dr, dp;
-                if (sscanf(line, "%*s %d %d %d %d %d", &sr, &sb, &dr, &dp, &reps) < 4) continue;
+                int sr, sb, dr, dp, prio = 0;
+                if (sscanf(line, "%*s %d %d %d %d %d %d", &sr, &sb, &dr, &dp, &reps, &prio) < 4) continue;
+                // optional 6th number: priority of the DECODE stream (hipStreamCreateWithPriority; -1 = high, 0 = default, 1 = low -> then System-1 is the default one)
+                hipStream_t sdec = s2;
+                if (prio != 0) {
+                    int lo = 0, hi = 0;
+                    HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    HIP_OK(hipStreamCreateWithPriority(&sdec, hipStreamNonBlocking, prio < 0 ? hi : lo));
+                    printf("# decode stream priority %d (device range: lowest %d .. highest %d)\n", prio < 0 ? hi : lo, lo, hi);
+                }
                 ChainDef cs = defs[2], cd = defs[0];
                 cs.layers = sb;
                 Inst xs = make_inst(cs, sr, 300), xd = make_inst(cd, dr, 400);
@@ -314,20 +322,20 @@ int main(int argc, char** argv) {
                     for (int r = 0; r < reps; ++r) {
                         HIP_OK(hipDeviceSynchronize());
                         HIP_OK(hipEventRecord(e0, s1));
-                        HIP_OK(hipStreamWaitEvent(s2, e0, 0));
+                        HIP_OK(hipStreamWaitEvent(sdec, e0, 0));
                         // issue order: one decoder pass, then its share of the System-1 blocks (the host must not starve either stream)
                         const int per = with_dec ? (cs.layers + dp - 1) / dp : cs.layers;
                         int l1 = 0;
                         for (int pass = 0; pass < (with_dec ? dp : 1); ++pass) {
                             if (with_dec)
                                 for (int l = 0; l < cd.layers; ++l)
-                                    for (int gi = 0; gi < 4; ++gi) launch_one(cd, xd, Wd[l % 28], gi, au, s2);
+                                    for (int gi = 0; gi < 4; ++gi) launch_one(cd, xd, Wd[l % 28], gi, au, sdec);
                             if (with_s1)
                                 for (int k = 0; k < per && l1 < cs.layers; ++k, ++l1)
                                     for (int gi = 0; gi < 4; ++gi) launch_one(cs, xs, Wt[2], gi, au, s1);
                         }
                         HIP_OK(hipEventRecord(es, s1));
-                        HIP_OK(hipEventRecord(ed, s2));
+                        HIP_OK(hipEventRecord(ed, sdec));
                         HIP_OK(hipEventSynchronize(es)); HIP_OK(hipEventSynchronize(ed));
                         float ms1 = 0, ms2 = 0;
                         HIP_OK(hipEventElapsedTime(&ms1, e0, es));
@@ -345,6 +353,7 @@ int main(int argc, char** argv) {
                        "decode ends %8.3f ms (sum alone %8.3f, max %8.3f)\n", sr, sb, s_alone, dr, dp, d_alone, s_both, d_both, s_alone + d_alone, std::max(s_alone, d_alone));
                 fflush(stdout);
                 free_inst(xs); free_inst(xd);
+                if (sdec != s2) HIP_OK(hipStreamDestroy(sdec));
                 continue;
             }
             if (sscanf(line, "%15s %d %d %d %d %d %d %d", cn, &ra, &rb, &c0, &c1, &c2, &c3, &reps) < 7) continue;
