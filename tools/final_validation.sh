@@ -51,6 +51,7 @@ if [ -x tools/native/chain_sweep ]; then
   timeout 90 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_w4.txt > $R/gpurun_out/${TAG}_native_w4.log 2>&1
   timeout 90 tools/native/chain_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_w4_chain.txt spec > $R/gpurun_out/${TAG}_native_w4_chain.log 2>&1
   timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so all part > $R/gpurun_out/${TAG}_native_chain_partitions.log 2>&1
+  timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_phase_mix.txt spec > $R/gpurun_out/${TAG}_native_phase_mix.log 2>&1
   timeout 20 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
   timeout 20 tools/native/attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_attn.log 2>&1
 fi
