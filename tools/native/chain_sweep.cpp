@@ -296,8 +296,8 @@ int main(int argc, char** argv) {
                 // `mix s1_rows s1_blocks decode_rows decode_passes [reps]`: the concurrent phase of the n1_dual step reduced to its GEMMs - the d = 384 chain of the
                 // System-1 call (s1_blocks x 4 tiled GEMMs over s1_rows rows) on one stream beside decode_passes weight-streaming passes of the decoder
                 // (28 x 4 GEMMs at M = decode_rows <= 64) on another: each chain alone, then both together with the end time of each stream
-                int sr, sb, dr, dp, prio = 0;
-                if (sscanf(line, "%*s %d %d %d %d %d %d", &sr, &sb, &dr, &dp, &reps, &prio) < 4) continue;
+                int sr, sb, dr, dp, prio = 0, dcfg = 0;
+                if (sscanf(line, "%*s %d %d %d %d %d %d %d", &sr, &sb, &dr, &dp, &reps, &prio, &dcfg) < 4) continue;
                 // optional 6th number: priority of the DECODE stream (hipStreamCreateWithPriority; -1 = high, 0 = default, 1 = low -> then System-1 is the default one)
                 hipStream_t sdec = s2;
                 if (prio != 0) {
@@ -315,6 +315,8 @@ int main(int argc, char** argv) {
                     for (int l = 0; l < 28; ++l)
                         for (int gi = 0; gi < 4; ++gi) Wd[l][gi] = dalloc((size_t)cd.g[gi].N * cd.g[gi].K * 2, 900 + 4 * l + gi, 0.03f);
                 const Policy au{{0, 0, 0, 0}, {0, 0, 0, 0}};
+                const Policy pd{{dcfg, dcfg, dcfg, dcfg}, {0, 0, 0, 0}};      // optional 7th number: force_cfg of the decoder GEMMs (31 = split-K + epilogue kernel, 32 = fused)
+                if (dcfg) printf("# decoder GEMMs forced to cfg %d\n", dcfg);
                 hipEvent_t es, ed;
                 HIP_OK(hipEventCreate(&es)); HIP_OK(hipEventCreate(&ed));
                 auto run = [&](bool with_s1, bool with_dec, double& t_s1, double& t_dec) {
@@ -329,7 +331,7 @@ int main(int argc, char** argv) {
                         for (int pass = 0; pass < (with_dec ? dp : 1); ++pass) {
                             if (with_dec)
                                 for (int l = 0; l < cd.layers; ++l)
-                                    for (int gi = 0; gi < 4; ++gi) launch_one(cd, xd, Wd[l % 28], gi, au, sdec);
+                                    for (int gi = 0; gi < 4; ++gi) launch_one(cd, xd, Wd[l % 28], gi, pd, sdec);
                             if (with_s1)
                                 for (int k = 0; k < per && l1 < cs.layers; ++k, ++l1)
                                     for (int gi = 0; gi < 4; ++gi) launch_one(cs, xs, Wt[2], gi, au, s1);
