@@ -884,7 +884,10 @@ def main():
         return bench_sft.main()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from internnav_amd.dist import under_launcher
+
+    # a scheduler's WORLD_SIZE without a rank is not a launcher: only a launcher's environment makes this process one of N ranks
+    world = int(os.environ["WORLD_SIZE"]) if under_launcher() else 1
     host_stub = a.workload == "host_stub"
     from internnav_amd import runtime
 
@@ -907,9 +910,24 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         pinned = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # own slice of the host cores per rank
+    t_setup = time.perf_counter()
     wl = {"n1_dual": N1Dual, "s2_only": N1Dual, "navdp_s1": NavDPS1, "unet1d_s1": UNet1DS1, "host_stub": HostStub}[a.workload](a, dev, rank)
+    t_weights = time.perf_counter() - t_setup
     if not a.no_graph:
         wl.capture()
+    if not host_stub:
+        torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    # what the process group REALLY is (not an echo of the environment): backend and size as torch.distributed reports them, and every
+    # rank's setup time (weights + graph capture) so an N-rank run is known to fit the driver's timeout
+    dist_info = {"backend": None, "ranks": 1, "setup_s_per_rank": [round(t_setup, 1)], "weights_s_per_rank": [round(t_weights, 1)]}
+    if world > 1:
+        ts = torch.tensor([t_setup, t_weights], device=dev, dtype=torch.float64)
+        allt = torch.empty(world * 2, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, ts)
+        allt = allt.view(world, 2).cpu()
+        dist_info = {"backend": str(dist.get_backend()), "ranks": int(dist.get_world_size()),
+                     "setup_s_per_rank": [round(float(x), 1) for x in allt[:, 0]], "weights_s_per_rank": [round(float(x), 1) for x in allt[:, 1]]}
     gathered = torch.empty((world * wl.action_shape[0],) + tuple(wl.action_shape[1:]), device=dev,
                            dtype=torch.int32 if a.workload in ("n1_dual", "s2_only", "host_stub") else torch.float32) if world > 1 else None
 
@@ -957,7 +975,8 @@ def main():
         time.sleep(0.2)
         print(json.dumps({"metric": "policy steps/sec/node", "value": round(value, 2), "unit": "policy steps/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "int32", "data": "synthetic trajectories", "rccl_ranks": 0, "gloo_ranks": world,
+                          "dtype": "int32", "data": "synthetic trajectories", "rccl_ranks": 0, "gloo_ranks": dist_info["ranks"] if dist_info["backend"] == "gloo" else 0,
+                          "dist": dist_info,
                           "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}", "device": arch,
                                           "host_cores_per_rank": pinned, "host_cores": len(os.sched_getaffinity(0)) if pinned is None else None}, **wl.desc),
                           "roofline": None, "cpu_baseline": None}), flush=True)
@@ -1003,7 +1022,8 @@ def main():
             "value": round(value, 2), "unit": getattr(wl, "unit", "policy steps/s"), "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at the true shapes, synthetic camera frames / prompts)",
-            "rccl_ranks": world,
+            # ranks of the process group torch.distributed initialised on backend "nccl" (= RCCL on ROCm); 1 = no process group (single GPU)
+            "rccl_ranks": dist_info["ranks"] if (world == 1 or dist_info["backend"] == "nccl") else 0, "dist": dist_info,
             "config": dict({"workload": wl.name, "envs_per_gpu": wl.B, "parallelism": f"dp{world}", "calibration": calib,
                             "launch": "eager" if a.no_graph else "hipGraph replay",
                             "schedule": ("S2 ViT+prefill, then S2 decode+latent queries || S1(envs keeping their latents) on a side stream, then S1(S2 envs)"

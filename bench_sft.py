@@ -62,7 +62,9 @@ def build(a, dev, rank):
     weights = synthetic.LazyDeviceWeights(synthetic.qwen_spec(qcfg), dev, seed=0)
     eng = QwenVLEngine(weights, qcfg, dev, max_seqs=B, max_seq_len=(S + qcfg["n_query"] + 63) // 64 * 64, max_patches=B * F * per)
     sd_s = {k: v.float() for k, v in synthetic.materialize(synthetic.n1_nextdit_spec(), 0).items()}
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from internnav_amd.dist import under_launcher
+
+    world = int(os.environ["WORLD_SIZE"]) if under_launcher() else 1
     tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1)
     tr.step_idx = 10          # past the warm-up: non-zero learning rate
     tr.prefetch_first = bool(getattr(a, "prefetch_first", False))
@@ -160,7 +162,11 @@ def main():
     from internnav_amd.dist import maybe_self_spawn
 
     maybe_self_spawn(str(Path(__file__).resolve()), a.gpus)
-    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    from internnav_amd.dist import under_launcher
+
+    # a scheduler's WORLD_SIZE without a rank is not a launcher
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ["WORLD_SIZE"]) if under_launcher() else 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     from internnav_amd import runtime
@@ -224,7 +230,8 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         step_tflops = fl["total"] * a.steps / dt / 1e12
         line = {
-            "metric": "SFT samples/sec/node", "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "rccl_ranks": world, "steps": a.steps, "warmup": a.warmup,
+            "metric": "SFT samples/sec/node", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
+            "rccl_ranks": int(dist.get_world_size()) if dist is not None else 1, "dist_backend": str(dist.get_backend()) if dist is not None else None, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded random weights at the true shapes, synthetic prompts / frames / trajectories)",
             "config": {"workload": f"sft_nextdit_async_b{info['B']}x{info['T']}", "micro_batch_per_gpu": info["B"], "subgoals_per_sample": info["T"],

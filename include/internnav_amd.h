@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 2
+#define INA_ABI_VERSION 3
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0

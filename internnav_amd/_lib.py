@@ -321,6 +321,9 @@ SYMBOLS = {
 }
 
 _lib = None
+# the struct layouts above mirror include/internnav_amd.h at THIS version of the C-ABI (INA_ABI_VERSION there): lib() refuses a shared object
+# built from another version - a stale .so would read pointers at the wrong offsets
+ABI_VERSION = 3
 
 
 class EngineError(RuntimeError):
@@ -340,6 +343,9 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(h, name)  # AttributeError if the .so is stale
             fn.restype, fn.argtypes = res, args
+        if h.ina_abi_version() != ABI_VERSION:
+            raise EngineError(f"{LIB_PATH} was built for C-ABI version {h.ina_abi_version()}, these bindings are version {ABI_VERSION}: "
+                              "rebuild it (`python -m internnav_amd.build`)")
         _lib = h
     return _lib
 

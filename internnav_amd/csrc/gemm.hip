@@ -215,8 +215,9 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
         // instead of 64 FLOP per operand byte, 3 workgroups per CU: +14-15 % (740-816 vs 632-704 TF/s, profiles/r02m_gemm_s1_tile_sweep.log)
         if (p.K <= 512 && p.N >= 1024 && p.M >= 4096) cfg = p.N >= 1536 ? 26 : 27;
         // K = 384, wide output, many rows, plain or SwiGLU epilogue (the fused q|k|v|q2 and SwiGLU projections of a NextDiT block over >= 16 envs):
-        // row-panel kernels - activations as register-resident MFMA fragments, only W streams through LDS (gemm_rowpanel.hip). Bit-equal
-        // to the tiled kernels. Isolated they are within +-10 % of cfg 26 (0.75-0.86 PF/s, profiles/r04b_native_rowpanel.log); inside the
+        // row-panel kernels - activations as register-resident MFMA fragments, only W streams through LDS (gemm_rowpanel.hip). NOT bit-equal
+        // to the tiled kernels (K in ascending order but by 16-wide MFMA steps: last-bit differences in < 20 % of the bf16 outputs,
+        // tests/test_ops_gpu.py::test_gemm_rowpanel_k384). Isolated they are within +-10 % of cfg 26 (0.75-0.86 PF/s, profiles/r04b_native_rowpanel.log); inside the
         // System-1 call, where the tiled kernel's operands start cold, the call of 64 envs goes 84.2 -> 75.0 ms (r04f_s1_variants.log).
         // Below ~16 k rows their one-workgroup-per-256-rows grid leaves the chip empty (7168 rows: 72 vs 17 us).
         // The bias + activation epilogue of those kernels exists (force_cfg 34 / 35) but is NOT selected: the biased q|k|v / GELU-FFN

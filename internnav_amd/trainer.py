@@ -67,6 +67,7 @@ class InternVLAN1SftTrainer:
         self.engine, self.device = engine, torch.device(device)
         self.graph_s1 = bool(graph_s1)
         self._s1_graphs: Dict[tuple, tuple] = {}
+        self.max_s1_graphs = 2
         self._salt = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device.type == "cuda" else None
         nq, H = engine.latent_q.shape
         sd = dict(s1_state_dict)
@@ -277,8 +278,13 @@ class InternVLAN1SftTrainer:
             self.P.g32.copy_(keep)
             del keep
             ent = (g, st, stage)
+            # every entry pins a captured activation pool + static input copies (GBs): keep the two most recently used geometries only
+            # (a ragged last batch beside the regular one); anything older is released and re-captured if it ever comes back
+            while len(self._s1_graphs) >= self.max_s1_graphs:
+                self._s1_graphs.pop(next(iter(self._s1_graphs)))
             self._s1_graphs[key] = ent
         else:
+            self._s1_graphs[key] = self._s1_graphs.pop(key)      # most recently used last
             g, st, _ = ent
             st["hq"].copy_(hq)
             st["noise"].copy_(noise)
@@ -288,7 +294,9 @@ class InternVLAN1SftTrainer:
                 st[n].copy_(batch[n])
         self._salt.fill_(self._mask_seed())
         loss, dh = g()
-        return loss, dh
+        # the graph's outputs live in its private pool and are overwritten by the next replay: hand out copies, as the eager path hands out
+        # fresh tensors (a gradient-accumulation loop may keep the k micro-batch losses and reduce them afterwards - ADVICE r4)
+        return loss.clone(), dh.clone()
 
     def _mask_seed(self) -> int:
         """dropout-mask seed of this micro-step: (seed, rank, micro_idx) hashed together (a linear mix collides across ranks / steps)."""

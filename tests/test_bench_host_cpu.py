@@ -88,7 +88,7 @@ def test_bench_rank_logic_world8_gloo_host_stub():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["gloo_ranks"] == 8 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 8 and d["gloo_ranks"] == 8 and d["dist"]["backend"] == "gloo" and d["dist"]["ranks"] == 8 and len(d["dist"]["setup_s_per_rank"]) == 8 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["parallelism"] == "dp8" and d["config"]["envs_per_gpu"] == 64
     # whole-job aggregate: 8 ranks x 64 envs x steps / max-over-ranks time
     assert abs(d["value"] - 8 * 64 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]

@@ -140,6 +140,16 @@ def test_graphed_system1_step_equals_eager_and_redraws_masks(built_lib, system1)
         d = (eager.P.g32 - graph.P.g32).norm().item() / eager.P.g32.norm().item()
         assert d < 1e-3, f"micro-step {k}: accumulated gradients differ by {d:.3e}"        # (accumulates over the three)
     assert len(graph._s1_graphs) == 1
+    # losses held ACROSS replays keep their own values (the graph's static output tensor used to be handed out, so a gradient-
+    # accumulation loop that reduces its k micro-batch losses afterwards got k copies of the last one)
+    held = [graph.forward_backward(b_, n_.to(DEV), t_, loss_scale=0.5) for b_, n_, t_ in ((batch, noise, t_index), (batch2, noise2, t_index2))]
+    ref = [eager.forward_backward(b_, n_.to(DEV), t_, loss_scale=0.5) for b_, n_, t_ in ((batch, noise, t_index), (batch2, noise2, t_index2))]
+    assert held[0].data_ptr() != held[1].data_ptr() and held[0].item() != held[1].item()
+    assert torch.equal(held[0], ref[0]) and torch.equal(held[1], ref[1])
+    # the graph cache is bounded: a third geometry evicts the least recently used one
+    graph.max_s1_graphs = 1
+    graph.forward_backward(batch, noise.to(DEV), t_index, loss_scale=0.25)
+    assert len(graph._s1_graphs) == 1 and next(iter(graph._s1_graphs))[2] == 0.25
     # dropout: fresh masks per replay through the device-side seed word
     drop = InternVLAN1SftTrainer(eng, sd_s, DEV, dropout=0.1, graph_s1=True, **kw)
     l1 = drop.forward_backward(batch, noise.to(DEV), t_index).item()
