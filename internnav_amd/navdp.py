@@ -308,13 +308,27 @@ class NavDPNet(_NavDPBase):
                                            x_init: torch.Tensor, step_noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """goal_point f32 [B,3]; input_images f32 [B,M,224,224,3] in 0..1; input_depths f32 [B,1,224,224,1] metres;
         x_init f32 [B,S,T,3]; step_noise f32 [K,B,S,T,3]  ->  (negative, positive) f32 [B,8,T,3]."""
-        B = goal_point.shape[0]
-        assert B <= self.b_max
+        return self._predict_batch_action_vel(goal_point, input_images, input_depths, x_init, step_noise)
+
+    def predict_nogoal_batch_action_vel(self, input_images: torch.Tensor, input_depths: torch.Tensor, x_init: torch.Tensor,
+                                        step_noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """the zero-goal sibling (navdp_policy.py:323-339): the three goal slots of the condition hold `zeros_like(rgbd_embed[:, 0:1])`
+        instead of the embedded point goal (so only `cond_pos_embed` remains in them); sampler, critic and ranking are the same.
+        Same tensor arguments as the point-goal call minus the goal."""
+        return self._predict_batch_action_vel(None, input_images, input_depths, x_init, step_noise)
+
+    def _predict_batch_action_vel(self, goal_point: Optional[torch.Tensor], input_images: torch.Tensor, input_depths: torch.Tensor,
+                                  x_init: torch.Tensor, step_noise: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        B = input_images.shape[0]
+        assert B <= self.b_max and (goal_point is None or goal_point.shape[0] == B)
         S, T, D, Lc = self.S, self.T, self.D, self.Lc
         self.encode_rgbd(B, input_images, input_depths)
         cond = self.cond[: B * Lc]
-        for j in (1, 2, 3):  # the point-goal embedding fills the three goal slots (navdp_policy.py:162)
-            ops.embed3(goal_point, self.pt_w, self.pt_b, out=cond, pos=self.cond_pos[j:j + 1], rows=B, out_map=(1, Lc, j))
+        for j in (1, 2, 3):  # the goal embedding (point goal, or zeros: table fill) fills the three goal slots (navdp_policy.py:162)
+            if goal_point is None:
+                ops.embed3(None, None, None, out=cond, pos=self.cond_pos[j:j + 1], rows=B, out_map=(1, Lc, j))
+            else:
+                ops.embed3(goal_point, self.pt_w, self.pt_b, out=cond, pos=self.cond_pos[j:j + 1], rows=B, out_map=(1, Lc, j))
         sample = self._denoise(B, x_init, step_noise)
         # critic (navdp_policy.py:172-185): no-goal condition with slots 0..3 masked -> the K/V of cond rows 4.. are reused,
         # rows 0..3 are excluded by kv_start = 4 (memory_mask), no causal mask.

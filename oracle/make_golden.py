@@ -103,6 +103,45 @@ def gold_navdpnet(B=2):
                 oracle_max_abs_diff=d)
 
 
+def gold_navdpnet_nogoal(B=2):
+    """the reference's own `NavDPNet.predict_nogoal_batch_action_vel` (navdp_policy.py:323-339), one env per call as it executes, with the
+    same weights / frames / injected noise as the point-goal fixture (its own file: navdpnet.pt stays byte-identical)."""
+    torch_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        npm = R.navdp_policy_module()
+        cfg = W.NAVDPNET_CFG
+        il = dict(image_size=224, memory_size=cfg["memory_size"], predict_size=cfg["predict_size"], pixel_channel=4,
+                  temporal_depth=cfg["temporal_depth"], heads=cfg["heads"], channels=3, dropout=0.1,
+                  token_dim=cfg["token_dim"], scratch=False, finetune=False)
+        net = npm.NavDPNet(npm.NavDPModelConfig(model_cfg={"model": {}, "local_rank": 0, "il": il}))
+    finally:
+        torch.load = torch_load
+    sd = W.navdpnet_state_dict(seed=0)
+    net = _load_strict(net, sd, allow_missing_prefixes=("pixel_encoder.", "image_encoder.", "pixel_aux_head.", "image_aux_head."))
+    net._device = torch.device("cpu")
+    net.cond_critic_mask = net.cond_critic_mask.float()
+    inp = W.navdpnet_inputs(B, seed=0)
+    negs, poss = [], []
+    with torch.no_grad():
+        for b in range(B):
+            _Inject(npm, net.noise_scheduler, inp["x_init"][b], inp["step_noise"][:, b])
+            real_randn = torch.randn
+            torch.randn = lambda *a, **k: inp["x_init"][b].clone()       # the initial noise of navdp_policy.py:328
+            try:
+                neg, pos = net.predict_nogoal_batch_action_vel(inp["images"][b:b + 1], inp["depths"][b:b + 1])
+            finally:
+                torch.randn = real_randn
+            negs.append(neg)
+            poss.append(pos)
+            net.noise_scheduler.step = net.noise_scheduler.__class__.step.__get__(net.noise_scheduler)
+        neg, pos = torch.stack(negs), torch.stack(poss)
+        o_neg, o_pos, o_fin, o_cr, _ = o_navdp.navdpnet_pointgoal(sd, None, inp["images"], inp["depths"], inp["x_init"], inp["step_noise"], cfg,
+                                                                  return_all=True)
+    d = max((neg - o_neg).abs().max().item(), (pos - o_pos).abs().max().item())
+    return dict(B=B, seed=0, negative=neg, positive=pos, oracle_final=o_fin, oracle_critic=o_cr, oracle_max_abs_diff=d)
+
+
 def gold_n1_navdp(B=2):
     torch_load = torch.load
     torch.load = lambda *a, **k: {}
@@ -675,7 +714,7 @@ def gold_sft_navdp(B=1, T=2):
                 oracle_max_abs_diff=worst)
 
 
-UNITS = {"sft_navdp": gold_sft_navdp, "sft": gold_sft, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "n1_navdp": gold_n1_navdp}
+UNITS = {"sft_navdp": gold_sft_navdp, "sft": gold_sft, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "navdpnet_nogoal": gold_navdpnet_nogoal, "n1_navdp": gold_n1_navdp}
 
 
 def main():

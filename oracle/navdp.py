@@ -124,16 +124,20 @@ def navdpnet_predict_critic(sd, traj, rgbd_embed, cfg):
 
 
 def navdpnet_pointgoal(sd, goal_point, images, depths, x_init, step_noise, cfg, return_all=False):
-    """NavDPNet.predict_pointgoal_batch_action_vel (navdp_policy.py:302-321), looped over envs.
+    """NavDPNet.predict_pointgoal_batch_action_vel (navdp_policy.py:302-321), looped over envs; goal_point None = its zero-goal sibling
+    predict_nogoal_batch_action_vel (:323-339).
     goal_point [B,3]; images [B,M,224,224,3] (0..1); depths [B,1,224,224,1]; x_init [B,S,T,3]; step_noise [K,B,S,T,3]
     (K = num_train_timesteps; the entry of the last step, t = 0, is unused). Returns negative / positive trajectories
     [B,8,T,3] (+ final samples [B,S,T,3] and critic values [B,S])."""
-    B = goal_point.shape[0]
+    B = images.shape[0]
     K = cfg["num_train_timesteps"]
     sch = DDPMScheduler(num_train_timesteps=K)
     sch.set_timesteps(K)
     rgbd = rgbd_backbone(images, depths, sd)
-    goal = linear(goal_point.float(), sd, "point_encoder").unsqueeze(1)
+    if goal_point is None:       # predict_nogoal_batch_action_vel (navdp_policy.py:323-339): nogoal_embed = zeros_like(rgbd_embed[:, 0:1])
+        goal = torch.zeros_like(rgbd[:, 0:1])
+    else:
+        goal = linear(goal_point.float(), sd, "point_encoder").unsqueeze(1)
     neg, pos, finals, critics = [], [], [], []
     for b in range(B):
         x = x_init[b].float()

@@ -22,7 +22,7 @@ def _stats(out, ref):
     return d.mean().item(), d.max().item(), ref.abs().max().item()
 
 
-def _assert_sampler_output(out, ref, what):
+def _assert_sampler_output(out, ref, what, max_bound=1.5e-1):
     """waypoint increments in [-1, 1] after 10-20 clipped sampler steps: mean |err| inside the north-star 1e-3, 99th percentile inside 1e-2,
     and a max bound of 1.5e-1. A tight bound on the MAX is the wrong statistic for a chaotic recursion - bf16-autocast PyTorch's own max |err|
     on such a batch has a median of 4.6e-2 over 64 envs and a 90th percentile of 1.4e-1 (profiles/r03E_navdp_bf16_yardstick_cpu.log), and
@@ -31,7 +31,7 @@ def _assert_sampler_output(out, ref, what):
     d = (out.float().cpu() - ref.float().cpu()).abs().flatten()
     m, p99, mx = d.mean().item(), torch.quantile(d[: 1 << 24], 0.99).item(), d.max().item()
     print(f"{what}: mean|err| {m:.3e} p99 {p99:.3e} max|err| {mx:.3e} ref max {ref.abs().max().item():.2f}")
-    assert m < 1e-3 and p99 < 1e-2 and mx < 1.5e-1, (what, m, p99, mx)
+    assert m < 1e-3 and p99 < 1e-2 and mx < max_bound, (what, m, p99, mx)
 
 
 def _gold(name):
@@ -73,7 +73,9 @@ def test_navdpnet_vs_reference_fixture(built_lib):
     S, T = net.S, net.T
     # continuous quantities: the 32 denoised samples per env (waypoint increments in [-1, 1]) and their critic values
     fin = net.sample[: B * S * T].view(B, S, T, 3)
-    _assert_sampler_output(fin, gold["oracle_final"], "final samples")
+    # this B = 2 fixture is the per-fixture regression guard: measured max 4.0e-2 (16-row attention) / 5.5e-2 (32-row kernel,
+    # deferred maximum), so 8e-2 attributes a regression of the wide / deferred path while leaving room for a summation-order change
+    _assert_sampler_output(fin, gold["oracle_final"], "final samples", max_bound=8e-2)
     cr = net.critic[: B * S].view(B, S).float().cpu()
     m, mx, ref = _stats(cr, gold["oracle_critic"])
     print(f"critic: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
@@ -97,6 +99,42 @@ def test_navdpnet_vs_reference_fixture(built_lib):
     for b in range(B):
         assert torch.allclose(neg[b].cpu(), traj[b][cr[b].argsort()[:8]], atol=1e-5)
         assert torch.allclose(pos[b].cpu(), traj[b][(-cr[b]).argsort()[:8]], atol=1e-5)
+
+
+def test_navdpnet_nogoal_vs_reference_fixture(built_lib):
+    """the zero-goal sibling of the config-#2 entry point (navdp_policy.py:323-339): fixture from the reference's own
+    `predict_nogoal_batch_action_vel`; same sampler / critic / ranking checks as the point-goal test, B = 2 envs in one call."""
+    from internnav_amd.navdp import NavDPNet
+
+    gold = _gold("navdpnet_nogoal")
+    B = gold["B"]
+    sd = W.navdpnet_state_dict(seed=gold["seed"])
+    inp = {k: v.to(DEV) for k, v in W.navdpnet_inputs(B, seed=gold["seed"]).items()}
+    net = NavDPNet(sd, W.NAVDPNET_CFG, DEV, max_envs=B)
+    neg, pos = net.predict_nogoal_batch_action_vel(inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
+    torch.cuda.synchronize()
+    S, T = net.S, net.T
+    fin = net.sample[: B * S * T].view(B, S, T, 3)
+    _assert_sampler_output(fin, gold["oracle_final"], "nogoal final samples", max_bound=8e-2)
+    cr = net.critic[: B * S].view(B, S).float().cpu()
+    m, mx, ref = _stats(cr, gold["oracle_critic"])
+    print(f"nogoal critic: mean|err| {m:.3e} max|err| {mx:.3e} ref max {ref:.2f}")
+    assert mx < 5e-2 * max(ref, 1.0)
+    gc = gold["oracle_critic"]
+    for b in range(B):
+        order = gc[b].argsort()
+        for name, out, idx_ref, gap in (("negative", neg, order[:8], gc[b][order[8]] - gc[b][order[7]]),
+                                        ("positive", pos, order.flip(0)[:8], gc[b][order[-8]] - gc[b][order[-9]])):
+            mine = cr[b].argsort()[:8] if name == "negative" else (-cr[b]).argsort()[:8]
+            if gap > 2 * mx:
+                assert set(mine.tolist()) == set(idx_ref.tolist()), f"env {b} {name}: selected set differs"
+            if torch.equal(mine, idx_ref):
+                m2, mx2, _ = _stats(out[b], gold[name][b])
+                assert m2 < 5e-3 and mx2 < 1e-1
+    # and the point-goal call on the same engine afterwards is unaffected by the table-filled goal slots
+    neg2, _ = net.predict_pointgoal_batch_action_vel(inp["goal"], inp["images"], inp["depths"], inp["x_init"], inp["step_noise"])
+    torch.cuda.synchronize()
+    _assert_sampler_output(net.sample[: B * S * T].view(B, S, T, 3), _gold("navdpnet")["oracle_final"], "point goal after nogoal", max_bound=8e-2)
 
 
 def test_n1_navdp_head_vs_reference_fixture(built_lib):

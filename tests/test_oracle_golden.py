@@ -44,6 +44,22 @@ def test_navdpnet_matches_reference():
     assert (pos - gold["positive"]).abs().max().item() < 1e-4
 
 
+def test_navdpnet_nogoal_matches_reference():
+    """NavDPNet.predict_nogoal_batch_action_vel of the reference (navdp_policy.py:323-339, batch-1 calls) == the oracle with goal None; the
+    zero goal is a different policy output than the point goal of the sibling fixture."""
+    gold, gold_pg = _load("navdpnet_nogoal"), _load("navdpnet")
+    B = gold["B"]
+    sd = W.navdpnet_state_dict(seed=gold["seed"])
+    inp = W.navdpnet_inputs(B, seed=gold["seed"])
+    with torch.no_grad():
+        neg, pos, fin, critic, _ = o_navdp.navdpnet_pointgoal(sd, None, inp["images"], inp["depths"], inp["x_init"], inp["step_noise"],
+                                                              W.NAVDPNET_CFG, return_all=True)
+    assert (neg - gold["negative"]).abs().max().item() < 1e-4
+    assert (pos - gold["positive"]).abs().max().item() < 1e-4
+    assert (fin - gold["oracle_final"]).abs().max().item() < 1e-4
+    assert (gold["oracle_final"] - gold_pg["oracle_final"]).abs().max().item() > 1e-2
+
+
 def test_n1_navdp_head_matches_reference():
     gold = _load("n1_navdp")
     B = gold["B"]
