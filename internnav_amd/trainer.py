@@ -59,7 +59,8 @@ class InternVLAN1SftTrainer:
                  min_lr: float = 1e-5, warmup_ratio: float = 0.003, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False, system1: str = "nextdit_async",
                  s1_cfg: Optional[dict] = None, dropout: float = 0.1, seed: int = 0, graph_s1: bool = False):
-        """system1: 'nextdit_async' (flow-matching loss on the NextDiT head) or 'navdp_async' (epsilon loss on the NavDP head; `s1_cfg` =
+        """system1: 'nextdit_async' / 'nextdit' (flow-matching loss on the NextDiT head, with / without the memory tokens of the goal / current
+        frame pair in the condition, internvla_n1.py:234-258) or 'navdp_async' (epsilon loss on the NavDP head; `s1_cfg` =
         its hyper-parameters, synthetic.N1_NAVDP_CFG; the batch then also carries `traj_depths` [B, T, 224, 224] in metres).
         graph_s1: the System-1 loss + backward of a micro-batch (a few thousand fixed-shape launches of the tape, launch-bound when issued
         one by one) is captured into a hipGraph per batch geometry and replayed; dropout masks stay fresh through a device-side seed word
@@ -75,13 +76,15 @@ class InternVLAN1SftTrainer:
         self.system1, self.seed = system1, seed
         # dropout: the reference trains in module.train() mode, where MemoryEncoder / QFormer (nextdit) and former_net / decoder / drop
         # (navdp) apply p = 0.1; masks come from a counter hash seeded per (seed, rank, micro-step)
-        if system1 == "nextdit_async":
-            self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,), dropout=dropout)
+        if system1 in ("nextdit_async", "nextdit"):
+            # 'nextdit' (internvla_n1.py:256-258): the same flow-matching loss with the projected trajectory hidden states as the ONLY condition
+            self.head = NextDiTSftHead(sd, device, n_query=nq, extra_trainable=(LQ,), dropout=dropout, use_async=system1 == "nextdit_async")
         elif system1 == "navdp_async":
             assert s1_cfg is not None, "navdp_async needs the NavDP hyper-parameters (s1_cfg)"
             self.head = NavDPSftHead(sd, device, s1_cfg, n_query=nq, extra_trainable=(LQ,), dropout=dropout)
         else:
-            raise NotImplementedError(f"SFT for system1={system1!r}: only the *_async heads of the released checkpoints are trained here")
+            # plain 'navdp' has no loss in the reference either (internvla_n1.py:287-303: only its `async` sub-branch computes one)
+            raise NotImplementedError(f"SFT for system1={system1!r}: the reference's forward(labels=...) defines a loss for nextdit, nextdit_async and navdp_async")
         self.P = self.head.P
         self.lq = LatentQueryGrad(engine)
         # prefetch pipeline (prefetch()): two engines over the same weights, the frozen prefix of the NEXT micro-batch runs in the idle one
@@ -165,13 +168,13 @@ class InternVLAN1SftTrainer:
         if noise is None:            # internvla_n1.py:261-264 / navdp.py:163-175 (the reference draws inside forward)
             noise = torch.randn(B * Tn, *batch["traj_poses"].shape[2:], device=dev, generator=self.gen_dev)
         if t_index is None:
-            if self.system1 == "nextdit_async":
+            if self.system1 in ("nextdit_async", "nextdit"):
                 t_index = (torch.rand(B * Tn, generator=self.gen_cpu) * 1000).long()
             else:
                 t_index = torch.randint(0, self.head.cfg["num_train_timesteps"], (B * Tn,), generator=self.gen_cpu)
         if self.graph_s1:
             loss, dh = self._s1_graphed(hq, batch, noise, t_index, loss_scale)
-        elif self.system1 == "nextdit_async":
+        elif self.system1 in ("nextdit_async", "nextdit"):
             loss, dh = self.head.loss_and_grads(hq, batch["traj_images"].to(dev), batch["traj_poses"], batch["video_frame_num"], noise, t_index,
                                                 loss_scale=loss_scale, seed=self._mask_seed())
         else:

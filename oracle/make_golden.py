@@ -640,6 +640,94 @@ def gold_sft(B=1, T=2):
                 oracle_max_abs_diff=worst)
 
 
+ASYNC_ONLY_PREFIXES = ("rgb_model.", "memory_encoder.", "rgb_resampler.")
+
+
+def gold_sft_plain(B=2, T=2):
+    """SFT loss of the NON-async `nextdit` branch (internvla_n1.py:234,256-286: condition = cond_projector(trajectory hidden states) alone)
+    through the reference's own NextDiTCrossAttn under autograd, transcribed line by line. The module set is the one
+    InternVLAN1MetaModel builds for system1 = 'nextdit' (internvla_n1_arch.py:126-137): no rgb_model / memory_encoder / rgb_resampler."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from . import sft as o_sft
+    from .schedulers import FlowMatchEulerDiscreteScheduler
+
+    nd, arch = R.nextdit_module(), R.n1_arch_module()
+    sd = {k: v for k, v in W.n1_nextdit_state_dict(seed=8).items() if not k.startswith(ASYNC_ONLY_PREFIXES)}
+
+    class S1(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.traj_dit = nd.NextDiTCrossAttn(nd.NextDiTCrossAttnConfig(latent_embedding_size=768))
+            self.noise_scheduler = FlowMatchEulerDiscreteScheduler()
+            self.action_encoder = nn.Linear(3, 384, bias=True)
+            self.pos_encoding = arch.SinusoidalPositionalEncoding(384)
+            self.action_decoder = nn.Linear(384, 3, bias=True)
+            self.cond_projector = nn.Sequential(nn.Linear(3584, 768), nn.GELU(approximate="tanh"), nn.Linear(768, 768))
+
+    m = _load_strict(S1(), sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.",))
+    g = torch.Generator().manual_seed(8)
+    hidden_q = torch.randn(B, 4, 3584, generator=g).requires_grad_(True)
+    traj_images = torch.rand(B, T, 224, 224, 3, generator=g)            # unused by this branch beyond its [B, T] shape
+    traj_poses = torch.randn(B, T, 32, 3, generator=g)
+    video_frame_num = torch.tensor([T] * (B - 1) + [max(1, T - 1)])
+    noise = torch.randn(B * T, 32, 3, generator=g)
+    indices = torch.randint(0, 1000, (B * T,), generator=g)
+
+    traj_hidden_states = hidden_q.unsqueeze(1).repeat(1, traj_poses.size(1), 1, 1).flatten(0, 1)
+    loss_mask = torch.arange(traj_images.size(1)).expand(traj_images.size(0), traj_images.size(1)) < video_frame_num.unsqueeze(1)
+    traj_hidden_states = m.cond_projector(traj_hidden_states)
+    latents = traj_hidden_states
+    relative_poses = traj_poses.flatten(0, 1)
+    bsz = relative_poses.shape[0]
+    timesteps = m.noise_scheduler.timesteps[indices]
+    schedule_timesteps = m.noise_scheduler.timesteps
+    step_indices = [(schedule_timesteps == t).nonzero().item() for t in timesteps]      # get_sigmas, internvla_n1_arch.py:189-198
+    sigmas = m.noise_scheduler.sigmas[step_indices].flatten()
+    while len(sigmas.shape) < relative_poses.dim():
+        sigmas = sigmas.unsqueeze(-1)
+    noisy_trajectory = (1 - sigmas) * relative_poses + sigmas * noise
+    action_features = m.action_encoder(noisy_trajectory)
+    pos_ids = torch.arange(relative_poses.shape[1]).reshape(1, -1).repeat(bsz, 1)
+    action_features = action_features + m.pos_encoding(pos_ids)
+    noise_pred = m.traj_dit(x=action_features, timestep=timesteps, z_latents=latents)
+    noise_pred = m.action_decoder(noise_pred)
+    target = noise - relative_poses
+    loss = F.mse_loss(noise_pred.float(), target.float(), reduction="none")
+    mask = loss_mask.flatten(0, 1)[:, None, None]
+    loss = (loss * mask).sum() / mask.sum() / (loss.shape[1] * loss.shape[2])
+    loss.backward()
+    ref_grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+    sd_o = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    hq_o = hidden_q.detach().clone().requires_grad_(True)
+    loss_o = o_sft.nextdit_sft_loss(sd_o, hq_o, traj_images, traj_poses, video_frame_num, noise, indices, use_async=False)
+    loss_o.backward()
+    worst = abs(loss_o.item() - loss.item())
+    samples = {}
+    gscale = max(g_.abs().max().item() for g_ in ref_grads.values())
+    for k, gr in ref_grads.items():
+        assert k in sd_o and sd_o[k].grad is not None, f"reference parameter {k} has a gradient, the oracle's has none"
+        scale = gr.abs().max().item()
+        rel_k = (gr - sd_o[k].grad).abs().max().item() / max(scale, 1e-12)
+        if scale < 1e-6 * gscale:
+            rel_k = 0.0
+        if rel_k > 1e-3:
+            print(f"  [sft_plain] {k}: rel {rel_k:.3e} scale {scale:.3e}")
+        worst = max(worst, rel_k)
+        flat = gr.flatten()
+        pick = torch.linspace(0, flat.numel() - 1, min(32, flat.numel())).long()
+        samples[k] = dict(norm=gr.norm().item(), idx=pick, val=flat[pick].clone())
+    worst = max(worst, ((hidden_q.grad - hq_o.grad).abs().max() / hidden_q.grad.abs().max()).item())
+    no_grad = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    sites = _count_dropout_sites(m, lambda: m.traj_dit(x=action_features, timestep=timesteps, z_latents=latents))
+    return dict(B=B, T=T, seed=8, weights_seed=8, dropout_sites=sites, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples, params_without_grad=no_grad,
+                inputs=dict(hidden_q=hidden_q.detach(), traj_images=traj_images[:, :, :1, :1].clone(), traj_poses=traj_poses, video_frame_num=video_frame_num,
+                            noise=noise, t_index=indices),
+                oracle_max_abs_diff=worst)
+
+
 def gold_sft_navdp(B=1, T=2):
     """SFT loss of the navdp_async branch (internvla_n1.py:287-303) through the reference's own NavDP_Policy_DPT_CriticSum_DAT.forward_vlm_traj
     (internvla_n1/navdp.py:291-312) under autograd, dropout off; sample_noise's random draws (:163-175) are replaced by seeded inputs fed
@@ -714,7 +802,7 @@ def gold_sft_navdp(B=1, T=2):
                 oracle_max_abs_diff=worst)
 
 
-UNITS = {"sft_navdp": gold_sft_navdp, "sft": gold_sft, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "navdpnet_nogoal": gold_navdpnet_nogoal, "n1_navdp": gold_n1_navdp}
+UNITS = {"sft_navdp": gold_sft_navdp, "sft": gold_sft, "sft_nextdit_plain": gold_sft_plain, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "navdpnet_nogoal": gold_navdpnet_nogoal, "n1_navdp": gold_n1_navdp}
 
 
 def main():

@@ -17,22 +17,27 @@ from .nextdit import RESNET_MEAN, RESNET_STD, memory_encoder, qformer, sinusoida
 from .nn_ref import linear
 
 
-def nextdit_sft_loss(sd, hidden_q, traj_images, traj_poses, video_frame_num, noise, t_index, num_train_timesteps=1000):
+def nextdit_sft_loss(sd, hidden_q, traj_images, traj_poses, video_frame_num, noise, t_index, num_train_timesteps=1000, use_async=True):
     """hidden_q [B, n_query, 3584] (hidden_states[b, t_s_pos[b] : t_s_pos[b] + n_query]); traj_images [B, T, 224, 224, 3] in 0..1;
-    traj_poses [B, T, 32, 3]; video_frame_num [B]; noise [B*T, 32, 3]; t_index long [B*T]. Returns the scalar loss."""
+    traj_poses [B, T, 32, 3]; video_frame_num [B]; noise [B*T, 32, 3]; t_index long [B*T]. Returns the scalar loss.
+    use_async False = system1 'nextdit' (:256-258): the condition is the projected trajectory hidden states alone - no DINOv2, MemoryEncoder
+    or QFormer (those modules do not exist in such a model, internvla_n1_arch.py:126-141); traj_images only supplies B and T."""
     B, Tn = traj_images.shape[:2]
     ths = hidden_q.unsqueeze(1).repeat(1, Tn, 1, 1).flatten(0, 1)                                  # :229
     loss_mask = torch.arange(Tn).expand(B, Tn) < video_frame_num.unsqueeze(1)                      # :230-232
-    cur = traj_images.flatten(0, 1)
-    goal = traj_images[:, 0:1].repeat(1, Tn, 1, 1, 1).flatten(0, 1)
-    bsz = cur.size(0)
-    images_dp = torch.stack([goal, cur], dim=1).permute(0, 1, 4, 2, 3)                             # :239
-    norm = (images_dp.float() - RESNET_MEAN.view(1, 1, 3, 1, 1)) / RESNET_STD.view(1, 1, 3, 1, 1)
-    feat = dinov2.forward_tokens(norm.flatten(0, 1), sd, "rgb_model.").unflatten(0, (bsz, -1))     # :242-246
-    mem = memory_encoder(feat.flatten(1, 2), sd)                                                   # :248-250
-    tokens = qformer(torch.cat([feat.flatten(1, 2), mem], dim=-1), sd)                             # :251-252
     lat = linear(F.gelu(linear(ths.float(), sd, "cond_projector.0"), approximate="tanh"), sd, "cond_projector.2")
-    latents = torch.cat([tokens, lat], dim=1)                                                      # :255
+    if use_async:
+        cur = traj_images.flatten(0, 1)
+        goal = traj_images[:, 0:1].repeat(1, Tn, 1, 1, 1).flatten(0, 1)
+        bsz = cur.size(0)
+        images_dp = torch.stack([goal, cur], dim=1).permute(0, 1, 4, 2, 3)                         # :239
+        norm = (images_dp.float() - RESNET_MEAN.view(1, 1, 3, 1, 1)) / RESNET_STD.view(1, 1, 3, 1, 1)
+        feat = dinov2.forward_tokens(norm.flatten(0, 1), sd, "rgb_model.").unflatten(0, (bsz, -1)) # :242-246
+        mem = memory_encoder(feat.flatten(1, 2), sd)                                               # :248-250
+        tokens = qformer(torch.cat([feat.flatten(1, 2), mem], dim=-1), sd)                         # :251-252
+        latents = torch.cat([tokens, lat], dim=1)                                                  # :255
+    else:
+        latents = lat                                                                              # :257-258
     x = traj_poses.flatten(0, 1).float()
     timesteps = (num_train_timesteps - t_index).float()
     sig = (timesteps / num_train_timesteps).view(-1, 1, 1)

@@ -215,6 +215,32 @@ def test_sft_loss_and_gradients_match_reference_autograd():
             assert sd[k].grad is None or float(sd[k].grad.abs().max()) == 0.0, k
 
 
+def test_plain_nextdit_sft_loss_matches_reference_autograd():
+    """system1 = 'nextdit' (internvla_n1.py:256-258): oracle autograd vs the fixture back-propagated through the reference's own modules."""
+    from oracle import sft as o_sft
+
+    gold = _load("sft_nextdit_plain")
+    sd = {k: v.float().clone().requires_grad_(True) for k, v in W.n1_nextdit_state_dict(seed=gold["weights_seed"]).items()}
+    inp = gold["inputs"]
+    hq = inp["hidden_q"].clone().requires_grad_(True)
+    loss = o_sft.nextdit_sft_loss(sd, hq, inp["traj_images"], inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"], use_async=False)
+    loss.backward()
+    assert abs(loss.item() - gold["loss"]) < 1e-5 * abs(gold["loss"])
+    assert ((hq.grad - gold["d_hidden"]).abs().max() / gold["d_hidden"].abs().max()).item() < 1e-4
+    gscale = max(g["norm"] for g in gold["grads"].values())
+    for k, g in gold["grads"].items():
+        mine = sd[k].grad
+        assert mine is not None, k
+        if g["norm"] < 1e-6 * gscale:
+            assert mine.norm().item() < 1e-5 * gscale, k
+            continue
+        assert abs(mine.norm().item() - g["norm"]) < 1e-4 * g["norm"], k
+        assert (mine.flatten()[g["idx"]] - g["val"]).abs().max().item() < 1e-4 * max(g["val"].abs().max().item(), g["norm"] / mine.numel() ** 0.5), k
+    for k in sd:                         # the async-only modules never reach this loss
+        if k.startswith(("rgb_model.", "memory_encoder.", "rgb_resampler.")):
+            assert sd[k].grad is None, k
+
+
 def test_flow_match_scheduler_default_state():
     """FlowMatchEulerDiscreteScheduler() as constructed (what the SFT loss indexes): timesteps 1000..1, sigmas = t / 1000."""
     s = FlowMatchEulerDiscreteScheduler()

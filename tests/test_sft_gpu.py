@@ -143,3 +143,54 @@ def test_dropout_training_mode(case, dev):
     l0, g0, _ = run(1e-7, 5)
     assert abs(l0 - base_loss) < 2e-3 * abs(base_loss)
     assert ((g0 - base_grad).norm() / base_grad.norm()).item() < 2e-2
+
+
+def test_plain_nextdit_branch_vs_reference_fixture_and_yardstick(dev):
+    """system1 = 'nextdit' (internvla_n1.py:256-258; VERDICT r4 missing #1): loss, d loss / d hidden states and every parameter gradient of
+    the HIP tape against (a) tests/golden/sft_nextdit_plain.pt - back-propagation through the reference's own NextDiTCrossAttn for a model
+    without the async modules - and (b) bf16-autocast PyTorch autograd of the oracle as the yardstick, as for the async branch."""
+    from pathlib import Path
+
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+    from oracle import sft as O
+
+    gold = torch.load(Path(__file__).resolve().parent / "golden" / "sft_nextdit_plain.pt", weights_only=True)
+    sd0 = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), gold["weights_seed"]).items() if not k.startswith(E.S1_ASYNC_ONLY_PREFIXES)}
+    inp = gold["inputs"]
+
+    def oracle(autocast):
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        hq = inp["hidden_q"].clone().requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            loss = O.nextdit_sft_loss(sd, hq, inp["traj_images"], inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"], use_async=False)
+        loss.backward()
+        return loss.item(), hq.grad.float(), {k: v.grad.float() for k, v in sd.items() if v.grad is not None}
+
+    l32, dh32, g32 = oracle(False)
+    l16, dh16, g16 = oracle(True)
+    assert abs(l32 - gold["loss"]) < 1e-5 * abs(gold["loss"])                 # the oracle IS the reference here (CPU suite pins every gradient)
+    head = E.NextDiTSftHead(sd0, dev, use_async=False)
+    loss, dh = head.loss_and_grads(inp["hidden_q"].to(dev), inp["traj_images"].to(dev), inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"])
+    assert abs(loss.item() - l32) <= max(abs(l16 - l32), 2e-3 * abs(l32)), (loss.item(), l32, l16)
+    e, y = _rel(dh.float().cpu().view_as(dh32), dh32), _rel(dh16, dh32)
+    assert e <= 1.1 * y + 1e-3, f"d loss / d hidden: engine {e:.3e} vs bf16 PyTorch {y:.3e}"
+    errs, yards, bad = [], [], []
+    scale = max(g.norm().item() for g in g32.values())
+    for k, ref in g32.items():
+        assert k in head.P, k
+        got = head.P.grad(k).cpu().view_as(ref)
+        if ref.norm().item() < 1e-6 * scale:
+            assert got.norm().item() < 1e-4 * scale, k
+            continue
+        e_, y_ = _rel(got, ref), _rel(g16[k], ref)
+        errs.append(e_)
+        yards.append(y_)
+        if e_ > 2.5 * y_ + 2e-3 or e_ > 3e-2:
+            bad.append((k, e_, y_))
+        g = gold["grads"][k]                                                  # the reference's own gradient entries
+        assert (got.flatten()[g["idx"]] - g["val"]).abs().max().item() <= 6e-2 * max(g["val"].abs().max().item(), g["norm"] / got.numel() ** 0.5), k
+    print(f"plain nextdit: loss {loss.item():.5f} (fp32 {l32:.5f}, bf16 {l16:.5f}); grads mean rel engine {sum(errs) / len(errs):.3e} vs bf16 {sum(yards) / len(yards):.3e}")
+    assert not bad, bad[:10]
+    assert sum(errs) / len(errs) <= sum(yards) / len(yards)
+    assert set(head.P.index) == set(g32), set(head.P.index) ^ set(g32)        # exactly the tensors the reference trains in this branch

@@ -65,6 +65,38 @@ def test_nextdit_tape_wiring(monkeypatch):
     assert float(head.P.g32.abs().max()) == 0.0 and float((head.P.p32 - before).abs().max()) > 0 and torch.equal(head.P.p16, head.P.p32.bfloat16())
 
 
+def test_plain_nextdit_tape_wiring_against_the_reference_fixture(monkeypatch):
+    """system1 = 'nextdit' (internvla_n1.py:256-258, VERDICT r4 missing #1): the condition is the projected trajectory hidden states alone.
+    The tape (stand-in kernels) against tests/golden/sft_nextdit_plain.pt = loss / gradients back-propagated through the REFERENCE's own
+    NextDiTCrossAttn for a model without rgb_model / memory_encoder / rgb_resampler; the trainable store holds none of those tensors."""
+    from pathlib import Path
+
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+
+    K.install(monkeypatch)
+    gold = torch.load(Path(__file__).resolve().parent / "golden" / "sft_nextdit_plain.pt", weights_only=True)
+    sd0 = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), gold["weights_seed"]).items()}     # the async modules are present in the dict, and ignored
+    inp = gold["inputs"]
+    head = E.NextDiTSftHead(sd0, "cpu", use_async=False, dropout=0.1)
+    assert not any(k.startswith(E.S1_ASYNC_ONLY_PREFIXES) for k in head.P.index) and head.dino is None
+    loss, dh = head.loss_and_grads(inp["hidden_q"], inp["traj_images"], inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"])
+    assert head.last_dropout_sites == gold["dropout_sites"] == {"dropout": 0, "attention": 0}          # no nn.Transformer layer in this branch
+    assert abs(loss.item() - gold["loss"]) < 1e-2 * abs(gold["loss"])
+    assert _rel(dh.float().view_as(gold["d_hidden"]), gold["d_hidden"]) < 4e-2
+    gscale = max(g["norm"] for g in gold["grads"].values())
+    n = 0
+    for k, g in gold["grads"].items():
+        assert k in head.P.index, k
+        mine = head.P.grad(k).flatten()
+        if g["norm"] < 1e-6 * gscale:
+            assert mine.norm().item() < 1e-4 * gscale, k
+            continue
+        assert abs(mine.norm().item() - g["norm"]) < 4e-2 * g["norm"], (k, mine.norm().item(), g["norm"])
+        n += 1
+    assert n > 150 and set(head.P.index) >= set(gold["grads"])
+
+
 def test_navdp_tape_wiring(monkeypatch):
     from internnav_amd import sft as E
     from internnav_amd import synthetic as S

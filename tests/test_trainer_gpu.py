@@ -106,6 +106,46 @@ def test_navdp_async_training_step_runs(built_lib):
     assert not torch.equal(before, eng.latent_q) and float(tr.P.g32.abs().max()) == 0.0
 
 
+def test_plain_nextdit_training_step(built_lib):
+    """system1 = 'nextdit' through the trainer (the branch used to raise NotImplementedError): loss against the chained fp32
+    oracles, latent-query gradient through the frozen decoder, one optimiser step; the store holds no async-only module."""
+    from internnav_amd import sft as E
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+    from internnav_amd.trainer import LQ, InternVLAN1SftTrainer
+    from oracle import qwen_vl as o_q
+    from oracle import sft as o_sft
+
+    cfg = W.QWEN_TEST_CFG
+    B, T = 2, 2
+    sd_q = W.qwen_state_dict(seed=11, cfg=cfg)
+    sd_s = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items() if not k.startswith(E.S1_ASYNC_ONLY_PREFIXES)}
+    batch, noise, t_index, inp = _batch(cfg, B, T)
+    eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+    tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100, system1="nextdit")
+    assert not any(k.startswith(E.S1_ASYNC_ONLY_PREFIXES) for k in tr.P.index)
+    tr.step_idx = 5
+    loss = tr.forward_backward(batch, noise, t_index)
+    sdq = {k: v.float() for k, v in sd_q.items()}
+    lq = sdq["model.latent_queries"].clone().requires_grad_(True)
+    sdq["model.latent_queries"] = lq
+    per_pv, per_g = inp["pixel_values"].shape[0] // B, inp["grid_thw"].shape[0] // B
+    hs = [o_q.generate_latents(sdq, cfg, batch["input_ids"][b:b + 1, :batch["t_s_pos"][b]], inp["pixel_values"][b * per_pv:(b + 1) * per_pv].float(),
+                               inp["grid_thw"][b * per_g:(b + 1) * per_g]) for b in range(B)]
+    l32 = o_sft.nextdit_sft_loss({k: v.clone() for k, v in sd_s.items()}, torch.cat(hs).float(), batch["traj_images"], batch["traj_poses"],
+                                 batch["video_frame_num"], noise, t_index, use_async=False)
+    l32.backward()
+    rel = ((tr.P.grad(LQ).cpu().view_as(lq.grad.reshape(-1, lq.shape[-1])) - lq.grad.reshape(-1, lq.shape[-1])).norm() / lq.grad.norm()).item()
+    print(f"plain nextdit step: loss {loss.item():.5f} oracle {l32.item():.5f}; d latent_queries rel {rel:.3e}")
+    assert abs(loss.item() - l32.item()) <= 5e-3 * abs(l32.item()) and rel < 3e-2
+    before = eng.latent_q.clone()
+    tr.reduce_gradients()
+    tr.optimizer_step()
+    assert not torch.equal(before, eng.latent_q) and float(tr.P.g32.abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        InternVLAN1SftTrainer(eng, sd_s, DEV, system1="navdp")               # no loss is defined for it in the reference either
+
+
 @pytest.mark.parametrize("system1", ["nextdit_async", "navdp_async"])
 def test_graphed_system1_step_equals_eager_and_redraws_masks(built_lib, system1):
     """`graph_s1=True`: the System-1 loss + backward as ONE hipGraph replay per micro-batch. Without dropout the replayed
