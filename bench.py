@@ -73,6 +73,10 @@ def parse():
                     help="n1_dual: prefix-KV reuse variant - the K/V of system prompt + instruction + first history frame (296 of the 920 prompt "
                          "tokens, identical between the System-2 calls of an episode) come from a per-env cache; the call encodes 3 of 4 frames and "
                          "prefills 624 tokens per env. Exact (causal mask); algorithmic FLOPs are accounted accordingly. Reported next to the headline.")
+    ap.add_argument("--s2-every", type=int, default=1,
+                    help="n1_dual, nominal cadence: run the System-2 micro-batch only on every E-th step (E = 2: 12-13 envs every other step instead of 6-7 every "
+                         "step). Every env still runs System-2 once per 10 steps and System-1 every step; the decode / latent-query passes stream the "
+                         "15 GB of decoder weights 9 times per TWO steps instead of per step. Trades step-latency uniformity for throughput; reported next to the default.")
     ap.add_argument("--no-split-prefill", action="store_true",
                     help="n1_dual: System-2 prefill as ONE launch sequence instead of two half micro-batches on two streams")
     ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
@@ -98,7 +102,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, rest=[])
+                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -334,10 +338,17 @@ class N1Dual:
         else:
             self.PERIOD = 1
         P_ = self.PERIOD
-        self.mb = [B // P_ + (1 if j < B % P_ else 0) for j in range(P_)]   # micro-batch sizes, sum = B
+        self.s2_every = max(1, int(getattr(a, "s2_every", 1)))
+        assert self.s2_every == 1 or (self.cadence == "nominal" and P_ % self.s2_every == 0), "--s2-every needs the nominal cadence and must divide its period of 10"
+        slots = [j for j in range(P_) if j % self.s2_every == 0]          # the steps of a period that carry a System-2 micro-batch
+        per_slot = [B // len(slots) + (1 if k < B % len(slots) else 0) for k in range(len(slots))]
+        self.mb = [per_slot[slots.index(j)] if j in slots else 0 for j in range(P_)]   # micro-batch sizes, sum = B (0 = a System-1-only step)
         self.mb_start = np.concatenate([[0], np.cumsum(self.mb)])
-        assert min(self.mb) >= 1, f"--envs {B} is smaller than the cadence period {P_}"
+        assert min(per_slot) >= 1, f"--envs {B} is smaller than the number of System-2 steps per period ({len(slots)})"
         mmax = max(self.mb)
+        if self.s2_every > 1:
+            tag += f"_s2every{self.s2_every}"
+            self.name += f"_s2every{self.s2_every}"
 
         def envs_of(j):
             return list(range(int(self.mb_start[j]), int(self.mb_start[j]) + self.mb[j]))
@@ -402,7 +413,7 @@ class N1Dual:
                      "s2": f"{self.N_IMG} frames x 784 patches" + (f" + the un-resized look-down frame ({per_ld} patches)" if self.lookdown else "") +
                            f" + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
                      "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps" if self.with_s1 else "none",
-                     "s2_microbatches_per_period": self.mb, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
+                     "s2_microbatches_per_period": self.mb, "s2_every": self.s2_every, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
         self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
         if not getattr(a, "no_s1_merge_images", False) and self.cadence == "nominal" and self.with_s1 and not getattr(a, "no_overlap", False) and not a.no_graph:
@@ -445,7 +456,7 @@ class N1Dual:
                     self.kv_prefix[lo + k].copy_(q.export_prefix_kv(k, pl))
             self.desc["prefix_kv"] = (f"K/V of the first {pl} prompt tokens (template + instruction + frame 0) of every env from the prefix cache: "
                                       f"{self.S - pl} tokens prefilled and {n_fresh} of {self.N_IMG} frames encoded per System-2 call")
-        for m in sorted(set(self.mb)):
+        for m in sorted(set(self.mb) - {0}):
             cache0 = torch.empty(m, per // 4, qcfg["t_hidden"], dtype=torch.bfloat16, device=dev) if self.vit_cache else None
             cached = [c for k in range(m) for c in ([cache0[k]] + [None] * (self.N_IMG - 1))] if self.vit_cache else None
             P = q.plan(ids[:m].cpu(), torch.cat([self.grid] * m), n_decode=self.N_DECODE, with_latents=True, cached_embeds=cached,
@@ -547,6 +558,8 @@ class N1Dual:
             q = self.model.qwen
             for j in range(self.PERIOD):
                 m, nA = self.mb[j], len(self.idxA_host[j])
+                if m == 0:              # System-1-only step (--s2-every): the all-env System-1 graph captured above
+                    continue
                 mg = self.merge_images
                 if mg and (nA, m) not in self.gAimg:
                     # one encoder pass over the look-down pairs of the side envs AND the System-2 envs; the latter's 32 memory tokens go to the small engine
@@ -606,6 +619,8 @@ class N1Dual:
     def step_overlapped(self, i):
         j = i % self.PERIOD
         m, lo = self.mb[j], int(self.mb_start[j])
+        if m == 0:
+            return self._step_s1_only()
         idx, hostidx = self.idxA[j], self.idxA_host[j]
         nA = len(hostidx)
         s = self.s2[m]
@@ -663,11 +678,27 @@ class N1Dual:
         self.actions.copy_(torch.from_numpy(acts))
         return self.actions
 
+    def _step_s1_only(self):
+        """a step without a System-2 micro-batch (--s2-every E > 1): System-1 for every env on the latents their last System-2 call left, one
+        graph replay; the host post-processing of the first half of the envs runs while the second half's trajectories are still in flight."""
+        if not getattr(self, "freeze_noise", False):
+            self.x_init.normal_(generator=self.g)
+        self._ingest_s1()
+        traj = self.s1_graph() if self.s1_graph else self._s1_call()
+        self.last_traj = traj
+        t = traj.cpu()
+        acts = np.zeros((self.B, 4), dtype=np.int32)
+        self._emit(acts, {b: self._plan(t[b]) for b in range(self.B)})
+        self.actions.copy_(torch.from_numpy(acts))
+        return self.actions
+
     def step(self, i):
         if self.overlap:
             return self.step_overlapped(i)
         j = i % self.PERIOD
         m, lo = self.mb[j], int(self.mb_start[j])
+        if m == 0:
+            return self._step_s1_only()
         s = self.s2[m]
         # System-2 for the envs whose plan expires this step: gather their prompt / frames, run, scatter the latents back
         s["P"]["ids"].copy_(self.ids[lo:lo + m, self.prefix_len:].reshape(-1).to(torch.int32))
@@ -951,10 +982,14 @@ def main():
         step(i)
     sync()
     t0 = time.perf_counter()
+    marks = [t0]
     for i in range(a.steps):
         step(a.warmup + i)
+        marks.append(time.perf_counter())          # (a step returns after its host post-processing: its actions exist at this point)
     sync()
     dt = time.perf_counter() - t0
+    lat = np.diff(np.asarray(marks)) * 1e3
+    step_latency = {"p50": round(float(np.percentile(lat, 50)), 2), "min": round(float(lat.min()), 2), "max": round(float(lat.max()), 2)}
     if world > 1:
         # the exchanged actions are really everybody's: this rank's slice equals its own last output, every slice is a valid action table
         mine = wl.step_output_for_check()
@@ -1020,7 +1055,7 @@ def main():
         line = {
             "metric": "policy steps/sec/node" if getattr(wl, "unit", "policy steps/s") == "policy steps/s" else "System-2 calls/sec/node",
             "value": round(value, 2), "unit": getattr(wl, "unit", "policy steps/s"), "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "step_latency_ms": step_latency, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights at the true shapes, synthetic camera frames / prompts)",
             # ranks of the process group torch.distributed initialised on backend "nccl" (= RCCL on ROCm); 1 = no process group (single GPU)
             "rccl_ranks": dist_info["ranks"] if (world == 1 or dist_info["backend"] == "nccl") else 0, "dist": dist_info,

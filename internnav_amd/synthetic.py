@@ -141,6 +141,33 @@ class HashWeights:
         return u.to(torch.bfloat16).view(shape)
 
 
+OUTLIER_CHANNELS = (143, 647, 1151, 1879, 2495, 3083)
+OUTLIER_SCALES = (128, 256, 512, 1024, 256, 512)
+OUTLIER_OTHERS_GAIN = 8
+
+
+class OutlierHashWeights(HashWeights):
+    """HashWeights of the System-2 decoder with MASSIVE-ACTIVATION channels, as released Qwen2.5 checkpoints carry them (every
+    other parity run uses N(0, 0.02)-like weights, whose residual stream has no outliers). Six rows of layer 0's down projection are scaled
+    by 128 ... 1024, so from layer 0 on six channels of the residual stream sit at 60 ... 500 where the others are O(1) (x100 - x1000), for
+    every token and through all later layers. As in the real models the norm gains absorb them: in every RMSNorm behind layer 0 the gain of an
+    outlier channel is multiplied by 64 / scale (it enters the next GEMM at ~3x a normal channel) and all other gains by 8 (the outliers inflate
+    the row RMS ~9x; without this the rest of the network would fade to an identity map). All factors are powers of two: exact in bf16, so the
+    CPU fixture (oracle/make_golden_full.py --outliers) and the GPU test draw bit-identical tensors."""
+
+    def __getitem__(self, key: str) -> torch.Tensor:
+        w = super().__getitem__(key)
+        ch = torch.tensor(OUTLIER_CHANNELS, device=w.device)
+        sc = torch.tensor(OUTLIER_SCALES, device=w.device, dtype=torch.float32)
+        if key == "model.layers.0.mlp.down_proj.weight":
+            w[ch] = (w[ch].float() * sc[:, None]).to(torch.bfloat16)
+        elif key == "model.norm.weight" or (key.startswith("model.layers.") and key.endswith("layernorm.weight") and int(key.split(".")[2]) >= 1):
+            g = torch.full(w.shape, float(OUTLIER_OTHERS_GAIN), device=w.device)
+            g[ch] = 64.0 / sc
+            w = (w.float() * g).to(torch.bfloat16)
+        return w
+
+
 def materialize(spec: Spec, seed: int = 0) -> Dict[str, torch.Tensor]:
     return {k: _draw(k, shape, kind, seed) for k, (shape, kind) in spec.items()}
 

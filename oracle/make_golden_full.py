@@ -40,9 +40,9 @@ N_ROWS, N_COLS = 16, 128
 class CachedWeights:
     """HashWeights materialised once as bf16 in RAM (15 GB); the fp32 oracle reads each tensor through .float()."""
 
-    def __init__(self, spec, seed):
+    def __init__(self, spec, seed, outliers=False):
         t0 = time.time()
-        hw = W.HashWeights(spec, seed, "cpu")
+        hw = (W.OutlierHashWeights if outliers else W.HashWeights)(spec, seed, "cpu")
         self.bf16 = {k: hw[k] for k in spec}
         print(f"[weights] {sum(v.numel() for v in self.bf16.values()) / 1e9:.2f} B parameters drawn in {time.time() - t0:.0f} s", flush=True)
 
@@ -226,21 +226,29 @@ def main():
     ap.add_argument("--out", default=str(GOLD / "qwen_full.pt"))
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--reduced", action="store_true", help="dry run of this script on the 2+2-layer test configuration")
+    ap.add_argument("--outliers", action="store_true", help="massive-activation channels in the decoder's residual stream (synthetic.OutlierHashWeights) "
+                    "-> tests/golden/qwen_full_outliers.pt")
+    ap.add_argument("--envs", type=int, default=7, help="sequences in the batch (the outlier fixture uses 3: CPU time)")
     a = ap.parse_args()
+    globals()["B"] = a.envs
+    if a.outliers and a.out == str(GOLD / "qwen_full.pt"):
+        a.out = str(GOLD / "qwen_full_outliers.pt")
     torch.set_num_threads(a.threads)
     cfg = W.QWEN_TEST_CFG if a.reduced else W.QWEN_N1_CFG
     inp = W.qwen_inputs(B, N_IMG, seed=SEED, cfg=cfg, n_text=N_TEXT, n_tail=N_TAIL)
     assert inp["input_ids"].shape == (B, 920)
+    assert all(c in (torch.arange(N_COLS) * (cfg["t_hidden"] // N_COLS) + 3).tolist() for c in W.OUTLIER_CHANNELS)
     sp = sample_plan(cfg, inp)
-    wc = CachedWeights(W.qwen_spec(cfg), SEED)
+    wc = CachedWeights(W.qwen_spec(cfg), SEED, outliers=a.outliers)
     check = {k: int(wc.bf16[k].view(torch.int16).to(torch.int64).sum()) for k in
-             ("model.layers.0.self_attn.q_proj.weight", f"model.layers.{cfg['t_layers'] - 1}.mlp.down_proj.weight",
+             ("model.layers.0.self_attn.q_proj.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.1.input_layernorm.weight", "model.norm.weight",
+              f"model.layers.{cfg['t_layers'] - 1}.mlp.down_proj.weight",
               f"visual.blocks.{cfg['v_depth'] - 1}.mlp.up_proj.weight", "lm_head.weight", "model.embed_tokens.weight", "visual.merger.mlp.2.bias")}
     f32 = run_fp32(wc, cfg, inp, sp)
     gc.collect()
     b16 = run_bf16_transformers(wc, cfg, inp, sp, f32["tokens"])
     assert torch.equal(b16["position_ids"], f32["position_ids"]), "oracle rope_index != reference get_rope_index_25"
-    fx = dict(seed=SEED, B=B, n_img=N_IMG, n_text=N_TEXT, n_tail=N_TAIL, S=920, n_decode=N_DEC, weight_check=check, **sp,
+    fx = dict(seed=SEED, outliers=bool(a.outliers), outlier_channels=torch.tensor(W.OUTLIER_CHANNELS if a.outliers else ()), B=B, n_img=N_IMG, n_text=N_TEXT, n_tail=N_TAIL, S=920, n_decode=N_DEC, weight_check=check, **sp,
               position_ids=f32["position_ids"],
               vit_h=f32["vit_h"], vit_rms=f32["vit_rms"], llm_h=f32["llm_h"], llm_rms=f32["llm_rms"], emb=f32["emb"], emb_rms=f32["emb_rms"],
               tokens=f32["tokens"], margins=f32["margins"], latents=f32["latents"],
@@ -256,6 +264,17 @@ def main():
     fx["bf16_logits"] = {k: v[0] for k, v in _err(b16["last_logits_full"][:, sp["voc_idx"]].reshape(1, -1), fx["logits_samp"].reshape(1, -1)).items()}
     fx["bf16_latents"] = {k: v[0] for k, v in _err(b16["latents"].reshape(1, -1), f32["latents"].reshape(1, -1)).items()}
     fx["bf16_tokens0"] = b16["last_logits_full"].argmax(-1)
+    if a.outliers:
+        # the same per-layer yardstick over the NON-outlier columns of the samples only (the outlier columns alone carry the bf16 path's
+        # 2-4-unit roundings of a bf16 residual stream and would hide everything else in a mean), and over the outlier columns alone
+        oc = torch.isin(sp["llm_cols"], fx["outlier_channels"])
+        assert int(oc.sum()) == len(W.OUTLIER_CHANNELS), "every outlier channel must be one of the sampled columns"
+        for name, m in (("bf16_llm_rest", ~oc), ("bf16_llm_outl", oc)):
+            fx[name] = {k: torch.stack([_err(b16["llm_h"][i][..., m].reshape(1, -1), f32["llm_h"][i][..., m].reshape(1, -1))[k][0]
+                                        for i in range(cfg["t_layers"])]) for k in ("mean", "max", "rel")}
+        fx["outlier_abs_mean"] = torch.stack([f32["llm_h"][i][..., oc].abs().mean() for i in range(cfg["t_layers"])])
+        fx["rest_abs_mean"] = torch.stack([f32["llm_h"][i][..., ~oc].abs().mean() for i in range(cfg["t_layers"])])
+        print("outlier |x| per layer", [round(float(v), 1) for v in fx["outlier_abs_mean"]], "rest", [round(float(v), 2) for v in fx["rest_abs_mean"]])
     torch.save(fx, a.out)
     print("wrote", a.out, Path(a.out).stat().st_size / 1e6, "MB")
     print("layer | fp32 rms | bf16-PyTorch mean|err| max|err| rel")
