@@ -38,7 +38,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn, 20 gn_mish, 21 pad_rows, 22 ddim_step, 23 ew, 24 colsum, 25 norm_bwd, 26 transpose, 27 sparse_rows, 28 small_linear, 29 mse, 30 adamw, 31 gemm_nn, 32 attn_bwd):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn, 20 gn_mish, 21 pad_rows, 22 ddim_step, 23 ew, 24 colsum, 25 norm_bwd, 26 transpose, 27 sparse_rows, 28 small_linear, 29 mse, 30 adamw, 31 gemm_nn, 32 attn_bwd, 33 dit_rowchain):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 38 / 39 = gemm_bf16_w4_kernel<256, 0|1> (four-wave 256x256 tile), 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 38 / 39 = gemm_bf16_w4_kernel<256, 0|1> (four-wave 256x256 tile), 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel, 42 = dit_rowchain_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
@@ -406,6 +406,35 @@ typedef struct ina_dit_ffn_args {
     int32_t rotate;         /* 1: workgroup b starts at F chunk b % (F/128) (spreads the concurrent workgroups over the weight lines) */
 } ina_dit_ffn_args;
 int ina_dit_ffn(const ina_dit_ffn_args* args, void* stream);
+
+/* ---- dit_rowchain (round 5): everything of a NextDiT block between two attention stages that is local to a row, in one launch:
+ *          P  = A . W1^T (bf16)                                     attn2.to_out (K1 = 384) / feed_forward.linear_2 (K1 = 1024)
+ *          X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma1         norm2 / ffn_norm2 + gate + residual (fp32, in place)
+ *          H  = rmsnorm(X) * gamma2 * (1 + mod_scale2[r/mod_div])   ffn_norm1 / the next block's norm1 + adaLN scale
+ *          C2 = H . W2^T  (glu2: silu(H . Wg^T) * (H . Wu^T), W2 rows interleaved [gate16 | up16])
+ *      replaces GEMM + norm launch + GEMM of diffusers' LuminaNextDiTBlock.forward (diffusers==0.33.1) as wired by
+ *      nextdit_traj.py:121-178: the projection and H stay in registers. W2 == NULL: no second GEMM (the last block); H != NULL
+ *      additionally writes H (bf16) to memory. Built pairs: (K1 = 384, glu2 = 1) and (K1 = 1024, glu2 = 0); N = 384 fixed.
+ *      M and mod_div must be multiples of the row panel (128 rows; 256 with waves = 8). */
+typedef struct ina_dit_rowchain_args {
+    const void* A;          /* bf16 [M,K1], row stride lda */
+    const void* W1;         /* bf16 [384,K1], row stride ldw1 */
+    const float* gamma1;    /* f32 [384] RMSNorm weight on the projection */
+    const float* gate;      /* f32 [M/mod_div, mod_ld] (tanh applied) or NULL */
+    float* X;               /* f32 [M,384] residual stream, updated in place, row stride ldx */
+    const float* gamma2;    /* f32 [384] or NULL */
+    const float* mod_scale2;/* f32 [M/mod_div, mod_ld] or NULL */
+    void* H;                /* bf16 [M,384] or NULL, row stride ldh */
+    const void* W2;         /* bf16 [N2,384] or NULL, row stride ldw2 */
+    void* C2;               /* bf16 [M,N2] (N2/2 columns with glu2), row stride ldc2 */
+    int32_t M, K1, N2;
+    int32_t lda, ldw1, ldx, ldh, ldw2, ldc2;
+    int32_t glu2;
+    int32_t mod_div, mod_ld;
+    float eps;
+    int32_t waves;          /* 0 / 4: 128-row panels, two workgroups per CU; 8: 256-row panels */
+} ina_dit_rowchain_args;
+int ina_dit_rowchain(const ina_dit_rowchain_args* args, void* stream);
 
 /* ---- dit_attention: the attention stage of one NextDiT block in one launch:
  *          O = SDPA(LN(q1), LN(k1), v1) + tanh(head_gate[h]) * SDPA(LN(q2), K2, V2)

@@ -166,6 +166,16 @@ class DitFfnArgs(C.Structure):
     ]
 
 
+class DitRowchainArgs(C.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W1", c_void_p), ("gamma1", c_void_p), ("gate", c_void_p), ("X", c_void_p), ("gamma2", c_void_p),
+        ("mod_scale2", c_void_p), ("H", c_void_p), ("W2", c_void_p), ("C2", c_void_p),
+        ("M", c_int32), ("K1", c_int32), ("N2", c_int32),
+        ("lda", c_int32), ("ldw1", c_int32), ("ldx", c_int32), ("ldh", c_int32), ("ldw2", c_int32), ("ldc2", c_int32),
+        ("glu2", c_int32), ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("waves", c_int32),
+    ]
+
+
 class GnMishArgs(C.Structure):
     _fields_ = [("X", c_void_p), ("Y", c_void_p), ("R", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("film_env", c_void_p),
                 ("film_step", c_void_p)] + [(n, c_int32) for n in ("seqs", "T", "C", "groups", "pad", "in_seq_stride", "ldx", "ldy", "ldr",
@@ -299,6 +309,7 @@ SYMBOLS = {
     "ina_u8_lut": (C.c_int, [C.POINTER(U8LutArgs), c_void_p]),
     "ina_resize_f32": (C.c_int, [C.POINTER(ResizeF32Args), c_void_p]),
     "ina_dit_ffn": (C.c_int, [C.POINTER(DitFfnArgs), c_void_p]),
+    "ina_dit_rowchain": (C.c_int, [C.POINTER(DitRowchainArgs), c_void_p]),
     "ina_gn_mish": (C.c_int, [C.POINTER(GnMishArgs), c_void_p]),
     "ina_pad_rows": (C.c_int, [C.POINTER(PadRowsArgs), c_void_p]),
     "ina_ddim_step": (C.c_int, [C.POINTER(DdimStepArgs), c_void_p]),

@@ -211,6 +211,7 @@ int ina_struct_size(int k) {
         case 30: return (int)sizeof(ina_adamw_args);
         case 31: return (int)sizeof(ina_gemm_nn_args);
         case 32: return (int)sizeof(ina_attn_bwd_args);
+        case 33: return (int)sizeof(ina_dit_rowchain_args);
         default: return -1;
     }
 }
@@ -237,6 +238,7 @@ INA_ENTRY(ina_u8_lut, ina_u8_lut_args, ina_launch_u8_lut)
 INA_ENTRY(ina_resize_f32, ina_resize_f32_args, ina_launch_resize_f32)
 INA_ENTRY(ina_argmax_rows, ina_argmax_args, ina_launch_argmax)
 INA_ENTRY(ina_dit_ffn, ina_dit_ffn_args, ina_launch_dit_ffn)
+INA_ENTRY(ina_dit_rowchain, ina_dit_rowchain_args, ina_launch_dit_rowchain)
 INA_ENTRY(ina_gn_mish, ina_gn_mish_args, ina_launch_gn_mish)
 INA_ENTRY(ina_pad_rows, ina_pad_rows_args, ina_launch_pad_rows)
 INA_ENTRY(ina_ddim_step, ina_ddim_step_args, ina_launch_ddim_step)

@@ -28,6 +28,7 @@ using QwenPatchifyArgs = ina_qwen_patchify_args;
 using U8LutArgs = ina_u8_lut_args;
 using ResizeF32Args = ina_resize_f32_args;
 using DitFfnArgs = ina_dit_ffn_args;
+using DitRowchainArgs = ina_dit_rowchain_args;
 using GnMishArgs = ina_gn_mish_args;
 using PadRowsArgs = ina_pad_rows_args;
 using DdimStepArgs = ina_ddim_step_args;
@@ -74,6 +75,7 @@ int ina_launch_u8_lut(const U8LutArgs& p, hipStream_t stream);
 int ina_launch_resize_f32(const ResizeF32Args& p, hipStream_t stream);          // one axis of PIL's float ("F" mode) bicubic resample
 int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream);  // q/k-LayerNorm + self-attention + gated cross-attention of a NextDiT block
 int ina_launch_dit_ffn(const DitFfnArgs& p, hipStream_t stream);  // fused SwiGLU FFN + gated rmsnorm + residual + next pre-norm of a NextDiT block
+int ina_launch_dit_rowchain(const DitRowchainArgs& p, hipStream_t stream);  // GEMM + gated rmsnorm + residual + next pre-norm + next GEMM of a NextDiT block, one launch
 int ina_launch_gn_mish(const GnMishArgs& p, hipStream_t stream);      // GroupNorm + Mish (+ FiLM, + residual) of a ConditionalUnet1D block
 int ina_launch_pad_rows(const PadRowsArgs& p, hipStream_t stream);
 int ina_launch_ddim_step(const DdimStepArgs& p, hipStream_t stream);

@@ -43,7 +43,7 @@ def _interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 class NextDiTSystem1:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, fuse_rownorm: bool = False,
-                 fuse_ffn: bool = False, use_async: bool = True):
+                 fuse_ffn: bool = False, use_async: bool = True, row_chain: bool = True, chain_waves: int = 4):
         """use_async: the 'async' System-1 types condition the DiT on [32 memory tokens of the two look-down frames | projected VLM latents]
         (internvla_n1.py:364-381); without it ('nextdit': :382-383) the condition is the n_query projected latents alone - no DINOv2,
         MemoryEncoder or QFormer weights are read."""
@@ -53,6 +53,13 @@ class NextDiTSystem1:
         self.cfg, self.device, self.b_max = cfg, dev, max_envs
         # attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue (needs dim 384). Off by
         # default: 5 % faster than the GEMM + chained-norm pair in isolation, 1 % slower end to end next to the concurrent decode phase.
+        # round 5: everything of a block between two attention stages that is local to a row as TWO launches (csrc/dit_rowchain.hip):
+        # [attn2.to_out + norm2 / gate / residual + ffn_norm1 + linear_1/3 SwiGLU] and [linear_2 + ffn_norm2 / gate / residual + the next block's
+        # norm1 + its fused q1|k1|v1|q2 projection]; the bf16 projection and the pre-normed GEMM operand stay in registers. Used from 16 k rows
+        # (16 envs) on - below that the one-workgroup-per-128-rows grid leaves the chip empty, as for the row-panel GEMMs it is built from.
+        self.row_chain = bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] == 1024 and not fuse_rownorm and not fuse_ffn
+        self.chain_waves = chain_waves
+        self.chain_min_rows = 16384
         self.fuse_rownorm = bool(fuse_rownorm) and cfg["dit_dim"] == 384
         # feed_forward.linear_1/3 -> SiLU gate -> linear_2 -> ffn_norm2 + gate + residual -> next norm1 as ONE launch (dit_ffn.hip): the
         # [rows, 1024] intermediate never reaches HBM (3 launches and 670 MB of traffic per block at 64 envs otherwise). Parity-tested;
@@ -261,13 +268,28 @@ class NextDiTSystem1:
         mod = cs["mod"]
         m = mod[:B, l * 4 * D:(l + 1) * 4 * D]
         scale_msa, gate_msa, scale_mlp, gate_mlp = m[:, :D], m[:, D:2 * D], m[:, 2 * D:3 * D], m[:, 3 * D:]
-        if l == 0:   # later blocks get their pre-norm from the previous block's ffn_norm2 launch (chained)
-            ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
-        ops.linear(h, Lr["wq"], out=qkvq)
+        chain = self.row_chain and rows >= self.chain_min_rows
+        if l == 0 or not chain:   # later blocks of the row chain get their projection from the previous block's second launch
+            if l == 0:            # (unchained: later blocks get their pre-norm from the previous block's ffn_norm2 launch)
+                ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
+            ops.linear(h, Lr["wq"], out=qkvq)
         # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
         # env's condition rows (shared by its S samples): one launch, the projection row is read once
         kv5 = cs["kv2"][l][: B * Lz].view(B, Lz, 2, nh, hd)
         ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5)
+        if chain:
+            last = l + 1 >= self.nl
+            # attn2.to_out -> x += tanh(gate_msa) * norm2(.) -> ffn_norm1(x) * (1 + scale_mlp) -> linear_1/3 + SiLU gate
+            ops.dit_rowchain(att, Lr["wo"], Lr["n2"], x, gate=gate_msa, gamma2=Lr["fn1"], mod_scale2=scale_mlp, w2=Lr["w13"], c2=ff, glu2=True,
+                             mod_div=S * T, eps=1e-5, waves=self.chain_waves)
+            # linear_2 -> x += tanh(gate_mlp) * ffn_norm2(.) -> the next block's norm1(x) * (1 + scale_msa) -> its q1|k1|v1|q2 projection
+            if last:
+                ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, mod_div=S * T, eps=1e-5, waves=self.chain_waves)
+            else:
+                nxt = mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
+                ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt,
+                                 w2=self.layers[l + 1]["wq"], c2=qkvq, mod_div=S * T, eps=1e-5, waves=self.chain_waves)
+            return
         if self.fuse_rownorm:
             # attn2.to_out as a row-block GEMM whose epilogue does x += tanh(gate) * norm2(.) and h = ffn_norm1(x) * (1 + scale_mlp)
             ops.gemm_rownorm(att, Lr["wo"], Lr["n2"], x, gate=gate_msa, h=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp, mod_div=S * T, eps=1e-5)

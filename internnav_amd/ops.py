@@ -479,6 +479,42 @@ def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: to
     return x
 
 
+def dit_rowchain(a_in: torch.Tensor, w1: torch.Tensor, gamma1: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
+                 gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None,
+                 w2: Optional[torch.Tensor] = None, c2: Optional[torch.Tensor] = None, glu2: bool = False, mod_div: int = 0, eps: float = 1e-5,
+                 waves: int = 4) -> torch.Tensor:
+    """the row-local chain of a NextDiT block in one launch (csrc/dit_rowchain.hip):
+        x += tanh(gate[r // mod_div]) * rmsnorm(bf16(a_in @ w1.T)) * gamma1
+        H  = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div])
+        c2 = H @ w2.T   (glu2: silu(H @ wg.T) * (H @ wu.T) with w2's rows interleaved [gate16 | up16])
+    a_in bf16 [M, K1] (K1 = 384 | 1024), w1 bf16 [384, K1], x f32 [M, 384] (in place); w2 bf16 [N2, 384] -> c2 bf16 [M, N2 (/ 2)], or w2 None
+    (then h bf16 [M, 384] may be given to receive H). The projection and H never leave the chip."""
+    assert a_in.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and a_in.dim() == 2 and a_in.stride(1) == 1 and w1.stride(1) == 1
+    M, K1 = a_in.shape
+    assert w1.shape == (384, K1) and x.dtype == torch.float32 and x.shape == (M, 384) and x.stride(1) == 1
+    a = _lib.DitRowchainArgs()
+    a.A, a.W1, a.gamma1, a.X = a_in.data_ptr(), w1.data_ptr(), _f32(gamma1).data_ptr(), x.data_ptr()
+    a.M, a.K1, a.lda, a.ldw1, a.ldx = M, K1, a_in.stride(0), w1.stride(0), x.stride(0)
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.stride(-1) == 1
+        a.gate, a.mod_ld = gate.data_ptr(), gate.stride(0)
+    a.gamma2 = _ptr(_f32(gamma2))
+    if mod_scale2 is not None:
+        assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and a.mod_ld in (0, mod_scale2.stride(0))
+        a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
+    if h is not None:
+        assert w2 is None and h.dtype == torch.bfloat16 and h.shape == (M, 384) and h.stride(1) == 1
+        a.H, a.ldh = h.data_ptr(), h.stride(0)
+    if w2 is not None:
+        N2 = w2.shape[0]
+        assert w2.dtype == torch.bfloat16 and w2.shape == (N2, 384) and w2.stride(1) == 1 and c2 is not None
+        assert c2.dtype == torch.bfloat16 and c2.shape == (M, N2 // 2 if glu2 else N2) and c2.stride(1) == 1
+        a.W2, a.C2, a.N2, a.ldw2, a.ldc2, a.glu2 = w2.data_ptr(), c2.data_ptr(), N2, w2.stride(0), c2.stride(0), int(glu2)
+    a.mod_div, a.eps, a.waves = mod_div, eps, waves
+    _lib.check(_lib.lib().ina_dit_rowchain(C.byref(a), _stream()), "dit_rowchain")
+    return x
+
+
 def dit_ffn(h_in: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, gamma: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
             h: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None,
             mod_div: int = 1, eps: float = 1e-5, rotate: int = 0) -> torch.Tensor:

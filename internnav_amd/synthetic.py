@@ -143,7 +143,7 @@ class HashWeights:
 
 OUTLIER_CHANNELS = (143, 647, 1151, 1879, 2495, 3083)
 OUTLIER_SCALES = (128, 256, 512, 1024, 256, 512)
-OUTLIER_OTHERS_GAIN = 8
+OUTLIER_OTHERS_GAIN = 2
 
 
 class OutlierHashWeights(HashWeights):
@@ -151,9 +151,11 @@ class OutlierHashWeights(HashWeights):
     other parity run uses N(0, 0.02)-like weights, whose residual stream has no outliers). Six rows of layer 0's down projection are scaled
     by 128 ... 1024, so from layer 0 on six channels of the residual stream sit at 60 ... 500 where the others are O(1) (x100 - x1000), for
     every token and through all later layers. As in the real models the norm gains absorb them: in every RMSNorm behind layer 0 the gain of an
-    outlier channel is multiplied by 64 / scale (it enters the next GEMM at ~3x a normal channel) and all other gains by 8 (the outliers inflate
-    the row RMS ~9x; without this the rest of the network would fade to an identity map). All factors are powers of two: exact in bf16, so the
-    CPU fixture (oracle/make_golden_full.py --outliers) and the GPU test draw bit-identical tensors."""
+    outlier channel is multiplied by 64 / scale (it enters the next GEMM at ~2.5x a normal channel) and all other gains by 2. The outliers
+    inflate the row RMS ~13x, so the other channels enter the later layers at ~0.15-0.3 of their usual size: the later layers are attenuated,
+    deliberately - with gains of 3 and more the random-weight network turns chaotic (bf16 PyTorch itself drifts to O(1) relative error within
+    ten layers, measured) and is useless as a yardstick; with 2 its bf16 error stays at the percent level over the 28 layers.
+    All factors are powers of two: exact in bf16, so the CPU fixture (oracle/make_golden_full.py --outliers) and the GPU test draw identical bits."""
 
     def __getitem__(self, key: str) -> torch.Tensor:
         w = super().__getitem__(key)

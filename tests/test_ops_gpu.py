@@ -792,3 +792,81 @@ def test_gemm_rowpanel_bias_activation_epilogue(ops, cfg, M, N, act):
     _close(out, ref)
     d = (out.float() - tiled.float()).abs()
     assert d.max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item()) and (d > 0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("M,K1,N2,glu", [(256, 384, 2048, True), (2048, 1024, 1536, False), (1024 + 256, 384, 256, True), (512, 1024, 0, False),
+                                         (768, 384, 0, False)])
+def test_dit_rowchain(ops, waves, M, K1, N2, glu):
+    """csrc/dit_rowchain.hip: GEMM 1 (N = 384) + gated rmsnorm + residual + next pre-norm + GEMM 2 of a NextDiT block in one launch, against
+    (a) the fp32 formula of the chain with the unfused chain's rounding points (bf16 projection, bf16 pre-normed operand), (b) the three
+    launches it replaces. Several environments per launch (mod_div = 256: a workgroup's rows share one modulation row), more than one
+    workgroup per environment, row-strided views, both weight pairs; N2 = 0: no second GEMM, H written to memory instead."""
+    D, div = 384, 256
+    g = torch.Generator().manual_seed(M + K1 + N2 + waves)
+    aw = _rand((M, K1 + 64), g)
+    a_in = aw[:, :K1]                                                    # row-strided A
+    w1 = _rand((D, K1), g, scale=K1 ** -0.5)
+    x0 = torch.randn(M, D, generator=g).to(_dev())
+    g1, g2 = [(1.0 + 0.1 * torch.randn(D, generator=g)).to(_dev()) for _ in range(2)]
+    mod = (0.5 * torch.randn(M // div, 3 * D + 16, generator=g)).to(_dev())
+    gate, ms2 = mod[:, :D], mod[:, D:2 * D]
+    rowb = torch.arange(M, device=_dev()) // div
+    rms = lambda t: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5)
+    proj = (a_in.float() @ w1.float().t()).to(torch.bfloat16).float()
+    x_ref = x0 + torch.tanh(gate[rowb]) * rms(proj) * g1
+    h_ref = rms(x_ref) * g2 * (1.0 + ms2[rowb])
+    x = x0.clone()
+    if N2 == 0:
+        h = torch.full((M, D), 7.0, dtype=torch.bfloat16, device=_dev())
+        ops.dit_rowchain(a_in, w1, g1, x, gate=gate, gamma2=g2, mod_scale2=ms2, h=h, mod_div=div, waves=waves)
+        torch.cuda.synchronize()
+        _close(x, x_ref, rtol=2e-3, atol=5e-3)
+        _close(h, h_ref, rtol=1.0 / 128, atol=1e-2)
+        x2 = x0.clone()                                                  # the last block's form: no H, no second GEMM
+        ops.dit_rowchain(a_in, w1, g1, x2, gate=gate, mod_div=div, waves=waves)
+        assert torch.equal(x2, x)
+        return
+    w2 = _rand((N2, D), g, scale=D ** -0.5)
+    n_out = N2 // 2 if glu else N2
+    cw = torch.zeros(M, n_out + 8, dtype=torch.bfloat16, device=_dev())
+    c2 = cw[:, :n_out]
+    ops.dit_rowchain(a_in, w1, g1, x, gate=gate, gamma2=g2, mod_scale2=ms2, w2=w2, c2=c2, glu2=glu, mod_div=div, waves=waves)
+    torch.cuda.synchronize()
+    _close(x, x_ref, rtol=2e-3, atol=5e-3)
+    assert float(cw[:, n_out:].abs().max()) == 0.0, "columns beyond the output were written"
+    hb = h_ref.to(torch.bfloat16).float()
+    if glu:
+        wg = w2.view(N2 // 32, 2, 16, D)[:, 0].reshape(N2 // 2, D).float()
+        wu = w2.view(N2 // 32, 2, 16, D)[:, 1].reshape(N2 // 2, D).float()
+        ref2 = torch.nn.functional.silu(hb @ wg.t()) * (hb @ wu.t())
+    else:
+        ref2 = hb @ w2.float().t()
+    # the kernel rounds U = x * gamma2 * (1 + scale) to bf16 and applies the row's 1 / rms to the fp32 accumulators: one bf16 rounding of the
+    # operand either way, at a different place - the results agree to the bf16 step of the operand amplified by the K = 384 sum
+    d = (c2.float() - ref2).abs()
+    scale = ref2.abs().max().item()
+    assert d.max().item() <= 2.0 ** -6 * max(1.0, scale) and d.mean().item() <= 2.0 ** -9 * max(1.0, ref2.abs().mean().item()) + 1e-3, (d.max().item(), d.mean().item(), scale)
+    # the three launches it replaces
+    pj = ops.linear(a_in, w1)
+    xu, hu = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device=_dev())
+    ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
+    cu = ops.linear(hu, w2, act="silu", glu=True) if glu else ops.linear(hu, w2)
+    torch.cuda.synchronize()
+    _close(x, xu, rtol=1.0 / 128, atol=2e-2)
+    du = (c2.float() - cu.float()).abs()
+    assert du.max().item() <= 2.0 ** -5 * max(1.0, scale) and du.mean().item() <= 2.0 ** -8 * max(1.0, ref2.abs().mean().item()) + 1e-3, (du.max().item(), du.mean().item())
+
+
+def test_dit_rowchain_rejects_what_it_does_not_compute(ops):
+    from internnav_amd._lib import EngineError
+
+    g = torch.Generator().manual_seed(3)
+    a, w1 = _rand((256, 512), g), _rand((384, 512), g)
+    x = torch.zeros(256, 384, device=_dev())
+    g1 = torch.ones(384, device=_dev())
+    with pytest.raises(EngineError, match="K1"):
+        ops.dit_rowchain(a, w1, g1, x)
+    a, w1 = _rand((200, 384), g), _rand((384, 384), g)
+    with pytest.raises(EngineError, match="multiples"):
+        ops.dit_rowchain(a, w1, g1, torch.zeros(200, 384, device=_dev()))

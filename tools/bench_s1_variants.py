@@ -1,4 +1,5 @@
-"""System-1 call (64 envs, eager and graph) with and without the fused row-norm GEMMs. Usage: python tools/bench_s1_variants.py"""
+"""System-1 call (64 / 57 envs, graph) by variant of the row-local part of the NextDiT blocks: round-4 launches (GEMM, norm, GEMM), the round-5 row
+chain (csrc/dit_rowchain.hip, 128- and 256-row panels), the older fused row-norm / FFN kernels. Usage: python tools/bench_s1_variants.py [envs ...]"""
 import sys
 import time
 from pathlib import Path
@@ -12,11 +13,12 @@ from internnav_amd.nextdit import NextDiTSystem1  # noqa: E402
 dev = torch.device("cuda:0")
 cfg = synthetic.N1_NEXTDIT_CFG
 sd = synthetic.n1_nextdit_state_dict(seed=0)
-B = 64
-inp = synthetic.n1_nextdit_inputs(B, seed=0)
-lat, img, x0 = inp["traj_latents"].to(dev, torch.bfloat16), inp["images"].to(dev), inp["x_init"].to(dev)
-ref = None
-for name, kw in (("unfused", {}), ("fuse_rownorm", dict(fuse_rownorm=True)), ("fuse_ffn", dict(fuse_ffn=True))):
+for B in ([int(x) for x in sys.argv[1:]] or [64, 57]):
+  inp = synthetic.n1_nextdit_inputs(B, seed=0)
+  lat, img, x0 = inp["traj_latents"].to(dev, torch.bfloat16), inp["images"].to(dev), inp["x_init"].to(dev)
+  ref = None
+  for name, kw in (("unfused", dict(row_chain=False)), ("row_chain w4", dict(row_chain=True, chain_waves=4)), ("row_chain w8", dict(row_chain=True, chain_waves=8)),
+                   ("fuse_rownorm", dict(fuse_rownorm=True)), ("fuse_ffn", dict(fuse_ffn=True))):
     eng = NextDiTSystem1(sd, cfg, dev, max_envs=B, **kw)
     out = eng.generate_traj(lat, img, x0).clone()
     torch.cuda.synchronize()
