@@ -82,6 +82,12 @@ def parse():
     ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
     ap.add_argument("--fuse-rownorm", action="store_true",
                     help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
+    ap.add_argument("--s1-delay-passes", type=int, default=0,
+                    help="n1_dual: the side stream's System-1 call starts after the first k single-token decode passes of the System-2 micro-batch instead of "
+                         "right behind the prefill (the decode chain is the longer one beside System-1: a head start balances the two chains' end times)")
+    ap.add_argument("--no-row-chain", action="store_true",
+                    help="n1_dual: the round-4 launches for the row-local part of the NextDiT blocks (GEMM, norm, GEMM) instead of the row-chain kernel")
+    ap.add_argument("--chain-waves", type=int, default=4, choices=[4, 8], help="n1_dual: row panels of the row-chain kernel (4 waves = 128 rows, 8 = 256)")
     ap.add_argument("--no-s1-merge-images", action="store_true",
                     help="n1_dual: encode the look-down frames of the System-2 envs in the small System-1 call behind the decode chain (round-3 schedule) "
                          "instead of inside the side stream's batched encoder pass over all 64 envs")
@@ -102,7 +108,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, rest=[])
+                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -368,6 +374,10 @@ class N1Dual:
                                             max_seq_len=max(1024, S_max), max_patches=mmax * self.pv_rows_seq, max_s2_seqs=mmax)
         if getattr(a, "fuse_rownorm", False):
             self.model.s1.fuse_rownorm = True
+            self.model.s1.row_chain = False
+        if getattr(a, "no_row_chain", False):
+            self.model.s1.row_chain = False
+        self.model.s1.chain_waves = int(getattr(a, "chain_waves", 4))
         if getattr(a, "no_fuse_decode_norm", False):
             self.model.qwen.fuse_decode_norm = False
         if getattr(a, "no_split_prefill", False):
@@ -412,7 +422,8 @@ class N1Dual:
                                if self.raw else "pre-processed pixel_values / 224x224 frames resident in HBM"),
                      "s2": f"{self.N_IMG} frames x 784 patches" + (f" + the un-resized look-down frame ({per_ld} patches)" if self.lookdown else "") +
                            f" + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
-                     "s1": "2 look-down frames @224x224, 32 samples x 10 flow-matching steps" if self.with_s1 else "none",
+                     "s1": ("2 look-down frames @224x224, 32 samples x 10 flow-matching steps" + ("" if getattr(a, "no_row_chain", False) else
+                            f"; row-local chain of every DiT block in two launches (dit_rowchain, {int(getattr(a, 'chain_waves', 4)) * 32}-row panels)")) if self.with_s1 else "none",
                      "s2_microbatches_per_period": self.mb, "s2_every": self.s2_every, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
         self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
@@ -493,8 +504,11 @@ class N1Dual:
             self.traj = torch.zeros(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
             self.hostA = torch.empty(nA, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
             self.hostB = torch.empty(mmax, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
-            self.gA, self.gB, self.gP, self.gD, self.gAimg = {}, {}, {}, {}, {}
-            self.ev, self.ev_img = torch.cuda.Event(), torch.cuda.Event()
+            self.gA, self.gB, self.gP, self.gD, self.gD1, self.gAimg = {}, {}, {}, {}, {}, {}
+            self.ev, self.ev_img, self.ev_go = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+            self.s1_delay = max(0, min(int(getattr(a, "s1_delay_passes", 0)), self.N_DECODE - 1))
+            if self.s1_delay:
+                self.desc["s1_start"] = f"side-stream System-1 call starts behind the first {self.s1_delay} single-token decode passes (its look-down encoder pass right behind the prefill)"
 
     # ---- ingest: raw frames -> engine inputs (inside the timed step)
     def _ingest_s2(self, lo, m, dst):
@@ -576,8 +590,12 @@ class N1Dual:
                     s = self.s2[m]
                     self.gP[m] = runtime.GraphedCall(lambda s=s: q.run_prefill(s["P"], s["pv"]), {})
 
+                    kd = self.s1_delay
+                    if kd:        # the decode chain in two graphs: tokens [0, kd] (kd single-token passes), then the rest + the latent queries
+                        self.gD1[m] = runtime.GraphedCall(lambda s=s: q.run_decode(s["P"], s["toks"], 0, kd), {})
+
                     def dec(s=s):
-                        q.run_decode(s["P"], s["toks"])
+                        q.run_decode(s["P"], s["toks"], kd, None)
                         q.run_latents(s["P"], s["lat"])
                     self.gD[m] = runtime.GraphedCall(dec, {})
 
@@ -642,11 +660,16 @@ class N1Dual:
         self._ingest_s2(lo, m, s["pv"])
         self.gP[m]()
         self.ev.record(main)
+        if self.s1_delay:
+            self.gD1[m]()
+            self.ev_go.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev)
             if self.merge_images:
                 self.gAimg[(nA, m)]()
                 self.ev_img.record(self.side)
+            if self.s1_delay:
+                self.side.wait_event(self.ev_go)
             trajA = self.gA[nA]()
         self.gD[m]()
         self.latent_table[lo:lo + m].copy_(s["lat"])

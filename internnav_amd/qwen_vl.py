@@ -499,13 +499,17 @@ class QwenVLEngine:
         what a caller stores in its per-frame cache and hands back through plan(..., cached_embeds=...)."""
         return {k: self.emb_tok[a:b].clone() for k, a, b in P["fresh_tokens"]}
 
-    def run_decode(self, P: dict, tokens_out: torch.Tensor):
-        """n_decode greedy tokens: the first from the prompt's last position, then n_decode - 1 single-token passes."""
+    def run_decode(self, P: dict, tokens_out: torch.Tensor, j0: int = 0, j1: Optional[int] = None):
+        """n_decode greedy tokens: the first from the prompt's last position, then n_decode - 1 single-token passes.
+        [j0, j1): the tokens this call produces (default: all) - the chain can be issued (and captured) in pieces, e.g. to let another stream
+        start between two passes; the pieces hand over through the engine's buffers (next token, KV cache) only."""
         B, S, n = P["B"], P["S_run"], P["n_decode"]               # rows of x: the tokens this call ran (all of them without a cached prefix)
-        if n == 0:
+        j1 = n if j1 is None else min(j1, n)
+        if n == 0 or j0 >= j1:
             return
-        self._last_logits(B, S, S - 1)
-        for j in range(n):
+        if j0 == 0:
+            self._last_logits(B, S, S - 1)
+        for j in range(j0, j1):
             tokens_out[:, j].copy_(self.next_tok[:B])
             if j == n - 1:
                 break
