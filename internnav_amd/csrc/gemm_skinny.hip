@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue(GemmArgs p, const fl
 // through LDS (NW > 1) and apply the epilogue in the same kernel: no partial workspace, no second launch (a decode pass of the
 // 28-layer LLM is 4 such GEMMs per layer: the separate epilogue launches were ~0.8 ms of every pass). NW is chosen per shape so
 // the launch has a few thousand waves: 1 for the 152064-row lm_head (long-lived independent waves), 8 for a 3584-row projection.
-template <int MF, int NT16, int NW, int NC, int DEPTH>
-__global__ __launch_bounds__(NW * NC * 64) void gemm_skinny_fused_kernel(GemmArgs p) {
+// OCC: minimum waves per SIMD the register allocation must allow (1 = unconstrained). The THIN builds (OCC = 5: at most 96 registers, 4-wave
+// workgroups) are sized to co-reside with System-1's row-chain workgroups, which leave 96 registers per SIMD and 90 KiB of LDS on a CU.
+template <int MF, int NT16, int NW, int NC, int DEPTH, int OCC = 1>
+__global__ __launch_bounds__(NW * NC * 64, OCC) void gemm_skinny_fused_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float red[NW > 1 ? NC : 1][NW > 1 ? NW : 1][NT16][MF][64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = wave / NW, w = wave % NW;
@@ -307,8 +309,8 @@ void launch_skinny_fused(const GemmArgs& p, hipStream_t stream) {
 // embeddings, L2 hits: every workgroup reads the same <= 230 KB), reduces the sum of squares and writes bf16(x * rstd * gamma) into an
 // LDS image whose rows sit 16 bytes past a multiple of 256 (the 16 fragment rows of a ds_read_b128 land on 16 different bank quads).
 // The main loop is the fused kernel's with the activation fragments read from that image instead of global memory.
-template <int NT16, int NW, int NC, int DEPTH>
-__global__ __launch_bounds__(NW * NC * 64) void gemm_skinny_prenorm_kernel(GemmArgs p) {
+template <int NT16, int NW, int NC, int DEPTH, int OCC = 1>
+__global__ __launch_bounds__(NW * NC * 64, OCC) void gemm_skinny_prenorm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     constexpr int NWAVES = NW * NC;
     const int lds_ld = p.K + 8;
@@ -466,10 +468,10 @@ __global__ __launch_bounds__(NW * NC * 64) void gemm_skinny_prenorm_kernel(GemmA
     else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = f32x4{v[0], v[1], v[2], v[3]};
 }
 
-template <int NT16, int NW, int NC, int DEPTH>
+template <int NT16, int NW, int NC, int DEPTH, int OCC = 1>
 int launch_skinny_prenorm(const GemmArgs& p, hipStream_t stream, int tiles) {
     const size_t lds = (((size_t)p.M * (p.K + 8) * sizeof(bf16) + 15) & ~size_t(15)) + (NW > 1 ? size_t(NC) * NW * NT16 * 256 * sizeof(float) : 0);
-    auto kern = gemm_skinny_prenorm_kernel<NT16, NW, NC, DEPTH>;
+    auto kern = gemm_skinny_prenorm_kernel<NT16, NW, NC, DEPTH, OCC>;
     static size_t attr = 0;
     if (lds > attr) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -528,6 +530,22 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     const long total = (long)p.M * (p.N / 4);
     const int eb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(gemm_skinny_epilogue, dim3(eb), dim3(256), 0, stream, p, part, splits);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// THIN decode GEMMs (force_cfg 60, M <= 16): 4-wave workgroups of at most 96 registers - one wave per SIMD - so that a workgroup fits on a CU
+// BESIDE System-1's 256-row row-chain workgroup (8 waves x 208 registers, 67 KiB of LDS): the weight-streaming decode chain and the MFMA-bound
+// System-1 chain then share the CUs instead of taking turns on them. Same arithmetic and K order per output as the 8-wave builds with NW = 4.
+int ina_launch_gemm_skinny_thin(const GemmArgs& p, hipStream_t stream) {
+    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0, asz = (p.norm_gamma && p.a_dtype == INA_DT_F32) ? 4.0 : 2.0;
+    InaProfScope prof(INA_PROF_GEMM_SKINNY, 2.0 * p.M * p.N * p.K, asz * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
+    if (p.norm_gamma) {
+        if (p.glu) return launch_skinny_prenorm<2, 4, 1, 2, 5>(p, stream, (p.N + 31) / 32);
+        return launch_skinny_prenorm<1, 4, 1, 2, 5>(p, stream, (p.N + 15) / 16);
+    }
+    if (p.glu) hipLaunchKernelGGL((gemm_skinny_fused_kernel<1, 2, 4, 1, 2, 5>), dim3((p.N + 31) / 32), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_skinny_fused_kernel<1, 1, 4, 1, 2, 5>), dim3((p.N + 15) / 16), dim3(256), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

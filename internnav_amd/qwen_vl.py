@@ -128,6 +128,7 @@ class QwenVLEngine:
         self.split_prefill = True
         self.split_serial = False     # True: the two half micro-batches of split_prefill on ONE stream (per-launch event timing, bench.py)
         self._side = None
+        self.thin_decode = False   # bench / experiments: thin weight-streaming builds in the single-token passes (see _layers)
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
         Ip = (I + 63) // 64 * 64   # SwiGLU width padded with zero rows/cols: GLU tiles need N % 32 == 0, the LDS-DMA GEMM K % 64 == 0
@@ -299,10 +300,13 @@ class QwenVLEngine:
         # single-token decode passes (<= 16 rows): the two RMSNorms of a layer run inside the weight-streaming GEMMs that consume them
         # (ina_gemm_bf16 norm_gamma): 2 of the 9 launches per layer disappear from a chain that is launch / latency bound
         fused_norm = rows <= 16 and self.fuse_decode_norm and self.tap is None
+        # thin_decode: the four weight-streaming GEMMs of a single-token pass as 4-wave / <= 96-register builds (force_cfg 60) that fit on a CU
+        # beside System-1's row-chain workgroups; same arithmetic (a column group of 4 waves, same K order per wave)
+        cfg = 60 if (fused_norm and self.thin_decode) else 0
         for li, L in enumerate(self.layers):
             src = x_in if li == 0 else x
             if fused_norm:
-                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6))
+                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6), force_cfg=cfg)
             else:
                 ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
                 ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
@@ -310,13 +314,13 @@ class QwenVLEngine:
             ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
             ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
-            ops.linear(att, L["o_w"], residual=src, out=x)
+            ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg)
             if fused_norm:
-                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6))
+                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg)
             else:
                 ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
                 ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
-            ops.linear(ff, L["down_w"], residual=x, out=x)
+            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg)
             if self.tap is not None:
                 self.tap("llm", li, x)
 
@@ -328,7 +332,7 @@ class QwenVLEngine:
             ops.norm(self.xl[:B], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B)
         else:
             ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
-        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B])
+        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], force_cfg=60 if (self.thin_decode and B <= 16) else 0)
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)

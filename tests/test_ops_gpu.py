@@ -870,3 +870,38 @@ def test_dit_rowchain_rejects_what_it_does_not_compute(ops):
     a, w1 = _rand((200, 384), g), _rand((384, 384), g)
     with pytest.raises(EngineError, match="multiples"):
         ops.dit_rowchain(a, w1, g1, torch.zeros(200, 384, device=_dev()))
+
+
+@pytest.mark.parametrize("M,N,K,glu,prenorm", [(7, 4608, 3584, False, True), (7, 37888, 3584, True, True), (7, 3584, 3584, False, False), (7, 3584, 18944, False, False),
+                                                (5, 3584, 3584, False, False), (16, 512, 1024, False, True), (1, 4608, 3584, False, True)])
+def test_gemm_skinny_thin_builds(ops, M, N, K, glu, prenorm):
+    """force_cfg 60: the decode passes' weight-streaming GEMMs as 4-wave / <= 96-register builds (they fit on a CU beside System-1's row-chain
+    workgroups). Same operation as the default builds: against the fp32 formula and against the default kernel on the same problem, with
+    and without the fused input RMSNorm, bias / fp32 residual epilogues, the SwiGLU form."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    w = _rand((N, K), g, scale=K ** -0.5)
+    if prenorm:
+        x = (torch.randn(M, K, generator=g) * 3.0).to(_dev())
+        gamma = (1.0 + 0.1 * torch.randn(K, generator=g)).to(_dev())
+        kw = dict(prenorm=(gamma, 1e-6))
+        xn = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma).bfloat16().float()
+    else:
+        x = _rand((M, K), g)
+        kw = {}
+        xn = x.float()
+    y = xn @ w.float().t()
+    if glu:
+        y4 = y.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(y4[:, :, 0]) * y4[:, :, 1]).reshape(M, N // 2)
+        thin = ops.linear(x, w, act="silu", glu=True, force_cfg=60, **kw)
+        dflt = ops.linear(x, w, act="silu", glu=True, **kw)
+    else:
+        bias, res = torch.randn(N, generator=g).to(_dev()), torch.randn(M, N, generator=g).to(_dev())
+        ref = y + bias + res
+        thin = ops.linear(x, w, bias=bias, residual=res, out_dtype=torch.float32, force_cfg=60, **kw)
+        dflt = ops.linear(x, w, bias=bias, residual=res, out_dtype=torch.float32, **kw)
+    torch.cuda.synchronize()
+    _close(thin, ref, rtol=4e-3, atol=1e-2)
+    assert (thin.float() - dflt.float()).abs().max().item() <= 2e-2        # another split of K over the waves: fp32 summation order only
+    with pytest.raises(Exception):
+        ops.linear(_rand((17, K), g), w, force_cfg=60)                      # built for <= 16 rows

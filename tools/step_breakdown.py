@@ -8,7 +8,15 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import bench  # noqa: E402
 
-a = bench.default_args()
+kw = {}
+argv = sys.argv[1:]
+for i, x in enumerate(argv):        # e.g. `python tools/step_breakdown.py --chain-waves 8 --thin-decode --no-row-chain`
+    if x == "--chain-waves":
+        kw["chain_waves"] = int(argv[i + 1])
+    elif x in ("--thin-decode", "--no-row-chain"):
+        kw[x[2:].replace("-", "_")] = True
+a = bench.default_args(**kw)
+print("# variant:", kw or "default")
 dev = torch.device("cuda:0")
 wl = bench.N1Dual(a, dev, 0)
 wl.capture()
