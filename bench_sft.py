@@ -45,6 +45,10 @@ def parse():
                     help="frozen prefix (ViT + prefill) of every micro-batch inside its own step, on the main stream (round-3 / early round-4 schedule) "
                          "instead of one step ahead on the prefetch stream (InternVLAN1SftTrainer.prefetch)")
     ap.add_argument("--prefetch-first", action="store_true", help="A/B: issue the next prefix before this step's own launches (first version of the pipeline)")
+    ap.add_argument("--graph-prefix", action="store_true",
+                    help="the frozen prefix (ViT + ragged prefill, ~1 100 launches) as ONE hipGraph replay per prompt geometry instead of eager launches. Measured "
+                         "neutral (15.96 vs 16.27 samples/s on one box, profiles/r05g_bench_sft*.json): the pipelined step is bound by the GPU-side overlap of the "
+                         "MFMA-bound prefix with the System-1 graph, not by the host's launch rate - off by default")
     ap.add_argument("--no-graph-s1", action="store_true", help="System-1 loss + backward as eager launches (round-3 path) instead of one hipGraph replay")
     return ap.parse_args()
 
@@ -65,7 +69,7 @@ def build(a, dev, rank):
     from internnav_amd.dist import under_launcher
 
     world = int(os.environ["WORLD_SIZE"]) if under_launcher() else 1
-    tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1)
+    tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1, graph_prefix=bool(getattr(a, "graph_prefix", False)))
     tr.step_idx = 10          # past the warm-up: non-zero learning rate
     tr.prefetch_first = bool(getattr(a, "prefetch_first", False))
     g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
@@ -220,6 +224,7 @@ def main():
     if rank == 0:
         fl = flops_per_step(qcfg, info["S"], info["B"], info["T"], info["F"])
         runtime.prof_enable(True)
+        tr.graph_prefix = False           # the instrumented pass times every launch of the prefix with HIP events: eager
         tr.forward_backward(batch)
         torch.cuda.synchronize()
         prof = runtime.prof_read()
@@ -238,7 +243,8 @@ def main():
                        "s2_prompt": f"{info['F']} frames x 784 patches + text, S={info['S']} + 4 <traj> tokens", "parallelism": f"dp{world}" + ("-zero2" if a.zero2 else ""),
                        "trainable_parameters": int(sum(int(np.prod(s)) for _, s in tr.P.index.values())), "optimizer": "fused AdamW + clip 1.0, cosine_with_min_lr", "dropout": 0.1,
                        "launch": ("frozen prefix one step ahead on a prefetch stream (engine twin); " if pipe else "frozen prefix inside the step; ") +
-                                 ("System-1 loss + backward as one hipGraph replay" if not a.no_graph_s1 else "eager"), "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
+                                 ("System-1 loss + backward as one hipGraph replay" if not a.no_graph_s1 else "eager") +
+                                 ("; frozen prefix as one hipGraph replay per prompt geometry" if getattr(a, "graph_prefix", False) else ""), "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": dom["launches"],
                          "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "traffic": None,

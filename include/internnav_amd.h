@@ -127,7 +127,9 @@ typedef struct ina_attn_args {
     uint32_t drop_seed;
     uint32_t drop_thresh;
     float drop_scale;
-    int32_t kernel;         /* 0 = automatic (long dense shapes run the 32-rows-per-wave kernel of attention_wide.hip, everything else the
+    int32_t kernel;         /* (decode shapes - few query rows against a long dense KV - have their own kernels: 0 = one launch (d = 128: eight waves,
+                             * K fragments straight from global memory; otherwise four waves), 1 = the split + combine pair, 3 = the four-wave one-launch kernel.)
+                             * 0 = automatic (long dense shapes run the 32-rows-per-wave kernel of attention_wide.hip, everything else the
                              * 16-rows-per-wave kernel), 1 = the 16-rows-per-wave kernel, 2 = the 32-rows-per-wave kernel (an error outside its
                              * contract: d 64 / 80 / 128, Lq and Lk >= 128 - or packed d-80 sequences of <= 64 tokens, the Qwen ViT windows - no head gate /
                              * accumulate / dropout). Same result up to the bf16

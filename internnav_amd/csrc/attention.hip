@@ -557,6 +557,195 @@ __global__ __launch_bounds__(DEC_FUSED_WAVES * 64) void attn_decode_fused_kernel
     }
 }
 
+// Round 5: the same one-launch decode attention with the key axis spread over EIGHT waves and a quarter of the LDS. The 4-wave kernel above
+// keeps a K image and a V^T image per wave (35 KiB each, 143 KiB per workgroup): a workgroup needs an all but empty CU before it can start -
+// inside the step, where System-1's workgroups hold 67-137 KiB per CU, every layer's attention launch waited for one - and each wave walks four
+// chunks one after the other (23.6 us per layer for 13 MB of K / V). Here
+//   * the K fragments of a chunk are loaded straight from global memory in MFMA operand layout (lane -> key row t * 16 + lq, 16 bytes of its
+//     32-wide k slice: 64 contiguous bytes per row and instruction, the weight-streaming GEMMs' access pattern) - no K image, no K store pass;
+//   * V still goes through a transposed LDS image, but in two halves of the head dim (64 dims x 64 keys = 9 KiB per wave);
+//   * the next chunk's K and V are requested as soon as the current chunk's S = K Q^T MFMAs have consumed the K registers (V's registers were
+//     freed by the LDS store pass): the prefetch needs no second register set;
+//   * 8 waves x 9 KiB = 72 KiB per workgroup, two chunks per wave at Lk <= 1024.
+// The chunk arithmetic (scores, running max / sum, P V) is the 4-wave kernel's; the eight partials meet in LDS in wave order.
+constexpr int DEC8_WAVES = 8;
+
+template <int DP, int DV>
+__global__ __launch_bounds__(DEC8_WAVES * 64) void attn_decode_fused8_kernel(AttnArgs p, int nsplit, int rtiles) {
+    constexpr int KVB = 64, VT_LD = KVB + 8, VCPR = DV / 8, NKK = DP / 32, NST = KVB / 16, NSB = KVB / 32, NDT = DV / 16, HDT = NDT / 2, DH = DV / 2;
+    constexpr int PER_WAVE = DH * VT_LD;                        // bf16 elements of one wave's half V^T image
+    constexpr int PLD = DV + 2;                                 // partial row: DV x O, m, l (f32)
+    static_assert(16 * PLD * 4 <= PER_WAVE * 2, "the partial of a wave fits its V^T image");
+    static_assert(NDT % 2 == 0 && VCPR % 2 == 0, "the head dim splits into two halves of whole 16-column tiles");
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, lq = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    bf16* Vt = reinterpret_cast<bf16*>(dec_smem) + wave * PER_WAVE;
+    const int kh = blockIdx.x / rtiles, rt = blockIdx.x % rtiles, b = blockIdx.y;
+    const int G = p.H / p.Hkv;
+    const int R = rt * 16 + lq;                    // packed row of this lane
+    const bool live = R < G * p.Lq;
+    const int head = kh * G + (live ? R / p.Lq : 0), qpos = live ? R % p.Lq : 0;
+    int len_k = p.Lk;
+    if (p.k_len) len_k = min(p.k_len[b], p.Lk);
+    const bf16* __restrict__ Q = reinterpret_cast<const bf16*>(p.Q) + (size_t)b * p.q_bs + (size_t)qpos * p.q_rs + (size_t)head * p.q_hs;
+    const bf16* __restrict__ K = reinterpret_cast<const bf16*>(p.K) + (size_t)b * p.k_bs + (size_t)kh * p.k_hs;
+    const bf16* __restrict__ V = reinterpret_cast<const bf16*>(p.V) + (size_t)b * p.v_bs + (size_t)kh * p.v_hs;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc_o[NDT];
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) acc_o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 qf[NKK];
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+        const int d = kk * 32 + g * 8;
+        qf[kk] = (live && d < p.D) ? *reinterpret_cast<const bf16x8*>(Q + d) : zero8;
+    }
+    constexpr int NVI = KVB * VCPR / 64;
+    static_assert((KVB * VCPR) % 64 == 0, "chunk pieces must divide evenly over the wave");
+    bf16x8 kf[NST][NKK], vreg[NVI];
+    auto fetch = [&](int kv0) {
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            const int kv = kv0 + t * 16 + lq;
+            const bf16* kr = K + (size_t)(kv < len_k ? kv : len_k - 1) * p.k_rs + g * 8;      // (keys beyond len_k: a valid row, their scores are masked)
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) kf[t][kk] = (kk * 32 + g * 8 < p.D) ? *reinterpret_cast<const bf16x8*>(kr + kk * 32) : zero8;
+        }
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) {
+            const int q = lane + u * 64, row = q / VCPR, c = q % VCPR, kv = kv0 + row;
+            vreg[u] = (kv < len_k) ? *reinterpret_cast<const bf16x8*>(V + (size_t)kv * p.v_rs + c * 8) : zero8;
+        }
+    };
+    const float sc = p.scale * 1.4426950408889634f;
+    const int causal_shift = len_k - p.Lq;
+    const int vc = lane % VCPR;                    // this lane's 8-dim chunk of a V row (the same for every piece u: 64 % VCPR == 0)
+    int split = wave;
+    if (split * DEC_CHUNK < len_k) fetch(split * DEC_CHUNK);
+    for (; split * DEC_CHUNK < len_k; split += DEC8_WAVES) {
+        const int kv0 = split * DEC_CHUNK;
+        // ---- S^T = K Q^T from the register fragments
+        f32x4 s[NST];
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
+        }
+        // V registers of this chunk are parked in a second set only logically: the two half images are written one after the other below,
+        // so the registers stay live until the second store pass; the NEXT chunk's V therefore goes to the same registers only after it
+        bf16x8 vcur[NVI];
+#pragma unroll
+        for (int u = 0; u < NVI; ++u) vcur[u] = vreg[u];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kv = kv0 + t * 16 + g * 4 + r;
+                const bool ok = live && (kv < len_k) && (!p.causal || kv <= qpos + causal_shift);
+                const float v = ok ? s[t][r] * sc : -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_use);
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = exp2f(s[t][r] - m_use);
+                s[t][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int nt = 0; nt < NDT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc_o[nt][r] *= alpha;
+        bf16x8 pf[NSB];
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[sb][r] = (bf16)s[2 * sb][r];
+                pf[sb][4 + r] = (bf16)s[2 * sb + 1][r];
+            }
+        // ---- O^T += V^T P^T, one half of the head dim at a time through the wave's half image
+#pragma unroll
+        for (int hv = 0; hv < 2; ++hv) {
+            // (the reads of the previous half / chunk were consumed by their MFMAs: the LDS queue of a wave is in order)
+            if (vc / (VCPR / 2) == hv) {
+#pragma unroll
+                for (int u = 0; u < NVI; ++u) {
+                    const int row = (lane + u * 64) / VCPR;
+                    const int pos = vt_pos(row);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) Vt[((vc - hv * (VCPR / 2)) * 8 + i) * VT_LD + ((pos + 8 * vc) & (KVB - 1))] = vcur[u][i];   // rotated rows: see vt_pos
+                }
+            }
+            if (hv == 1 && (split + DEC8_WAVES) * DEC_CHUNK < len_k) fetch((split + DEC8_WAVES) * DEC_CHUNK);   // next chunk in flight under this half's math
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+                for (int n2 = 0; n2 < HDT; ++n2) {
+                    const int dl = n2 * 16 + lq, d = hv * DH + dl;               // row of the half image / head dim
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[dl * VT_LD + ((sb * 32 + g * 8 + 8 * (d >> 3)) & (KVB - 1))]);
+                    acc_o[hv * HDT + n2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[sb], acc_o[hv * HDT + n2], 0, 0, 0);
+                }
+        }
+    }
+    // ---- the eight partials meet in LDS (each in its wave's image): row lq -> [DV] un-normalised O (exp2 domain), m, l
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float* part = reinterpret_cast<float*>(Vt);
+#pragma unroll
+    for (int nt = 0; nt < NDT; ++nt) *reinterpret_cast<f32x4*>(part + lq * PLD + nt * 16 + g * 4) = acc_o[nt];
+    if (g == 0) { part[lq * PLD + DV] = m_run; part[lq * PLD + DV + 1] = l_run; }
+    __syncthreads();
+    if (tid < 256) {        // 256 threads: row tid / 16, DV / 16 consecutive columns each
+        constexpr int CPT = DV / 16;
+        const int row = tid >> 4, c0 = (tid & 15) * CPT;
+        const int Rr = rt * 16 + row;
+        if (Rr < G * p.Lq) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < DEC8_WAVES; ++w)
+                m = fmaxf(m, (reinterpret_cast<const float*>(reinterpret_cast<const bf16*>(dec_smem) + w * PER_WAVE) + row * PLD)[DV]);
+            const float m_use = (m == -INFINITY) ? 0.f : m;
+            float l = 0.f, o[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) o[c] = 0.f;
+#pragma unroll
+            for (int w = 0; w < DEC8_WAVES; ++w) {
+                const float* pw = reinterpret_cast<const float*>(reinterpret_cast<const bf16*>(dec_smem) + w * PER_WAVE) + row * PLD;
+                const float ms = pw[DV];
+                const float wl = (ms == -INFINITY) ? 0.f : exp2f(ms - m_use);
+                l += pw[DV + 1] * wl;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) o[c] += pw[c0 + c] * wl;
+            }
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            const int hd = kh * G + Rr / p.Lq, qp = Rr % p.Lq;
+            bf16* O = reinterpret_cast<bf16*>(p.O) + (size_t)b * p.o_bs + (size_t)qp * p.o_rs + (size_t)hd * p.o_hs;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (c0 + c < p.D) O[c0 + c] = (bf16)(o[c] * inv);
+        }
+    }
+}
+
 template <int DP, int DV>
 int launch_decode(const AttnArgs& p, hipStream_t stream) {
     const int G = p.H / p.Hkv;
@@ -565,6 +754,21 @@ int launch_decode(const AttnArgs& p, hipStream_t stream) {
     const double keys = p.causal ? 0.5 * ((double)p.Lk + (double)(p.Lk - p.Lq) + 1.0) : (double)p.Lk;
     InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
                       2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)p.B * p.Hkv * p.Lk), stream);
+    if constexpr (DV == 128 && DP == 128) {
+        // the 8-wave / 72 KiB kernel (round 5) for the decoder's d = 128 heads; ina_attn_args.kernel = 3 pins the 4-wave kernel below
+        if (nsplit <= DEC_FUSED_MAX_CHUNKS && p.kernel != 1 && p.kernel != 3) {
+            constexpr size_t LDS8 = (size_t)DEC8_WAVES * (DV / 2) * (64 + 8) * sizeof(bf16);
+            auto kern8 = attn_decode_fused8_kernel<DP, DV>;
+            static bool attr8_done = false;
+            if (!attr8_done) {
+                INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS8));
+                attr8_done = true;
+            }
+            hipLaunchKernelGGL(kern8, dim3(p.Hkv * rtiles, p.B), dim3(DEC8_WAVES * 64), LDS8, stream, p, nsplit, rtiles);
+            INA_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+    }
     if (nsplit <= DEC_FUSED_MAX_CHUNKS && p.kernel != 1) {      // (ina_attn_args.kernel = 1 pins the two-launch split + combine pair: parity tests compare)
         constexpr size_t LDS = (size_t)DEC_FUSED_WAVES * (64 * (DP + 8) + DV * (64 + 8)) * sizeof(bf16);
         auto kern = attn_decode_fused_kernel<DP, DV>;

@@ -188,13 +188,13 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
                     "gemm: the fused input RMSNorm is built for the decode passes (M <= 16 rows, K <= 4096, one batch): M=%d K=%d N=%d batch=%d", p.M, p.K, p.N, p.batch);
         INA_REQUIRE(p.a_dtype == INA_DT_BF16 || p.a_dtype == INA_DT_F32, "gemm: a_dtype must be bf16 or f32 with norm_gamma");
         INA_REQUIRE(((uintptr_t)p.norm_gamma % 16) == 0 && (p.lda % (p.a_dtype == INA_DT_F32 ? 4 : 8)) == 0, "gemm(prenorm): misaligned gamma / lda");
-        kernel = p.force_cfg == 60 ? 60 : 30;
+        kernel = (p.force_cfg == 60 || p.force_cfg == 61) ? p.force_cfg : 30;
         return 0;
     }
     INA_REQUIRE(p.force_cfg != 30, "gemm: kernel 30 (fused input RMSNorm) is selected by norm_gamma, not by force_cfg");
-    if (p.force_cfg == 60) {      // thin weight-streaming build (4-wave workgroups, <= 96 registers): the decode passes beside System-1's row chain
+    if (p.force_cfg == 60 || p.force_cfg == 61) {      // thin weight-streaming build (4-wave workgroups, <= 96 registers): the decode passes beside System-1's row chain
         INA_REQUIRE(p.M <= 16 && p.batch == 1 && p.N >= 256, "gemm: the thin weight-streaming kernels are built for M <= 16, batch 1 (M=%d N=%d)", p.M, p.N);
-        kernel = 60;
+        kernel = p.force_cfg;
         return 0;
     }
     if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) { kernel = 32; return 0; }
@@ -275,7 +275,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
     int cfg = 0;
     if (int rc = ina_plan_gemm(p_in, p, cfg)) return rc;
     if (cfg == 30) return ina_launch_gemm_skinny_prenorm(p, stream);
-    if (cfg == 60) return ina_launch_gemm_skinny_thin(p, stream);
+    if (cfg == 60 || cfg == 61) return ina_launch_gemm_skinny_thin(p, stream);
     if (cfg == 31) return ina_launch_gemm_skinny(p, stream);
     if (cfg == 32) return ina_launch_gemm_skinny_fused(p, stream);
     ina_prof_set_sub(cfg);

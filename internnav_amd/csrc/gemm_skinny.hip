@@ -540,6 +540,16 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
 int ina_launch_gemm_skinny_thin(const GemmArgs& p, hipStream_t stream) {
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0, asz = (p.norm_gamma && p.a_dtype == INA_DT_F32) ? 4.0 : 2.0;
     InaProfScope prof(INA_PROF_GEMM_SKINNY, 2.0 * p.M * p.N * p.K, asz * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
+    if (p.force_cfg == 61) {      // the same 4-wave workgroups without the register cap (experiment: workgroup size alone)
+        if (p.norm_gamma) {
+            if (p.glu) return launch_skinny_prenorm<2, 4, 1, 2>(p, stream, (p.N + 31) / 32);
+            return launch_skinny_prenorm<1, 4, 1, 2>(p, stream, (p.N + 15) / 16);
+        }
+        if (p.glu) hipLaunchKernelGGL((gemm_skinny_fused_kernel<1, 2, 4, 1, 2>), dim3((p.N + 31) / 32), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_fused_kernel<1, 1, 4, 1, 2>), dim3((p.N + 15) / 16), dim3(256), 0, stream, p);
+        INA_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (p.norm_gamma) {
         if (p.glu) return launch_skinny_prenorm<2, 4, 1, 2, 5>(p, stream, (p.N + 31) / 32);
         return launch_skinny_prenorm<1, 4, 1, 2, 5>(p, stream, (p.N + 15) / 16);

@@ -26,38 +26,54 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs p) {
     }
 }
 
-// one thread handles 8 consecutive columns j..j+7 of the first half AND their partners j + D/2 of one head of one row.
+// one thread handles 8 consecutive columns j..j+7 of the first half AND their partners j + D/2 of HC consecutive heads of one row: the 32
+// cos / sin values of its columns are loaded once and reused for those heads (round 5: one head per thread re-read the row's tables for every
+// head - 4x the bytes of the activations themselves, all through the L2: 40 us per launch at 3680 rows where the data alone are 14 us).
 // With KV set (decoder layer, X rows = q | k | v): query heads are rotated in place, key heads are rotated INTO cache row kv_dst[r],
 // value heads (the v_heads heads behind the key heads) are copied there unrotated - rope + KV-cache append in one launch.
+template <int HC>
 __global__ __launch_bounds__(256) void rope_kernel(RopeArgs p) {
     const int half = p.D >> 1;
     const int groups = half >> 3;  // 8-wide groups per half
     const int hv = p.heads + (p.KV ? p.v_heads : 0);
-    const long total = (long)p.rows * hv * groups;
+    const int hchunks = (hv + HC - 1) / HC;
+    const long total = (long)p.rows * hchunks * groups;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int g = (int)(i % groups);
-        const int h = (int)((i / groups) % hv);
-        const int r = (int)(i / ((long)groups * hv));
-        bf16* x = reinterpret_cast<bf16*>(p.X) + (size_t)map_row(p.map, r) * p.ldx + p.col0 + h * p.D + g * 8;
-        bf16x8 lo = *reinterpret_cast<const bf16x8*>(x), hi = *reinterpret_cast<const bf16x8*>(x + half);
-        bf16* out = x;
-        if (p.KV && h >= p.kv_head0) out = reinterpret_cast<bf16*>(p.KV) + (size_t)p.kv_dst[r] * p.ldkv + (h - p.kv_head0) * p.D + g * 8;
-        if (h < p.heads) {
+        const int hc = (int)((i / groups) % hchunks);
+        const int r = (int)(i / ((long)groups * hchunks));
+        const int h0 = hc * HC;
+        bf16* xr = reinterpret_cast<bf16*>(p.X) + (size_t)map_row(p.map, r) * p.ldx + p.col0 + g * 8;
+        float c0[8], s0[8], c1[8], s1[8];
+        if (h0 < p.heads) {
             const int tr = p.tab ? p.tab[r] : r;
             const float* c = p.cos + (size_t)tr * p.D + g * 8;
             const float* s = p.sin + (size_t)tr * p.D + g * 8;
-            bf16x8 olo, ohi;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = (float)lo[j], b = (float)hi[j];
-                olo[j] = (bf16)(a * c[j] - b * s[j]);                  // x*cos + (-x2)*sin
-                ohi[j] = (bf16)(b * c[half + j] + a * s[half + j]);    // x2*cos + x1*sin
-            }
-            lo = olo;
-            hi = ohi;
+            for (int j = 0; j < 8; ++j) { c0[j] = c[j]; s0[j] = s[j]; c1[j] = c[half + j]; s1[j] = s[half + j]; }
         }
-        *reinterpret_cast<bf16x8*>(out) = lo;
-        *reinterpret_cast<bf16x8*>(out + half) = hi;
+#pragma unroll
+        for (int k = 0; k < HC; ++k) {
+            const int h = h0 + k;
+            if (h >= hv) break;
+            bf16* x = xr + h * p.D;
+            bf16x8 lo = *reinterpret_cast<const bf16x8*>(x), hi = *reinterpret_cast<const bf16x8*>(x + half);
+            bf16* out = x;
+            if (p.KV && h >= p.kv_head0) out = reinterpret_cast<bf16*>(p.KV) + (size_t)p.kv_dst[r] * p.ldkv + (h - p.kv_head0) * p.D + g * 8;
+            if (h < p.heads) {
+                bf16x8 olo, ohi;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = (float)lo[j], b = (float)hi[j];
+                    olo[j] = (bf16)(a * c0[j] - b * s0[j]);        // x*cos + (-x2)*sin
+                    ohi[j] = (bf16)(b * c1[j] + a * s1[j]);        // x2*cos + x1*sin
+                }
+                lo = olo;
+                hi = ohi;
+            }
+            *reinterpret_cast<bf16x8*>(out) = lo;
+            *reinterpret_cast<bf16x8*>(out + half) = hi;
+        }
     }
 }
 
@@ -128,9 +144,13 @@ int ina_launch_rope(const RopeArgs& p, hipStream_t stream) {
     INA_REQUIRE(!p.KV || (p.kv_dst && p.kv_head0 >= 0 && p.kv_head0 <= p.heads && p.v_heads >= 0 && p.ldkv % 8 == 0), "rope: bad KV-append arguments");
     const int hv = p.heads + (p.KV ? p.v_heads : 0);
     InaProfScope prof(INA_PROF_ELEMENTWISE, 6.0 * p.rows * p.heads * p.D, 4.0 * p.rows * hv * p.D, stream);
-    const long total = (long)p.rows * hv * (p.D / 16);
+    // heads per thread: 4 where that still leaves a few hundred thousand threads (the prefill / vision launches), 1 for the small decode launches
+    const bool chunked = (long)p.rows * hv * (p.D / 16) >= (1L << 19);
+    const int hc = chunked ? 4 : 1;
+    const long total = (long)p.rows * ((hv + hc - 1) / hc) * (p.D / 16);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(rope_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    if (chunked) hipLaunchKernelGGL(rope_kernel<4>, dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(rope_kernel<1>, dim3(blocks), dim3(256), 0, stream, p);
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -302,7 +302,7 @@ class QwenVLEngine:
         fused_norm = rows <= 16 and self.fuse_decode_norm and self.tap is None
         # thin_decode: the four weight-streaming GEMMs of a single-token pass as 4-wave / <= 96-register builds (force_cfg 60) that fit on a CU
         # beside System-1's row-chain workgroups; same arithmetic (a column group of 4 waves, same K order per wave)
-        cfg = 60 if (fused_norm and self.thin_decode) else 0
+        cfg = (self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (fused_norm and self.thin_decode) else 0
         for li, L in enumerate(self.layers):
             src = x_in if li == 0 else x
             if fused_norm:
@@ -332,7 +332,7 @@ class QwenVLEngine:
             ops.norm(self.xl[:B], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B)
         else:
             ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
-        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], force_cfg=60 if (self.thin_decode and B <= 16) else 0)
+        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], force_cfg=((self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (self.thin_decode and B <= 16) else 0))
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)
@@ -586,6 +586,12 @@ class QwenVLEngine:
         cache positions with per-sequence key lengths (the pad rows' K/V are never attended and get overwritten)."""
         P = self.plan(input_ids, image_grid_thw, cached_embeds=cached_embeds, prefix_len=prefix_len)
         self.run_prefill(P, pixel_values)
+        return self.prefill_state(P, input_ids, image_grid_thw, seq_lens)
+
+    def prefill_state(self, P: dict, input_ids, image_grid_thw, seq_lens=None) -> dict:
+        """the host-side state `prefill` returns for a plan that has been run (decode / latent passes continue from it): a function of the
+        prompt GEOMETRY only (lengths, image-token positions), not of the token values - a captured prefill can be replayed on new tokens
+        and pixels of the same geometry and continue from a copy of this state (trainer: graphed frozen prefix)."""
         st = dict(B=P["B"], S=P["S"], S_run=P["S_run"], next_pos=P["next_pos"].copy(), plan=P)
         if seq_lens is not None:
             lens = np.asarray(seq_lens, dtype=np.int64)

@@ -58,7 +58,7 @@ class InternVLAN1SftTrainer:
     def __init__(self, engine: QwenVLEngine, s1_state_dict: Dict[str, torch.Tensor], device, total_steps: int = 1000, lr: float = 1e-4,
                  min_lr: float = 1e-5, warmup_ratio: float = 0.003, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, process_group=None, zero2: bool = False, system1: str = "nextdit_async",
-                 s1_cfg: Optional[dict] = None, dropout: float = 0.1, seed: int = 0, graph_s1: bool = False):
+                 s1_cfg: Optional[dict] = None, dropout: float = 0.1, seed: int = 0, graph_s1: bool = False, graph_prefix: bool = False):
         """system1: 'nextdit_async' / 'nextdit' (flow-matching loss on the NextDiT head, with / without the memory tokens of the goal / current
         frame pair in the condition, internvla_n1.py:234-258) or 'navdp_async' (epsilon loss on the NavDP head; `s1_cfg` =
         its hyper-parameters, synthetic.N1_NAVDP_CFG; the batch then also carries `traj_depths` [B, T, 224, 224] in metres).
@@ -67,6 +67,14 @@ class InternVLAN1SftTrainer:
         (`ina_*_args.drop_salt`) that is rewritten before every replay."""
         self.engine, self.device = engine, torch.device(device)
         self.graph_s1 = bool(graph_s1)
+        # graph_prefix: the frozen prefix (ViT + ragged prefill, ~1 100 launches: the step is host-bound on them) is captured into a hipGraph per
+        # prompt GEOMETRY (batch, padded length, per-sequence lengths, image-token layout, grids) the second time that geometry is seen, and
+        # replayed on the new token ids / pixels afterwards; a geometry seen once runs eagerly (a data loader that never repeats one pays nothing)
+        self.graph_prefix = bool(graph_prefix)
+        self._prefix_graphs: Dict[tuple, dict] = {}
+        self._cap_slot = 0            # library workspace slot of a prefix captured now (3 while the prefetch stream issues it)
+        self._prefix_seen: Dict[tuple, int] = {}
+        self.max_prefix_graphs = 4
         self._s1_graphs: Dict[tuple, tuple] = {}
         self.max_s1_graphs = 2
         self._salt = torch.zeros(1, dtype=torch.int32, device=self.device) if self.device.type == "cuda" else None
@@ -192,7 +200,45 @@ class InternVLAN1SftTrainer:
         for b in range(ids.shape[0]):   # right-pad rows of shorter samples: the <traj> tokens / padding behind t_s_pos are not part of the prefix
             prefix[b, t_s_pos[b]:] = 0
         pv = batch["pixel_values"].to(self.device, torch.bfloat16)
-        return e.prefill(prefix, pv, batch["image_grid_thw"], seq_lens=t_s_pos)
+        if not self.graph_prefix:
+            return e.prefill(prefix, pv, batch["image_grid_thw"], seq_lens=t_s_pos)
+        return self._prefix_graphed(e, prefix, pv, batch["image_grid_thw"], t_s_pos)
+
+    def _prefix_graphed(self, e: QwenVLEngine, prefix: torch.Tensor, pv: torch.Tensor, grid, t_s_pos) -> dict:
+        from .runtime import GraphedCall
+
+        cfg = e.cfg
+        idn = prefix.cpu().numpy()
+        layout = np.zeros(idn.shape, dtype=np.uint8)              # what the plan reads of the token ids: image / vision-start / traj positions
+        for bit, name in ((1, "image_token_id"), (2, "vision_start_id"), (4, "traj_token_id")):
+            layout |= (idn == cfg[name]).astype(np.uint8) * bit
+        g = grid.cpu().numpy() if isinstance(grid, torch.Tensor) else np.asarray(grid)
+        key = (id(e), idn.shape, layout.tobytes(), g.tobytes(), tuple(int(x) for x in t_s_pos), tuple(pv.shape))
+        ent = self._prefix_graphs.get(key)
+        if ent is None:
+            self._prefix_seen[key] = self._prefix_seen.get(key, 0) + 1
+            if self._prefix_seen[key] < 2:
+                if len(self._prefix_seen) > 64:
+                    self._prefix_seen.clear()
+                return e.prefill(prefix, pv, grid, seq_lens=t_s_pos)
+            P = e.plan(prefix, grid)
+            pv_static = torch.empty_like(pv)
+            pv_static.copy_(pv)
+            graph = GraphedCall(lambda: e.run_prefill(P, pv_static), {}, warmup=1, workspace_slot=self._cap_slot)
+            ent = dict(P=P, pv=pv_static, graph=graph, state=e.prefill_state(P, prefix, grid, t_s_pos))
+            while len(self._prefix_graphs) >= self.max_prefix_graphs:
+                self._prefix_graphs.pop(next(iter(self._prefix_graphs)))
+            self._prefix_graphs[key] = ent
+        else:
+            self._prefix_graphs[key] = self._prefix_graphs.pop(key)      # most recently used last
+        ent["P"]["ids"].copy_(prefix.reshape(-1).to(torch.int32))
+        ent["pv"].copy_(pv)
+        ent["graph"]()
+        st = dict(ent["state"])
+        st["next_pos"] = st["next_pos"].copy()
+        if "lens" in st:
+            st["lens"] = st["lens"].copy()
+        return st
 
     def _acquire_prefix(self, batch: dict) -> dict:
         """prefill state of this micro-batch's frozen prefix: the prefetched one (the trainer then switches to the engine that holds its KV
@@ -228,12 +274,14 @@ class InternVLAN1SftTrainer:
         else:
             self._pf_stream.wait_stream(main)
         _lib.check(_lib.lib().ina_set_workspace_slot(3), "set_workspace_slot")      # library scratch of launches issued beside the main stream's
+        self._cap_slot = 3
         try:
             with torch.cuda.stream(self._pf_stream):
                 state = self._prefix(self._engines[slot], batch)
                 ev = torch.cuda.Event()
                 ev.record(self._pf_stream)
         finally:
+            self._cap_slot = 0
             _lib.check(_lib.lib().ina_set_workspace_slot(0), "set_workspace_slot")
         self._pf = (batch, slot, state, ev)
 

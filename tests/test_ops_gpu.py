@@ -523,6 +523,12 @@ def test_attention_decode_gqa_split_kv(ops, B, Lq, Lk, H, Hkv, D, causal):
     two = ops.attention(q, k, v, causal=causal, kernel=1)       # the split + combine pair it replaces
     _close(two, ref, atol=1.5e-2)
     assert (out.float() - two.float()).abs().max().item() <= 1.6e-2        # same chunks, another merge order: bf16 rounding of the outputs
+    if D == 128 and Lk <= 1024:
+        # d = 128 now runs the 8-wave kernel (K fragments straight from global memory, V^T image in two halves: round 5); kernel = 3 pins the
+        # 4-wave kernel it replaced - same chunk arithmetic, eight partials instead of four
+        four = ops.attention(q, k, v, causal=causal, kernel=3)
+        _close(four, ref, atol=1.5e-2)
+        assert (out.float() - four.float()).abs().max().item() <= 1.6e-2
     # per-sequence key lengths (ragged answers): keys beyond k_len[b] are ignored, causal offset follows k_len
     lens = torch.tensor([Lk - 3 * (i % 4) for i in range(B)], dtype=torch.int32)
     out2 = ops.attention(q, k, v, causal=causal, k_len=lens.to(_dev()))

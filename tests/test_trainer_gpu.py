@@ -245,3 +245,48 @@ def test_prefetched_prefix_gives_the_same_steps(built_lib):
             assert abs(a - b) <= tol * abs(a)
         if lr < 1e-20:
             assert abs(l_seq[0] - l_seq[2]) <= 2e-6 * abs(l_seq[0]) and abs(l_pipe[1] - l_pipe[3]) <= 2e-6 * abs(l_pipe[1])   # same batch, same weights
+
+
+def test_graphed_frozen_prefix_gives_the_same_steps(built_lib):
+    """`graph_prefix=True`: the frozen prefix (ViT + ragged prefill) is captured per prompt geometry the second time the geometry is seen and
+    replayed on new token ids / pixels. Same launches on the same inputs: every step's loss equals the eager run's (lr 1e-30: the weights do not
+    move; the attention backward's fp32 atomics are the only run-to-run difference), with and without the prefetch pipeline; a new geometry
+    falls back to eager launches and gets its own graph on its second visit."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.qwen_vl import QwenVLEngine
+    from internnav_amd.trainer import InternVLAN1SftTrainer
+
+    cfg = W.QWEN_TEST_CFG
+    B, T = 2, 2
+    sd_q = W.qwen_state_dict(seed=11, cfg=cfg)
+    sd_s = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
+    b0, noise, t_index, inp = _batch(cfg, B, T, seed=3)
+    b1 = _batch(cfg, B, T, seed=4)[0]
+    b1["input_ids"] = b1["input_ids"].clone()
+    b1["input_ids"][:, 5:20] = (b1["input_ids"][:, 5:20] + 7) % 1000          # other tokens, same geometry
+    b1["pixel_values"] = b1["pixel_values"] * 0.5                               # other pixels
+    b2 = dict(b0)                                                               # another geometry: the shorter sample loses three more tokens
+    b2["t_s_pos"] = [b0["t_s_pos"][0], b0["t_s_pos"][1] - 3]
+    ids2 = b0["input_ids"].clone()
+    ids2[1, b2["t_s_pos"][1]: b2["t_s_pos"][1] + cfg["n_query"]] = cfg["traj_token_id"]
+    b2["input_ids"] = ids2
+    order = [b0, b1, dict(b0), dict(b1), b2, dict(b2), dict(b0)]
+    runs = {}
+    for name, kw, pipelined in (("eager", dict(graph_prefix=False), False), ("graphed", dict(graph_prefix=True), False), ("graphed+prefetch", dict(graph_prefix=True), True)):
+        eng = QwenVLEngine(sd_q, cfg, DEV, max_seqs=B, max_seq_len=512, max_patches=inp["pixel_values"].shape[0])
+        tr = InternVLAN1SftTrainer(eng, sd_s, DEV, total_steps=100, dropout=0.0, lr=1e-30, min_lr=1e-31, **kw)
+        tr.step_idx = 5
+        losses = []
+        for i, b in enumerate(order):
+            nxt = order[i + 1] if (pipelined and i + 1 < len(order)) else None
+            losses.append(tr.training_step(b, noise, t_index, next_batch=nxt).item())
+        runs[name] = losses
+        if kw["graph_prefix"]:
+            assert 1 <= len(tr._prefix_graphs) <= tr.max_prefix_graphs
+            if not pipelined:
+                assert len(tr._prefix_graphs) == 2        # the common geometry (captured at its second visit) and b2's
+    print(runs)
+    for name in ("graphed", "graphed+prefetch"):
+        for a, b in zip(runs["eager"], runs[name]):
+            assert abs(a - b) <= 2e-6 * abs(a), (name, runs["eager"], runs[name])
+    assert runs["eager"][0] != runs["eager"][1] and runs["eager"][0] != runs["eager"][4]

@@ -82,7 +82,12 @@ int main(int argc, char** argv) {
                           {"ViT windows half 196 x 64 (varlen), 32-row kernel", 196, 64, 64, 16, 16, 80, 0, 1, 2},
                           {"DINOv2           128 x 257, 6 heads x d64", 128, 257, 257, 6, 6, 64, 0, 0},
                           {"decode           7 x (1 query, 927 keys), 28 / 4 x d128", 7, 1, 927, 28, 4, 128, 1, 0},
-                          {"latent queries   7 x (5 queries, 933 keys)", 7, 5, 933, 28, 4, 128, 1, 0}};
+                          {"latent queries   7 x (5 queries, 933 keys)", 7, 5, 933, 28, 4, 128, 1, 0},
+                          {"decode           7 x (1, 927), 4-wave one-launch kernel (kernel 3)", 7, 1, 927, 28, 4, 128, 1, 0, 3},
+                          {"latent queries   7 x (5, 933), 4-wave one-launch kernel (kernel 3)", 7, 5, 933, 28, 4, 128, 1, 0, 3},
+                          {"decode           7 x (1, 927), split + combine pair (kernel 1)", 7, 1, 927, 28, 4, 128, 1, 0, 1},
+                          {"decode          13 x (1, 927), 28 / 4 x d128", 13, 1, 927, 28, 4, 128, 1, 0},
+                          {"decode          13 x (1, 927), 4-wave one-launch kernel (kernel 3)", 13, 1, 927, 28, 4, 128, 1, 0, 3}};
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     for (const Case& c : cases) {
