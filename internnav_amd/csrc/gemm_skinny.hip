@@ -20,6 +20,15 @@ namespace {
 
 constexpr int SK_BN = 64;    // output columns (W rows) per workgroup: 4 waves x 16
 constexpr int SK_BK = 128;   // K elements per step
+// ina_gemm_args.group_m == SK_NT_FLAG (the field orders the tiles of the LDS-DMA kernels and means nothing here): the weight stream of the
+// column-owner kernels is loaded NON-TEMPORAL (each weight byte is read exactly once per launch and by one wave: it need not displace the
+// activations / KV cache from the L2 and the Infinity Cache on its way)
+constexpr int SK_NT_FLAG = 7;
+
+__device__ __forceinline__ bf16x8 sk_load_w(const bf16* ptr, bool nt) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(ptr);
+    return nt ? __builtin_nontemporal_load(q) : *q;
+}
 
 template <int MF>  // number of 16-row activation fragments (M <= 16*MF)
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p, float* __restrict__ part, int kslice) {
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(NW * NC * 64, OCC) void gemm_skinny_fused_kernel(Ge
     const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A);
     const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool nt = p.group_m == SK_NT_FLAG;
     const bf16* wrow[NT16];
     bool wok[NT16];
 #pragma unroll
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(NW * NC * 64, OCC) void gemm_skinny_fused_kernel(Ge
             const int k = k0 + s * 32;   // load s: the 4 lane groups of a row cover 64 contiguous bytes
             const bool kok = j < nmine && k < p.K;
 #pragma unroll
-            for (int t = 0; t < NT16; ++t) wf[slot][t][s] = (kok && wok[t]) ? *reinterpret_cast<const bf16x8*>(wrow[t] + k) : zero8;
+            for (int t = 0; t < NT16; ++t) wf[slot][t][s] = (kok && wok[t]) ? sk_load_w(wrow[t] + k, nt) : zero8;
 #pragma unroll
             for (int i = 0; i < MF; ++i) af[slot][i][s] = (kok && aok[i]) ? *reinterpret_cast<const bf16x8*>(arow[i] + k) : zero8;
         }
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(NW * NC * 64, OCC) void gemm_skinny_prenorm_kernel(
     const int r16 = lane & 15, g = lane >> 4;
     const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool nt = p.group_m == SK_NT_FLAG;
     const bf16* wrow[NT16];
     bool wok[NT16];
 #pragma unroll
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(NW * NC * 64, OCC) void gemm_skinny_prenorm_kernel(
             const int k = k0 + s * 32;
             const bool kok = j < nmine && k < p.K;
 #pragma unroll
-            for (int t = 0; t < NT16; ++t) wf[slot][t][s] = (kok && wok[t]) ? *reinterpret_cast<const bf16x8*>(wrow[t] + k) : zero8;
+            for (int t = 0; t < NT16; ++t) wf[slot][t][s] = (kok && wok[t]) ? sk_load_w(wrow[t] + k, nt) : zero8;
         }
     };
 #pragma unroll

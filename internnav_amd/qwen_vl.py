@@ -128,6 +128,7 @@ class QwenVLEngine:
         self.split_prefill = True
         self.split_serial = False     # True: the two half micro-batches of split_prefill on ONE stream (per-launch event timing, bench.py)
         self._side = None
+        self.nt_decode = False     # bench / experiments: non-temporal weight loads in the single-token passes' GEMMs (gemm_skinny.hip SK_NT_FLAG)
         self.thin_decode = False   # bench / experiments: thin weight-streaming builds in the single-token passes (see _layers)
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
@@ -303,10 +304,11 @@ class QwenVLEngine:
         # thin_decode: the four weight-streaming GEMMs of a single-token pass as 4-wave / <= 96-register builds (force_cfg 60) that fit on a CU
         # beside System-1's row-chain workgroups; same arithmetic (a column group of 4 waves, same K order per wave)
         cfg = (self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (fused_norm and self.thin_decode) else 0
+        gm = 7 if (rows <= 16 and self.nt_decode) else 0     # SK_NT_FLAG: non-temporal weight stream in the column-owner GEMMs
         for li, L in enumerate(self.layers):
             src = x_in if li == 0 else x
             if fused_norm:
-                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6), force_cfg=cfg)
+                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6), force_cfg=cfg, group_m=gm)
             else:
                 ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
                 ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
@@ -314,13 +316,13 @@ class QwenVLEngine:
             ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
             ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
-            ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg)
+            ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg, group_m=gm)
             if fused_norm:
-                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg)
+                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg, group_m=gm)
             else:
                 ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
                 ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
-            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg)
+            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm)
             if self.tap is not None:
                 self.tap("llm", li, x)
 
@@ -332,7 +334,7 @@ class QwenVLEngine:
             ops.norm(self.xl[:B], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B)
         else:
             ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
-        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], force_cfg=((self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (self.thin_decode and B <= 16) else 0))
+        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], group_m=(7 if (self.nt_decode and B <= 16) else 0), force_cfg=((self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (self.thin_decode and B <= 16) else 0))
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)

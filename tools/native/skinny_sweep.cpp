@@ -74,12 +74,14 @@ static float* f32_buf(size_t elems, uint32_t seed, float scale, float offset) {
 int main(int argc, char** argv) {
     const char* lib = argc > 1 ? argv[1] : "internnav_amd/libinternnav_amd.so";
     const int passes = argc > 2 ? atoi(argv[2]) : 4;
+    const int group_m = argc > 3 ? atoi(argv[3]) : 0;      // 7 = non-temporal weight loads (SK_NT_FLAG)
+    const int force_cfg = argc > 4 ? atoi(argv[4]) : 0;    // 60 / 61: four-wave builds
     void* h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", lib, dlerror()); return 1; }
     g_gemm = (gemm_fn)dlsym(h, "ina_gemm_bf16");
     g_err = (err_fn)dlsym(h, "ina_last_error");
     if (!g_gemm || !g_err) { fprintf(stderr, "missing symbols\n"); return 1; }
-    printf("# %s\n", lib);
+    printf("# %s  group_m %d  force_cfg %d\n", lib, group_m, force_cfg);
 
     const int M = 7, H = 3584, I = 18944, QKV = 4608, V = 152064, NL = 8, LAYERS = 28;
     void *Wq[NL], *Wo[NL], *Wg[NL], *Wd[NL];
@@ -105,7 +107,7 @@ int main(int argc, char** argv) {
         ina_gemm_args a;
         memset(&a, 0, sizeof a);
         a.A = A; a.W = W; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N; a.ldr = N;
-        a.out_dtype = INA_BF16; a.res_dtype = INA_F32; a.rowscale_div = 1; a.batch = 1;
+        a.out_dtype = INA_BF16; a.res_dtype = INA_F32; a.rowscale_div = 1; a.batch = 1; a.group_m = group_m; a.force_cfg = force_cfg;
         return a;
     };
     auto go = [&](const ina_gemm_args& a, hipStream_t st) {
