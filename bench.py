@@ -86,6 +86,7 @@ def parse():
                     help="n1_dual: the side stream's System-1 call starts after the first k single-token decode passes of the System-2 micro-batch instead of "
                          "right behind the prefill (the decode chain is the longer one beside System-1: a head start balances the two chains' end times)")
     ap.add_argument("--decode-cfg", type=int, default=0, help="n1_dual: force_cfg of the decode passes' weight-streaming GEMMs (60 thin, 61 four-wave uncapped)")
+    ap.add_argument("--no-chain-stats", action="store_true", help="n1_dual: the DiT attention stage computes its LayerNorm statistics itself (round-4 kernel)")
     ap.add_argument("--nt-decode", action="store_true", help="n1_dual: non-temporal weight loads in the decode passes' GEMMs (experiment)")
     ap.add_argument("--thin-decode", action="store_true",
                     help="n1_dual: the weight-streaming GEMMs of the single-token decode passes as 4-wave / <= 96-register builds that fit on a CU beside "
@@ -113,7 +114,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, rest=[])
+                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -383,6 +384,8 @@ class N1Dual:
         if getattr(a, "no_row_chain", False):
             self.model.s1.row_chain = False
         self.model.s1.chain_waves = int(getattr(a, "chain_waves", 4))
+        if getattr(a, "no_chain_stats", False):
+            self.model.s1.chain_stats = False
         if getattr(a, "no_fuse_decode_norm", False):
             self.model.qwen.fuse_decode_norm = False
         if getattr(a, "no_split_prefill", False):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 3
+#define INA_ABI_VERSION 4
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0
@@ -435,6 +435,10 @@ typedef struct ina_dit_rowchain_args {
     int32_t mod_div, mod_ld;
     float eps;
     int32_t waves;          /* 0 / 4: 128-row panels, two workgroups per CU; 8: 256-row panels */
+    float* seg_stats;       /* f32 [M][N2/384][mean, rstd] or NULL (plain second GEMM, N2 % 384 == 0): LayerNorm statistics (eps seg_eps) of every
+                             * 384-wide segment of the C2 rows, from the fp32 accumulators - what ina_dit_attn_args.stats consumes */
+    float seg_eps;
+    int32_t _pad;
 } ina_dit_rowchain_args;
 int ina_dit_rowchain(const ina_dit_rowchain_args* args, void* stream);
 
@@ -459,7 +463,9 @@ typedef struct ina_dit_attn_args {
     int64_t k2_bs, k2_rs, v2_bs, v2_rs;
     int32_t nseq, T, heads, seq_per_env, Lz, ldx, ldo;
     float scale, eps;
-    int32_t _pad;
+    int32_t stats_ld;       /* floats per row of stats (>= 8) */
+    const float* stats;     /* f32 [nseq*T][4 segments][mean, rstd] of the X rows as ina_dit_rowchain_args.seg_stats writes them, or NULL:
+                             * the kernel then computes the LayerNorm statistics itself (a second pass over three segments) */
 } ina_dit_attn_args;
 int ina_dit_attention(const ina_dit_attn_args* args, void* stream);
 

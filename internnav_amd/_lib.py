@@ -142,7 +142,7 @@ class DitAttnArgs(C.Structure):
         ("g_q2", c_void_p), ("b_q2", c_void_p), ("K2", c_void_p), ("V2T", c_void_p), ("V2T_src", c_void_p), ("head_gate", c_void_p),
         ("k2_bs", c_int64), ("k2_rs", c_int64), ("v2_bs", c_int64), ("v2_rs", c_int64),
         ("nseq", c_int32), ("T", c_int32), ("heads", c_int32), ("seq_per_env", c_int32), ("Lz", c_int32), ("ldx", c_int32), ("ldo", c_int32),
-        ("scale", c_float), ("eps", c_float), ("_pad", c_int32),
+        ("scale", c_float), ("eps", c_float), ("stats_ld", c_int32), ("stats", c_void_p),
     ]
 
 
@@ -173,6 +173,7 @@ class DitRowchainArgs(C.Structure):
         ("M", c_int32), ("K1", c_int32), ("N2", c_int32),
         ("lda", c_int32), ("ldw1", c_int32), ("ldx", c_int32), ("ldh", c_int32), ("ldw2", c_int32), ("ldc2", c_int32),
         ("glu2", c_int32), ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("waves", c_int32),
+        ("seg_stats", c_void_p), ("seg_eps", c_float), ("_pad", c_int32),
     ]
 
 
@@ -334,7 +335,7 @@ SYMBOLS = {
 _lib = None
 # the struct layouts above mirror include/internnav_amd.h at THIS version of the C-ABI (INA_ABI_VERSION there): lib() refuses a shared object
 # built from another version - a stale .so would read pointers at the wrong offsets
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class EngineError(RuntimeError):

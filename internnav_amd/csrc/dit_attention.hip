@@ -288,6 +288,217 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
     }
 }
 
+// ---- the same stage when the PRODUCER of the projection rows hands over the LayerNorm statistics (ina_dit_rowchain computes (mean, rstd)
+// of every 384-wide segment of its output rows in its epilogue, from the fp32 accumulators): no statistics pass, no LDS exchange between
+// waves and no barrier - a (sequence, head) unit is ONE single-wave workgroup with ONE exposed memory latency (every load it will ever
+// need is requested at the top: the raw q1 / k1 / q2 slices of both 16-token tiles, the V1 slice, the condition K / V fragments, six
+// (mean, rstd) pairs), then straight-line MFMA / VALU work on both tiles (two independent dependency chains, no branch between them). The
+// projection row is read ONCE (the statistics pass read three of its four segments a second time).
+// Measured (tools/native/dit_attn_probe, 64 envs x 32 samples x 32 tokens, Lz 64; profiles/r05k_*): 112 us with its own statistics pass ->
+// 89 us as six-wave workgroups given the statistics -> 71 us as single-wave workgroups (six waves that start in lockstep also stall in
+// lockstep; 3 or 2 waves per SIMD measure the same, a head's 64 columns are exactly one 128-byte line per row: heads share no lines).
+// What is left above the 50 us of the 251 MB at ~5 TB/s are the loads every unit repeats: the LayerNorm weights (24 x 16 B per lane,
+// 13 us) and the condition K / V fragments (16 x 16 B, 15 us; an XCD-aware unit -> env mapping does not change them: L2 hits either way).
+template <int NH>
+__global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
+    constexpr int HD = 64, D = NH * HD, VT_LD = 40;
+    __shared__ __attribute__((aligned(16))) bf16 Vt[HD * VT_LD];
+    const int lane = threadIdx.x, h = (int)(blockIdx.x % NH);
+    const int g = lane >> 4, lq = lane & 15;
+    const int seq = (int)(blockIdx.x / NH), env = seq / p.seq_per_env;
+    const int T = p.T;
+    const bf16* __restrict__ base = reinterpret_cast<const bf16*>(p.X) + (size_t)seq * T * p.ldx;
+    const float* __restrict__ st = p.stats + (size_t)seq * T * p.stats_ld;
+    const bf16* __restrict__ K2 = reinterpret_cast<const bf16*>(p.K2) + (size_t)env * p.k2_bs + h * HD;
+    const bf16* __restrict__ V2T = reinterpret_cast<const bf16*>(p.V2T) + ((size_t)env * NH + h) * HD * 64;
+    const int dcol = h * HD + g * 8;                     // first of this lane's 8 columns inside a 32-wide k step (+ kk*32)
+
+    // ---- every load of the wave (rows / keys beyond T or Lz come from a clamped valid row: masked to -inf / never stored)
+    bf16x8 q1r[2][2], k1r[2][2], q2r[2][2], vraw[4], k2f[4][2], v2f[2][4];
+    f32x2 sq1[2], sk1[2], sq2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tok = min(t * 16 + lq, T - 1);
+        const bf16* row = base + (size_t)tok * p.ldx + dcol;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            k1r[t][kk] = *reinterpret_cast<const bf16x8*>(row + D + kk * 32);
+            q1r[t][kk] = *reinterpret_cast<const bf16x8*>(row + kk * 32);
+            q2r[t][kk] = *reinterpret_cast<const bf16x8*>(row + 3 * D + kk * 32);
+        }
+        const float* srow = st + (size_t)tok * p.stats_ld;
+        sq1[t] = *reinterpret_cast<const f32x2*>(srow);
+        sk1[t] = *reinterpret_cast<const f32x2*>(srow + 2);
+        sq2[t] = *reinterpret_cast<const f32x2*>(srow + 6);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i >> 1) * 16 + (lane >> 3) * 2 + (i & 1);
+        vraw[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)min(row, T - 1) * p.ldx + 2 * D + h * HD + (lane & 7) * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int key = t * 16 + lq;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            k2f[t][kk] = *reinterpret_cast<const bf16x8*>(K2 + (size_t)min(key, p.Lz - 1) * p.k2_rs + g * 8 + kk * 32);
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) v2f[sb][nt] = *reinterpret_cast<const bf16x8*>(V2T + (size_t)(nt * 16 + lq) * 64 + sb * 32 + g * 8);
+
+    // ---- this wave's V1 head slice -> its own transposed, key-permuted LDS tile (layout as in dit_attn_kernel; written and read by this
+    //      wave only: LDS operations of one wave complete in order, no barrier)
+    {
+        bf16* vt = Vt;
+        const int c = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pos = (dit_vt_pos(i * 16 + (lane >> 3) * 2) + 8 * c) & 31;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<bf16x2*>(&vt[(c * 8 + e) * VT_LD + pos]) = bf16x2{vraw[2 * i][e], vraw[2 * i + 1][e]};
+        }
+    }
+
+    const float sc = p.scale * 1.4426950408889634f;   // exp2 domain
+    const float gate = p.head_gate ? tanhf(p.head_gate[h]) : 1.0f;
+    bf16* __restrict__ O = reinterpret_cast<bf16*>(p.O) + (size_t)seq * T * p.ldo + h * HD;
+
+    // normalised K1 fragments (keys t*16 + lq)
+    bf16x8 k1f[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_k1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_k1 + dcol + kk * 32 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_k1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_k1 + dcol + kk * 32 + 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) k1f[t][kk] = ln_apply8(k1r[t][kk], sk1[t][0], sk1[t][1], g0, g1, b0, b1);
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        // (both 16-token tiles unconditionally, no branch between them: rows beyond T are clamped copies that are never stored - the two
+        //  tiles are independent dependency chains the scheduler may interleave)
+        const int tok = qt * 16 + lq;
+        const bool qok = tok < T;
+        // ================= self-attention over the sequence's own tokens
+        f32x4 o1[4];
+        {
+            bf16x8 qf[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32 + 4);
+                qf[kk] = ln_apply8(q1r[qt][kk], sq1[qt][0], sq1[qt][1], g0, g1, b0, b1);
+            }
+            f32x4 s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1f[t][kk], qf[kk], s[t], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kv = t * 16 + g * 4 + r;
+                    const float v = kv < T ? s[t][r] * sc : -INFINITY;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float l = 0.f;
+            bf16x8 pf;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
+                    l += e;
+                    pf[t * 4 + r] = (bf16)e;
+                }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv_l = 1.0f / l;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int d = nt * 16 + lq;
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[d * VT_LD + ((g + (d >> 3)) & 3) * 8]);
+                o1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o1[nt][r] = (float)(bf16)(o1[nt][r] * inv_l);   // the unfused path stores bf16 here
+            }
+        }
+        // ================= gated cross-attention against the env's condition rows
+        {
+            bf16x8 qf[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32 + 4);
+                qf[kk] = ln_apply8(q2r[qt][kk], sq2[qt][0], sq2[qt][1], g0, g1, b0, b1);
+            }
+            f32x4 s[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k2f[t][kk], qf[kk], s[t], 0, 0, 0);
+            }
+            const int lim = p.Lz - g * 4;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (t * 16 + r) < lim ? s[t][r] * sc : -INFINITY;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float l = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
+                    s[t][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float w = gate / l;
+            f32x4 o2[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) o2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                bf16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = (bf16)s[2 * sb][r];
+                    pf[4 + r] = (bf16)s[2 * sb + 1][r];
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) o2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2f[sb][nt], pf, o2[nt], 0, 0, 0);
+            }
+            if (qok) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const bf16x4 o = {(bf16)(o1[nt][0] + o2[nt][0] * w), (bf16)(o1[nt][1] + o2[nt][1] * w),
+                                      (bf16)(o1[nt][2] + o2[nt][2] * w), (bf16)(o1[nt][3] + o2[nt][3] * w)};
+                    *reinterpret_cast<bf16x4*>(O + (size_t)tok * p.ldo + nt * 16 + g * 4) = o;
+                }
+            }
+        }
+    }
+}
+
 // condition V [env][Lz rows][heads x 64] -> V2T[env][head][64 dims][64 key slots], slot = dit_vt_pos(key), zero beyond Lz
 __global__ __launch_bounds__(256) void dit_v2t_kernel(const bf16* __restrict__ V, bf16* __restrict__ V2T, long v_bs, long v_rs, int nh, int Lz, long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -320,7 +531,12 @@ int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream) {
     if (p.nseq == 0) return 0;
     const double D = p.heads * 64.0, rows = (double)p.nseq * p.T;
     InaProfScope prof(INA_PROF_ATTN, 4.0 * rows * D * (p.T + p.Lz), 2.0 * rows * D * 5.0, stream);
-    hipLaunchKernelGGL(dit_attn_kernel<6>, dim3(p.nseq), dim3(6 * 64), 0, stream, p);
+    if (p.stats) {
+        INA_REQUIRE(p.stats_ld >= 8 && p.stats_ld % 2 == 0 && ((uintptr_t)p.stats % 8) == 0, "dit_attention: stats rows are [4 segments][mean, rstd] f32 (stats_ld=%d)", p.stats_ld);
+        hipLaunchKernelGGL(dit_attn_stats_kernel<6>, dim3(p.nseq * 6), dim3(64), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(dit_attn_kernel<6>, dim3(p.nseq), dim3(6 * 64), 0, stream, p);
+    }
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -379,6 +379,11 @@ __global__ __launch_bounds__(NW * 64, 2) void dit_rowchain_kernel(ina_dit_rowcha
         bf16* __restrict__ Cb = reinterpret_cast<bf16*>(p.C2);
         const size_t crow = (size_t)(m0 + lrow2) * p.ldc2;
         const int khalf = khalf2;
+        // LayerNorm statistics of the 384-wide segments of the C2 row (plain second GEMM only): running sum / sum of squares of this lane's
+        // 64 of a tile's 128 columns, closed every third tile
+        float seg_s = 0.f, seg_q = 0.f;
+        int seg_t = 0;
+        float* __restrict__ seg_out = p.seg_stats ? p.seg_stats + (size_t)(m0 + lrow2) * (size_t)(p.N2 / D) * 2 : nullptr;
         for (int nt = 0; nt < ntiles2; ++nt) {
             f32x16 acc[4];
 #pragma unroll
@@ -401,6 +406,31 @@ __global__ __launch_bounds__(NW * 64, 2) void dit_rowchain_kernel(ina_dit_rowcha
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] *= rstd2;
+            if constexpr (!GLU2) {
+                if (seg_out) {
+                    float ts[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            ts[j] += acc[j][r];
+                            tq[j] = fmaf(acc[j][r], acc[j][r], tq[j]);
+                        }
+                    seg_s += (ts[0] + ts[1]) + (ts[2] + ts[3]);
+                    seg_q += (tq[0] + tq[1]) + (tq[2] + tq[3]);
+                    asm volatile("" : "+v"(seg_s), "+v"(seg_q));
+                    if (++seg_t == 3) {
+                        seg_s += __shfl_xor(seg_s, 32);
+                        seg_q += __shfl_xor(seg_q, 32);
+                        const float mean = seg_s * (1.0f / D);
+                        const float var = fmaxf(seg_q * (1.0f / D) - mean * mean, 0.f);
+                        // both column halves of a row hold the same pair and store it to the same place (no exec-mask branch)
+                        *reinterpret_cast<f32x2*>(seg_out + (nt / 3) * 2) = f32x2{mean, rsqrtf(var + p.seg_eps)};
+                        seg_s = seg_q = 0.f;
+                        seg_t = 0;
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (GLU2) {
@@ -465,9 +495,11 @@ int ina_launch_dit_rowchain(const ina_dit_rowchain_args& p_in, hipStream_t strea
     INA_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.W1 % 16) == 0 && ((uintptr_t)p.X % 16) == 0 && ((uintptr_t)p.H % 16) == 0, "dit_rowchain: misaligned pointer");
     INA_REQUIRE((!p.gate && !p.mod_scale2) || p.mod_ld >= RC_D, "dit_rowchain: modulation needs mod_ld >= 384");
     INA_REQUIRE((size_t)384 * p.ldw1 < (1u << 30) && (!p.W2 || (size_t)p.N2 * p.ldw2 < (1u << 30)), "dit_rowchain: weight too large for 32-bit element offsets");
+    INA_REQUIRE(p.W2 || !p.seg_stats, "dit_rowchain: seg_stats are statistics of the second GEMM's output rows");
     if (p.W2) {
         INA_REQUIRE(p.C2 && p.N2 > 0 && p.N2 % 128 == 0 && p.ldw2 % 8 == 0 && p.ldc2 % 8 == 0 && ((uintptr_t)p.W2 % 16) == 0 && ((uintptr_t)p.C2 % 16) == 0,
                     "dit_rowchain: second GEMM needs C2, N2 %% 128 == 0 and 16-byte aligned rows (N2=%d)", p.N2);
+        INA_REQUIRE(!p.seg_stats || (!p.glu2 && p.N2 % 384 == 0 && ((uintptr_t)p.seg_stats % 8) == 0), "dit_rowchain: seg_stats needs a plain second GEMM with N2 %% 384 == 0 (N2=%d)", p.N2);
         INA_REQUIRE(p.K1 == (p.glu2 ? 384 : 1024), "dit_rowchain: built pairs are (K1 = 384, SwiGLU second GEMM) and (K1 = 1024, plain second GEMM)");
     }
     ina_prof_set_sub(42);

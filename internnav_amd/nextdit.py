@@ -60,6 +60,9 @@ class NextDiTSystem1:
         self.row_chain = bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] == 1024 and not fuse_rownorm and not fuse_ffn
         self.chain_waves = chain_waves
         self.chain_min_rows = 16384
+        # the chain's second launch also hands the attention stage the LayerNorm statistics of the projection rows it writes (blocks 1 ...):
+        # dit_attention then reads every row once and runs without its statistics pass / barrier
+        self.chain_stats = True
         self.fuse_rownorm = bool(fuse_rownorm) and cfg["dit_dim"] == 384
         # feed_forward.linear_1/3 -> SiLU gate -> linear_2 -> ffn_norm2 + gate + residual -> next norm1 as ONE launch (dit_ffn.hip): the
         # [rows, 1024] intermediate never reaches HBM (3 launches and 670 MB of traffic per block at 64 envs otherwise). Parity-tested;
@@ -167,6 +170,7 @@ class NextDiTSystem1:
         self.h = torch.empty(rows, D, dtype=bf, device=dev)
         self.att = torch.empty(rows, D, dtype=bf, device=dev)
         self.qkvq = torch.empty(rows, 4 * D, dtype=bf, device=dev)
+        self.qstats = torch.empty(rows, 4, 2, dtype=torch.float32, device=dev)
         self.proj = torch.empty(rows, D, dtype=bf, device=dev)   # wo / w2 outputs feed an RMSNorm, not the residual stream: bf16 halves their traffic
         self.ff = torch.empty(rows, cfg["dit_ffn"], dtype=bf, device=dev)
         self.sample = torch.empty(rows, 3, dtype=f32, device=dev)
@@ -276,7 +280,9 @@ class NextDiTSystem1:
         # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
         # env's condition rows (shared by its S samples): one launch, the projection row is read once
         kv5 = cs["kv2"][l][: B * Lz].view(B, Lz, 2, nh, hd)
-        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5)
+        stats = self.qstats[:rows] if (chain and self.chain_stats) else None
+        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5,
+                          stats=stats if l > 0 else None)
         if chain:
             last = l + 1 >= self.nl
             # attn2.to_out -> x += tanh(gate_msa) * norm2(.) -> ffn_norm1(x) * (1 + scale_mlp) -> linear_1/3 + SiLU gate
@@ -288,7 +294,7 @@ class NextDiTSystem1:
             else:
                 nxt = mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
                 ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt,
-                                 w2=self.layers[l + 1]["wq"], c2=qkvq, mod_div=S * T, eps=1e-5, waves=self.chain_waves)
+                                 w2=self.layers[l + 1]["wq"], c2=qkvq, mod_div=S * T, eps=1e-5, waves=self.chain_waves, seg_stats=stats, seg_eps=1e-5)
             return
         if self.fuse_rownorm:
             # attn2.to_out as a row-block GEMM whose epilogue does x += tanh(gate) * norm2(.) and h = ffn_norm1(x) * (1 + scale_mlp)

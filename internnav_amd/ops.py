@@ -430,11 +430,13 @@ def dit_v2t(kv2: torch.Tensor, heads: int, v2t: torch.Tensor) -> torch.Tensor:
 
 
 def dit_attention(x: torch.Tensor, out: torch.Tensor, norms, kv2: torch.Tensor, v2t: torch.Tensor, head_gate: Optional[torch.Tensor],
-                  T: int, seq_per_env: int, heads: int, eps: float = 1e-5, scale: Optional[float] = None) -> torch.Tensor:
+                  T: int, seq_per_env: int, heads: int, eps: float = 1e-5, scale: Optional[float] = None,
+                  stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """NextDiT attention stage in one launch: out = SDPA(LN(q1), LN(k1), v1) + tanh(gate) * SDPA(LN(q2), K2, V2).
 
     x bf16 [rows, 4*heads*64] = [q1 | k1 | v1 | q2] per token, rows = nseq * T; norms = ((g_q1, b_q1), (g_k1, b_k1), (g_q2, b_q2)) f32;
-    kv2 bf16 [envs, Lz, 2, heads, 64]; v2t from dit_v2t(kv2); out bf16 [rows, heads*64]."""
+    kv2 bf16 [envs, Lz, 2, heads, 64]; v2t from dit_v2t(kv2); out bf16 [rows, heads*64]. stats f32 [rows, 4, 2]: (mean, rstd) of the four
+    segments of every x row from the producer (dit_rowchain(seg_stats=)); None = the kernel computes them itself."""
     D = heads * 64
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 4 * D and x.stride(1) == 1 and x.shape[0] % T == 0
     assert out.dtype == torch.bfloat16 and out.shape == (x.shape[0], D) and out.stride(1) == 1
@@ -448,6 +450,9 @@ def dit_attention(x: torch.Tensor, out: torch.Tensor, norms, kv2: torch.Tensor, 
     a.k2_bs, a.k2_rs = k.stride(0), k.stride(1)
     a.nseq, a.T, a.heads, a.seq_per_env, a.Lz, a.ldx, a.ldo = nseq, T, heads, seq_per_env, kv2.shape[1], x.stride(0), out.stride(0)
     a.scale, a.eps = (scale if scale is not None else 64 ** -0.5), eps
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.shape == (x.shape[0], 4, 2) and stats.is_contiguous()
+        a.stats, a.stats_ld = stats.data_ptr(), 8
     _lib.check(_lib.lib().ina_dit_attention(C.byref(a), _stream()), "dit_attention")
     return out
 
@@ -482,13 +487,15 @@ def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: to
 def dit_rowchain(a_in: torch.Tensor, w1: torch.Tensor, gamma1: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
                  gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None,
                  w2: Optional[torch.Tensor] = None, c2: Optional[torch.Tensor] = None, glu2: bool = False, mod_div: int = 0, eps: float = 1e-5,
-                 waves: int = 4) -> torch.Tensor:
+                 waves: int = 4, seg_stats: Optional[torch.Tensor] = None, seg_eps: float = 1e-5) -> torch.Tensor:
     """the row-local chain of a NextDiT block in one launch (csrc/dit_rowchain.hip):
         x += tanh(gate[r // mod_div]) * rmsnorm(bf16(a_in @ w1.T)) * gamma1
         H  = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div])
         c2 = H @ w2.T   (glu2: silu(H @ wg.T) * (H @ wu.T) with w2's rows interleaved [gate16 | up16])
     a_in bf16 [M, K1] (K1 = 384 | 1024), w1 bf16 [384, K1], x f32 [M, 384] (in place); w2 bf16 [N2, 384] -> c2 bf16 [M, N2 (/ 2)], or w2 None
-    (then h bf16 [M, 384] may be given to receive H). The projection and H never leave the chip."""
+    (then h bf16 [M, 384] may be given to receive H). The projection and H never leave the chip.
+    seg_stats f32 [M, N2 // 384, 2] (plain second GEMM): receives (mean, rstd) of every 384-wide segment of the c2 rows = the LayerNorm
+    statistics dit_attention(stats=) consumes."""
     assert a_in.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and a_in.dim() == 2 and a_in.stride(1) == 1 and w1.stride(1) == 1
     M, K1 = a_in.shape
     assert w1.shape == (384, K1) and x.dtype == torch.float32 and x.shape == (M, 384) and x.stride(1) == 1
@@ -510,6 +517,10 @@ def dit_rowchain(a_in: torch.Tensor, w1: torch.Tensor, gamma1: torch.Tensor, x: 
         assert w2.dtype == torch.bfloat16 and w2.shape == (N2, 384) and w2.stride(1) == 1 and c2 is not None
         assert c2.dtype == torch.bfloat16 and c2.shape == (M, N2 // 2 if glu2 else N2) and c2.stride(1) == 1
         a.W2, a.C2, a.N2, a.ldw2, a.ldc2, a.glu2 = w2.data_ptr(), c2.data_ptr(), N2, w2.stride(0), c2.stride(0), int(glu2)
+    if seg_stats is not None:
+        assert w2 is not None and not glu2 and N2 % 384 == 0
+        assert seg_stats.dtype == torch.float32 and seg_stats.shape == (M, N2 // 384, 2) and seg_stats.is_contiguous()
+        a.seg_stats, a.seg_eps = seg_stats.data_ptr(), seg_eps
     a.mod_div, a.eps, a.waves = mod_div, eps, waves
     _lib.check(_lib.lib().ina_dit_rowchain(C.byref(a), _stream()), "dit_rowchain")
     return x

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol(built_lib):
         assert hasattr(h, name), f"{name} declared in include/internnav_amd.h but not exported"
     from internnav_amd import _lib
 
-    assert _lib.lib().ina_abi_version() == 3
+    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_sizes_match_header(built_lib):
@@ -38,7 +38,7 @@ def test_struct_sizes_match_header(built_lib):
                _lib.SeqpoolArgs, _lib.SelectArgs, _lib.PoolActArgs, _lib.GatherArgs,
                _lib.RopeArgs, _lib.MropeTableArgs, _lib.ArgmaxArgs, _lib.DitAttnArgs, _lib.GemmRownormArgs, _lib.ResizeU8Args, _lib.QwenPatchifyArgs, _lib.U8LutArgs, _lib.ResizeF32Args, _lib.DitFfnArgs, _lib.GnMishArgs, _lib.PadRowsArgs, _lib.DdimStepArgs,
                _lib.EwArgs, _lib.ColsumArgs, _lib.NormBwdArgs, _lib.TransposeArgs, _lib.SparseRowsArgs, _lib.SmallLinearArgs, _lib.MseArgs,
-               _lib.AdamwArgs, _lib.GemmNnArgs, _lib.AttnBwdArgs]
+               _lib.AdamwArgs, _lib.GemmNnArgs, _lib.AttnBwdArgs, _lib.DitRowchainArgs]
     for k, m in enumerate(mirrors):
         assert ctypes.sizeof(m) == _lib.lib().ina_struct_size(k), f"struct {k} ({m.__name__}) layout mismatch"
     assert _lib.lib().ina_struct_size(len(mirrors)) == -1

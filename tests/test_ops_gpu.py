@@ -592,6 +592,17 @@ def test_dit_attention_fused_qknorm_self_cross(ops, envs, S, T, Lz):
                   out=un.view(envs, S * T, heads, 64), accumulate=True)
     _close(out, un, atol=8e-3, rtol=1.0 / 128)
 
+    # the statistics handed over by the producer of the rows (ina_dit_rowchain's seg_stats): the one-pass kernel without its own statistics pass
+    seg4 = x.float().view(nseq * T, 4, D)
+    mean = seg4.mean(-1)
+    stats = torch.stack([mean, torch.rsqrt(seg4.var(-1, unbiased=False) + 1e-5)], -1).contiguous()
+    stats[:, 2] = float("nan")                                           # the v1 segment is not normalised: its pair must never be read
+    out_s = torch.full_like(out, 7.0)
+    ops.dit_attention(x, out_s, list(zip(norms, biases)), kv2, v2t, gate, T=T, seq_per_env=S, heads=heads, stats=stats)
+    torch.cuda.synchronize()
+    _close(out_s, ref, atol=2e-2)
+    _close(out_s, out, atol=8e-3, rtol=1.0 / 128)
+
 
 @pytest.mark.parametrize("rms,C", [(True, 384), (False, 384), (True, 1024), (True, 96)])
 def test_norm_chained_prenorm(ops, rms, C):
@@ -853,6 +864,18 @@ def test_dit_rowchain(ops, waves, M, K1, N2, glu):
     d = (c2.float() - ref2).abs()
     scale = ref2.abs().max().item()
     assert d.max().item() <= 2.0 ** -6 * max(1.0, scale) and d.mean().item() <= 2.0 ** -9 * max(1.0, ref2.abs().mean().item()) + 1e-3, (d.max().item(), d.mean().item(), scale)
+    if not glu and N2 % 384 == 0:
+        # LayerNorm statistics of the 384-wide segments of the produced rows, for the attention stage that consumes them
+        x3, c3 = x0.clone(), torch.zeros_like(cw)
+        st = torch.full((M, N2 // 384, 2), float("nan"), device=_dev())
+        ops.dit_rowchain(a_in, w1, g1, x3, gate=gate, gamma2=g2, mod_scale2=ms2, w2=w2, c2=c3[:, :n_out], mod_div=div, waves=waves, seg_stats=st, seg_eps=1e-5)
+        torch.cuda.synchronize()
+        assert torch.equal(x3, x) and torch.equal(c3, cw), "the statistics epilogue changed the outputs"
+        seg = c2.float().view(M, N2 // 384, 384)
+        m_ref, r_ref = seg.mean(-1), torch.rsqrt(seg.var(-1, unbiased=False) + 1e-5)
+        # (from the fp32 accumulators: the bf16 rounding of the 384 stored values averages out of both moments)
+        assert (st[..., 0] - m_ref).abs().max().item() <= 2e-3 * max(1.0, scale), (st[..., 0] - m_ref).abs().max().item()
+        assert ((st[..., 1] - r_ref).abs() / r_ref).max().item() <= 2e-3, ((st[..., 1] - r_ref).abs() / r_ref).max().item()
     # the three launches it replaces
     pj = ops.linear(a_in, w1)
     xu, hu = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device=_dev())

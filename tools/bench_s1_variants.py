@@ -17,9 +17,12 @@ for B in ([int(x) for x in sys.argv[1:]] or [64, 57]):
   inp = synthetic.n1_nextdit_inputs(B, seed=0)
   lat, img, x0 = inp["traj_latents"].to(dev, torch.bfloat16), inp["images"].to(dev), inp["x_init"].to(dev)
   ref = None
-  for name, kw in (("unfused", dict(row_chain=False)), ("row_chain w4", dict(row_chain=True, chain_waves=4)), ("row_chain w8", dict(row_chain=True, chain_waves=8)),
+  for name, kw in (("unfused", dict(row_chain=False)), ("row_chain w4", dict(row_chain=True, chain_waves=4)),
+                   ("row_chain w4 own-stats", dict(row_chain=True, chain_waves=4, chain_stats=False)), ("row_chain w8", dict(row_chain=True, chain_waves=8)),
                    ("fuse_rownorm", dict(fuse_rownorm=True)), ("fuse_ffn", dict(fuse_ffn=True))):
+    chain_stats = kw.pop("chain_stats", True)
     eng = NextDiTSystem1(sd, cfg, dev, max_envs=B, **kw)
+    eng.chain_stats = chain_stats
     out = eng.generate_traj(lat, img, x0).clone()
     torch.cuda.synchronize()
     if ref is None:
@@ -32,5 +35,5 @@ for B in ([int(x) for x in sys.argv[1:]] or [64, 57]):
         g()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
-    print(f"{name:14s} S1 call over {B} envs (graph): {ms:7.2f} ms   max|diff| vs unfused {(out - ref).abs().max().item():.3e}", flush=True)
+    print(f"{name:22s} S1 call over {B} envs (graph): {ms:7.2f} ms   max|diff| vs unfused {(out - ref).abs().max().item():.3e}", flush=True)
     del eng, g

@@ -50,6 +50,18 @@ __global__ void checksum(const uint32_t* p, size_t n, unsigned long long* out) {
     for (; i < n; i += stride) s += (unsigned long long)p[i] * (2 * i + 1);
     atomicAdd(out, s);
 }
+// (mean, rstd) of every D-wide segment of the X rows: what ina_dit_rowchain's seg_stats epilogue hands to the attention stage
+__global__ void row_stats(const uint16_t* x, float* st, size_t nseg, int D, float eps) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= nseg) return;
+    float s = 0.f, q = 0.f;
+    for (int c = 0; c < D; ++c) {
+        const float v = __uint_as_float((uint32_t)x[i * D + c] << 16);
+        s += v; q += v * v;
+    }
+    const float m = s / D, var = fmaxf(q / D - m * m, 0.f);
+    st[2 * i] = m; st[2 * i + 1] = rsqrtf(var + eps);
+}
 static void* bf16_buf(size_t n, uint32_t seed, float scale) {
     void* p;
     HIP_OK(hipMalloc(&p, n * 2));
@@ -83,6 +95,9 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&V2T, (size_t)ENVS * NH * 64 * 64 * 2));
     float *g1 = f32_buf(D, 3, 0.2f, 1.0f), *b1 = f32_buf(D, 4, 0.1f, 0.0f), *g2 = f32_buf(D, 5, 0.2f, 1.0f), *b2 = f32_buf(D, 6, 0.1f, 0.0f),
           *g3 = f32_buf(D, 7, 0.2f, 1.0f), *b3 = f32_buf(D, 8, 0.1f, 0.0f), *gate = f32_buf(NH, 9, 1.0f, 0.0f);
+    float* ST;
+    HIP_OK(hipMalloc(&ST, rows_max * 4 * 2 * sizeof(float)));
+    hipLaunchKernelGGL(row_stats, dim3((unsigned)((rows_max * 4 + 255) / 256)), dim3(256), 0, 0, (const uint16_t*)X, ST, rows_max * 4, D, 1e-5f);
     unsigned long long* cs;
     HIP_OK(hipMalloc(&cs, 8));
     HIP_OK(hipDeviceSynchronize());
@@ -108,21 +123,25 @@ int main(int argc, char** argv) {
         a.X = nullptr;                                             // first call: build the transposed condition-V image only
         if (dit(&a, nullptr) != 0) { fprintf(stderr, "ina_dit_attention (V2T): %s\n", err()); return 3; }
         a.V2T_src = nullptr; a.X = X;
-        HIP_OK(hipMemset(O, 0, rows_max * D * 2));
-        if (dit(&a, nullptr) != 0) { fprintf(stderr, "ina_dit_attention: %s\n", err()); return 3; }
-        HIP_OK(hipMemset(cs, 0, 8));
-        hipLaunchKernelGGL(checksum, dim3(256), dim3(256), 0, 0, (const uint32_t*)O, rows_max * D / 2, cs);
-        unsigned long long v = 0;
-        HIP_OK(hipMemcpy(&v, cs, 8, hipMemcpyDeviceToHost));
-        const int reps = 20;
-        HIP_OK(hipEventRecord(e0, 0));
-        for (int i = 0; i < reps; ++i) dit(&a, nullptr);
-        HIP_OK(hipEventRecord(e1, 0));
-        HIP_OK(hipEventSynchronize(e1));
-        float ms = 0;
-        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = ms * 1e3 / reps, bytes = 5.0 * a.nseq * c.T * D * 2.0;
-        printf("%-46s %8.1f us  %5.2f TB/s  checksum %016llx\n", c.name, us, bytes / us * 1e-6, v);
+        for (int with_stats = 0; with_stats < 2; ++with_stats) {
+            a.stats = with_stats ? ST : nullptr;
+            a.stats_ld = 8;
+            HIP_OK(hipMemset(O, 0, rows_max * D * 2));
+            if (dit(&a, nullptr) != 0) { fprintf(stderr, "ina_dit_attention: %s\n", err()); return 3; }
+            HIP_OK(hipMemset(cs, 0, 8));
+            hipLaunchKernelGGL(checksum, dim3(256), dim3(256), 0, 0, (const uint32_t*)O, rows_max * D / 2, cs);
+            unsigned long long v = 0;
+            HIP_OK(hipMemcpy(&v, cs, 8, hipMemcpyDeviceToHost));
+            const int reps = 20;
+            HIP_OK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; ++i) dit(&a, nullptr);
+            HIP_OK(hipEventRecord(e1, 0));
+            HIP_OK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / reps, bytes = 5.0 * a.nseq * c.T * D * 2.0;
+            printf("%-46s %-14s %8.1f us  %5.2f TB/s  checksum %016llx\n", c.name, with_stats ? "stats given" : "own stats", us, bytes / us * 1e-6, v);
+        }
     }
     return 0;
 }
