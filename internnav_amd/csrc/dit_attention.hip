@@ -294,15 +294,17 @@ __global__ __launch_bounds__(NH * 64, 3) void dit_attn_kernel(DitAttnArgs p) {
 // need is requested at the top: the raw q1 / k1 / q2 slices of both 16-token tiles, the V1 slice, the condition K / V fragments, six
 // (mean, rstd) pairs), then straight-line MFMA / VALU work on both tiles (two independent dependency chains, no branch between them). The
 // projection row is read ONCE (the statistics pass read three of its four segments a second time).
-// Measured (tools/native/dit_attn_probe, 64 envs x 32 samples x 32 tokens, Lz 64; profiles/r05k_*): 112 us with its own statistics pass ->
-// 89 us as six-wave workgroups given the statistics -> 71 us as single-wave workgroups (six waves that start in lockstep also stall in
-// lockstep; 3 or 2 waves per SIMD measure the same, a head's 64 columns are exactly one 128-byte line per row: heads share no lines).
-// What is left above the 50 us of the 251 MB at ~5 TB/s are the loads every unit repeats: the LayerNorm weights (24 x 16 B per lane,
-// 13 us) and the condition K / V fragments (16 x 16 B, 15 us; an XCD-aware unit -> env mapping does not change them: L2 hits either way).
-template <int NH>
+// Measured (tools/native/dit_attn_probe, 64 envs x 32 samples x 32 tokens, Lz 64; profiles/r05k_*, r05o_*): 112 us with its own statistics
+// pass -> 89 us as six-wave workgroups given the statistics -> 71 us as single-wave workgroups (six waves that start in lockstep also stall
+// in lockstep; 3 or 2 waves per SIMD measure the same; a head's 64 columns are exactly one 128-byte line per row: heads share no lines;
+// an XCD-aware unit -> env mapping changes nothing: the condition fragments are L2 hits either way) -> 60 us with the LayerNorm vectors
+// through an LDS table (below) = 4.2 TB/s of the 251 MB; the engine's shape (57 envs, Lz 36: three key tiles) 104 -> 48 us = 4.7 TB/s.
+// KT: 16-key tiles of the condition that can hold a real key (Lz <= 16 * KT)
+template <int NH, int KT>
 __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
     constexpr int HD = 64, D = NH * HD, VT_LD = 40;
     __shared__ __attribute__((aligned(16))) bf16 Vt[HD * VT_LD];
+    __shared__ __attribute__((aligned(16))) float gb[6][HD];   // LayerNorm weight / bias of q1, k1, q2 restricted to this head's 64 columns
     const int lane = threadIdx.x, h = (int)(blockIdx.x % NH);
     const int g = lane >> 4, lq = lane & 15;
     const int seq = (int)(blockIdx.x / NH), env = seq / p.seq_per_env;
@@ -314,6 +316,15 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
     const int dcol = h * HD + g * 8;                     // first of this lane's 8 columns inside a 32-wide k step (+ kk*32)
 
     // ---- every load of the wave (rows / keys beyond T or Lz come from a clamped valid row: masked to -inf / never stored)
+    // the head's slice of the six LayerNorm vectors: one coalesced 4-byte load per vector (lane = column) into an LDS table the lanes then read
+    // their 8-column groups from (per-lane 16-byte global loads of the same 1.5 KB - 24 per wave, each lane group repeating the others' addresses -
+    // were 13 us of the 71 us kernel)
+    float gbr[6];
+    {
+        const float* const vec[6] = {p.g_q1, p.b_q1, p.g_k1, p.b_k1, p.g_q2, p.b_q2};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gbr[i] = vec[i][h * HD + lane];
+    }
     bf16x8 q1r[2][2], k1r[2][2], q2r[2][2], vraw[4], k2f[4][2], v2f[2][4];
     f32x2 sq1[2], sk1[2], sq2[2];
 #pragma unroll
@@ -337,17 +348,19 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
         vraw[i] = *reinterpret_cast<const bf16x8*>(base + (size_t)min(row, T - 1) * p.ldx + 2 * D + h * HD + (lane & 7) * 8);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < KT; ++t) {
         const int key = t * 16 + lq;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
             k2f[t][kk] = *reinterpret_cast<const bf16x8*>(K2 + (size_t)min(key, p.Lz - 1) * p.k2_rs + g * 8 + kk * 32);
     }
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
+    for (int sb = 0; sb < (KT + 1) / 2; ++sb)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) v2f[sb][nt] = *reinterpret_cast<const bf16x8*>(V2T + (size_t)(nt * 16 + lq) * 64 + sb * 32 + g * 8);
 
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gb[i][lane] = gbr[i];
     // ---- this wave's V1 head slice -> its own transposed, key-permuted LDS tile (layout as in dit_attn_kernel; written and read by this
     //      wave only: LDS operations of one wave complete in order, no barrier)
     {
@@ -370,8 +383,8 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
     bf16x8 k1f[2][2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_k1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_k1 + dcol + kk * 32 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_k1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_k1 + dcol + kk * 32 + 4);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gb[2][g * 8 + kk * 32]), g1 = *reinterpret_cast<const f32x4*>(&gb[2][g * 8 + kk * 32 + 4]);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&gb[3][g * 8 + kk * 32]), b1 = *reinterpret_cast<const f32x4*>(&gb[3][g * 8 + kk * 32 + 4]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) k1f[t][kk] = ln_apply8(k1r[t][kk], sk1[t][0], sk1[t][1], g0, g1, b0, b1);
     }
@@ -388,8 +401,8 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
             bf16x8 qf[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q1 + dcol + kk * 32 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q1 + dcol + kk * 32 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gb[0][g * 8 + kk * 32]), g1 = *reinterpret_cast<const f32x4*>(&gb[0][g * 8 + kk * 32 + 4]);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&gb[1][g * 8 + kk * 32]), b1 = *reinterpret_cast<const f32x4*>(&gb[1][g * 8 + kk * 32 + 4]);
                 qf[kk] = ln_apply8(q1r[qt][kk], sq1[qt][0], sq1[qt][1], g0, g1, b0, b1);
             }
             f32x4 s[2];
@@ -438,21 +451,23 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
             bf16x8 qf[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32), g1 = *reinterpret_cast<const f32x4*>(p.g_q2 + dcol + kk * 32 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32), b1 = *reinterpret_cast<const f32x4*>(p.b_q2 + dcol + kk * 32 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(&gb[4][g * 8 + kk * 32]), g1 = *reinterpret_cast<const f32x4*>(&gb[4][g * 8 + kk * 32 + 4]);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(&gb[5][g * 8 + kk * 32]), b1 = *reinterpret_cast<const f32x4*>(&gb[5][g * 8 + kk * 32 + 4]);
                 qf[kk] = ln_apply8(q2r[qt][kk], sq2[qt][0], sq2[qt][1], g0, g1, b0, b1);
             }
             f32x4 s[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f};      // tiles >= KT hold no key: their probabilities stay 0
+                if (t < KT) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k2f[t][kk], qf[kk], s[t], 0, 0, 0);
+                    for (int kk = 0; kk < 2; ++kk) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k2f[t][kk], qf[kk], s[t], 0, 0, 0);
+                }
             }
             const int lim = p.Lz - g * 4;
             float mx = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = (t * 16 + r) < lim ? s[t][r] * sc : -INFINITY;
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float l = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(64, 2) void dit_attn_stats_kernel(DitAttnArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) o2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
+            for (int sb = 0; sb < (KT + 1) / 2; ++sb) {
                 bf16x8 pf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -533,7 +548,10 @@ int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream) {
     InaProfScope prof(INA_PROF_ATTN, 4.0 * rows * D * (p.T + p.Lz), 2.0 * rows * D * 5.0, stream);
     if (p.stats) {
         INA_REQUIRE(p.stats_ld >= 8 && p.stats_ld % 2 == 0 && ((uintptr_t)p.stats % 8) == 0, "dit_attention: stats rows are [4 segments][mean, rstd] f32 (stats_ld=%d)", p.stats_ld);
-        hipLaunchKernelGGL(dit_attn_stats_kernel<6>, dim3(p.nseq * 6), dim3(64), 0, stream, p);
+        if (p.Lz <= 16) hipLaunchKernelGGL((dit_attn_stats_kernel<6, 1>), dim3(p.nseq * 6), dim3(64), 0, stream, p);
+        else if (p.Lz <= 32) hipLaunchKernelGGL((dit_attn_stats_kernel<6, 2>), dim3(p.nseq * 6), dim3(64), 0, stream, p);
+        else if (p.Lz <= 48) hipLaunchKernelGGL((dit_attn_stats_kernel<6, 3>), dim3(p.nseq * 6), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((dit_attn_stats_kernel<6, 4>), dim3(p.nseq * 6), dim3(64), 0, stream, p);
     } else {
         hipLaunchKernelGGL(dit_attn_kernel<6>, dim3(p.nseq), dim3(6 * 64), 0, stream, p);
     }

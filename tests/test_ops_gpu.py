@@ -551,7 +551,7 @@ def test_argmax_rows_first_maximum(ops):
     assert o2.tolist() == y.argmax(-1).tolist()
 
 
-@pytest.mark.parametrize("envs,S,T,Lz", [(2, 5, 32, 36), (1, 3, 20, 64), (3, 1, 32, 5), (2, 32, 32, 36)])
+@pytest.mark.parametrize("envs,S,T,Lz", [(2, 5, 32, 36), (1, 3, 20, 64), (3, 1, 32, 5), (2, 32, 32, 36), (2, 4, 32, 20), (1, 2, 7, 48)])
 def test_dit_attention_fused_qknorm_self_cross(ops, envs, S, T, Lz):
     """NextDiT attention stage in one launch vs the unfused fp32 formula: LayerNorm across heads on q1 / k1 / q2, self-attention
     inside each T-token sequence, tanh-gated cross-attention against the env's Lz condition rows; and vs the unfused op sequence
