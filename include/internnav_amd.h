@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 4
+#define INA_ABI_VERSION 5
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0
@@ -87,12 +87,17 @@ typedef struct ina_gemm_args {
     const float* norm_gamma; /* f32 [K] or NULL (no fused norm; A is bf16) */
     float norm_eps;
     int32_t a_dtype;        /* dtype of A when norm_gamma is set: INA_BF16 | INA_F32 */
+    const void* Wp;         /* NULL, or the same W in MFMA fragment order (ina_gemm_preshuffle; N % 16 == 0, K % 32 == 0): tile config 40 takes its
+                             * B fragments from it straight into registers (selected where cfg 39 would run; bit-equal results) */
 } ina_gemm_args;
 int ina_gemm_bf16(const ina_gemm_args* args, void* stream);
+/* W bf16 [N,K] (row stride ldw) -> Wp bf16 [N*K]: fragment (n / 16, k / 32) is one contiguous KiB, element (n, k) at
+ * ((n / 16) * (K / 32) + k / 32) * 512 + ((k % 32) / 8 * 16 + n % 16) * 8 + k % 8. Done once per weight at load time. */
+int ina_gemm_preshuffle(const void* W, void* Wp, int32_t N, int32_t K, int64_t ldw, void* stream);
 /* Which kernel ina_gemm_bf16 would run for these arguments - validation and tile selection only, nothing is launched and no GPU is needed
  * (the selection is host arithmetic on M / N / K, the epilogue and force_cfg): *kernel = 1-8 register-staged tiles, 11-29 / 33 LDS-DMA tiles
  * (18 = 256x256 ping-pong, 21 = 192x256 ping-pong, 22 / 26 / 27 single-buffer tiles of the d = 384 heads, 33 = 256x256 with 16 waves),
- * 34-37 row-panel kernels (K = 384), 38 / 39 the 256x256 tile on four waves of 128x128 (39 is selected for wide no-residual K = 2048 .. 4096 GEMMs),
+ * 34-37 row-panel kernels (K = 384), 38 / 39 / 40 the 256x256 tile on four waves of 128x128 (39 is selected for wide no-residual K = 2048 .. 4096 GEMMs, 40 instead of it when Wp is given),
  * 30 = weight streaming with the fused input RMSNorm, 31 / 32 = weight streaming (M <= 64). Returns non-zero (and sets ina_last_error)
  * exactly when ina_gemm_bf16 would reject the arguments. */
 int ina_gemm_select(const ina_gemm_args* args, int* kernel);

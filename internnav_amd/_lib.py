@@ -25,6 +25,7 @@ class GemmArgs(C.Structure):
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
         ("force_cfg", c_int32), ("group_m", c_int32),
         ("norm_gamma", c_void_p), ("norm_eps", c_float), ("a_dtype", c_int32),
+        ("Wp", c_void_p),
     ]
 
 
@@ -291,6 +292,7 @@ SYMBOLS = {
     "ina_device_check": (C.c_int, [C.c_char_p, C.c_int]),
     "ina_gemm_bf16": (C.c_int, [C.POINTER(GemmArgs), c_void_p]),
     "ina_gemm_select": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int)]),
+    "ina_gemm_preshuffle": (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "ina_attention_bf16": (C.c_int, [C.POINTER(AttnArgs), c_void_p]),
     "ina_norm_bf16": (C.c_int, [C.POINTER(NormArgs), c_void_p]),
     "ina_patchify": (C.c_int, [C.POINTER(PatchifyArgs), c_void_p]),
@@ -335,7 +337,7 @@ SYMBOLS = {
 _lib = None
 # the struct layouts above mirror include/internnav_amd.h at THIS version of the C-ABI (INA_ABI_VERSION there): lib() refuses a shared object
 # built from another version - a stale .so would read pointers at the wrong offsets
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class EngineError(RuntimeError):

@@ -158,6 +158,10 @@ int ina_gemm_bf16(const ina_gemm_args* args, void* stream) {
     return ina_launch_gemm(*args, reinterpret_cast<hipStream_t>(stream));
 }
 
+int ina_gemm_preshuffle(const void* W, void* Wp, int32_t N, int32_t K, int64_t ldw, void* stream) {
+    return ina_launch_gemm_preshuffle(W, Wp, N, K, (long)ldw, reinterpret_cast<hipStream_t>(stream));
+}
+
 int ina_gemm_select(const ina_gemm_args* args, int* kernel) {
     INA_REQUIRE(args != nullptr && kernel != nullptr, "gemm_select: null argument");
     GemmArgs p;

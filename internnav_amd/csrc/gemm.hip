@@ -258,10 +258,16 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
             // (r04m_native_w4_chain.log). Bit-equal (same K order). It loses where the epilogue or the prologue weighs more: fp32-residual
             // outputs (o / down: -3 ... -14 %), K = 1280 (vision blocks: -4 ... -6 %) - those stay on cfg 18 / 33.
             if (cfg == 18 && !p.R && p.K >= 2048 && p.K <= 4096 && p.N >= 4096 && p.M >= 2048 && ina_gemm_w4_contract(p)) cfg = 39;
+            // ... and cfg 40 where the caller also holds W in MFMA fragment order (Wp, ina_gemm_preshuffle): B fragments straight from global
+            // memory into registers, LDS-DMA for A only - half the DMA pieces and half the fragment reads of cfg 39 (gemm_w4.hip). Bit-equal.
+            // Also ahead of the ping-pong tile on the long-K fp32-residual down projection (K = 18944: 444 vs 469 us at 3680 rows, 434 vs 442 at 2760;
+            // profiles/r05s_native_w4p.log); the short-K residual GEMMs (o, vision blocks) stay on cfg 33 / 18.
+            if ((cfg == 39 || (cfg == 18 && p.K >= 8192 && ina_gemm_w4_contract(p))) && p.Wp && p.N % 16 == 0 && p.batch == 1) cfg = 40;
         }
     }
-    if (cfg == 38 || cfg == 39)
-        INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 38 / 39 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
+    if (cfg == 40) INA_REQUIRE(p.Wp && p.N % 16 == 0 && p.batch == 1, "gemm: tile config 40 needs the fragment-ordered copy of W (Wp), N %% 16 == 0, no batch (N=%d)", p.N);
+    if (cfg == 38 || cfg == 39 || cfg == 40)
+        INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 38 / 39 / 40 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
                     "(M=%d N=%d K=%d ldc=%d)", p.M, p.N, p.K, p.ldc);
     if (cfg >= 34 && cfg <= 37)
         INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34-37 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
@@ -288,7 +294,7 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
         case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: case 38: case 39: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: case 38: case 39: case 40: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         case 34: case 35: case 36: case 37: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
 #ifdef INA_RP_EXPERIMENTS
         case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: return ina_launch_gemm_rowpanel(p, stream, cfg);

@@ -527,7 +527,7 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 24: return launch_pp32<256, 256, 4, 3>(p, stream);      // same with a 3-stage ring (96 KiB LDS)
         case 25: return launch_pp32<128, 256, 4, 4>(p, stream);      // 128x256, wave tile 64x64, 4-stage ring (96 KiB LDS)
         case 33: return launch_glds<256, 256, 4, 4, 2>(p, stream);   // 256x256 lock-step with 16 waves (wave tile 64x64, 4 waves per SIMD): the fp32-residual GEMMs with a short K loop
-        case 38: case 39: return ina_launch_gemm_w4(p, stream, cfg);                      // 256x256, FOUR waves of 128x128 (wave tile 128 x 128): gemm_w4.hip
+        case 38: case 39: case 40: return ina_launch_gemm_w4(p, stream, cfg);                      // 256x256, FOUR waves of 128x128 (wave tile 128 x 128): gemm_w4.hip
         case 29: return launch_pp32<128, 256, 4, 3>(p, stream);      // same with a 3-stage ring: 72 KiB LDS, 2 workgroups per CU (short-K experiment, round 3)
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }

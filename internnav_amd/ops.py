@@ -61,8 +61,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
            rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
-           batched: bool = False, group_m: int = 0, prenorm=None) -> torch.Tensor:
+           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
+
+    w_frag: the same weight in MFMA fragment order (gemm_preshuffle(w)): the wide no-residual GEMMs that would run tile config 39 then take
+    their B fragments from it straight into registers (config 40, bit-equal); ignored by every other tile.
 
     batched=True: x is [Bt, M, K] and out [Bt, M, N] views with arbitrary batch strides (rows contiguous-strided inside a
     batch); residual is [Bt, M, N] or a [M, N] table broadcast over the batch (e.g. positional embeddings).
@@ -110,11 +113,26 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.rowscale_div = rowscale_div
     a.force_cfg = force_cfg if force_cfg else _AUTO_CFG
     a.group_m = group_m
+    if w_frag is not None:
+        assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and w_frag.numel() == N * K and N % 16 == 0 and K % 32 == 0
+        a.Wp = w_frag.data_ptr()
     if prenorm is not None:
         gamma, eps = prenorm
         assert not batched and x.dtype in (torch.bfloat16, torch.float32) and gamma.dtype == torch.float32 and gamma.is_contiguous() and gamma.numel() == K
         a.norm_gamma, a.norm_eps, a.a_dtype = gamma.data_ptr(), float(eps), _DT[x.dtype]
     _lib.check(_lib.lib().ina_gemm_bf16(C.byref(a), _stream()), "gemm_bf16")
+    return out
+
+
+def gemm_preshuffle(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """w bf16 [N, K] -> the same elements in MFMA fragment order (flat [N * K]): fragment (n // 16, k // 32) is one contiguous KiB whose lane
+    (k % 32 // 8) * 16 + n % 16 holds 8 consecutive k. Done once per weight at load time; consumed by linear(w_frag=)."""
+    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    if out is None:
+        out = torch.empty(N * K, dtype=torch.bfloat16, device=w.device)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == N * K
+    _lib.check(_lib.lib().ina_gemm_preshuffle(w.data_ptr(), out.data_ptr(), N, K, w.stride(0), _stream()), "gemm_preshuffle")
     return out
 
 

@@ -189,6 +189,15 @@ class QwenVLEngine:
                 gu_w=_interleave16(W[b + "mlp.gate_proj.weight"].to(dev), W[b + "mlp.up_proj.weight"].to(dev)).to(bf),
                 down_w=w(b + "mlp.down_proj.weight"),
                 kv=torch.empty(max_seqs * max_seq_len, self.kv_w, dtype=bf, device=dev)))
+        # the three wide decoder weights a second time in MFMA fragment order (ops.gemm_preshuffle, + 12 GB at the 7B geometry): the prefill GEMMs
+        # that run the four-wave 256 x 256 tile then fetch their B fragments straight from global memory into registers (tile config 40,
+        # gemm_w4.hip: half the LDS-DMA pieces and fragment reads per stage; bit-equal); the single-token passes keep streaming the row-major copy
+        self.frag_weights = torch.device(dev).type == "cuda"
+        if self.frag_weights:
+            for L in self.layers:
+                for k in ("qkv_w", "gu_w", "down_w"):
+                    n_, k_ = L[k].shape
+                    L[k + "f"] = ops.gemm_preshuffle(L[k]) if (n_ % 16 == 0 and k_ % 32 == 0) else None
         self.norm_w = f("model.norm.weight")
         self.lm_head = w("lm_head.weight")
         self.latent_q = W["model.latent_queries"].to(device=dev, dtype=bf).reshape(-1, H).contiguous()
@@ -307,11 +316,12 @@ class QwenVLEngine:
         gm = 7 if (rows <= 16 and self.nt_decode) else 0     # SK_NT_FLAG: non-temporal weight stream in the column-owner GEMMs
         for li, L in enumerate(self.layers):
             src = x_in if li == 0 else x
+            wf = (lambda k, L=L: L.get(k)) if (self.frag_weights and rows > 64) else (lambda k: None)
             if fused_norm:
                 ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6), force_cfg=cfg, group_m=gm)
             else:
                 ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv)
+                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"))
             # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
             ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
@@ -321,8 +331,8 @@ class QwenVLEngine:
                 ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg, group_m=gm)
             else:
                 ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff)
-            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm)
+                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"))
+            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm, w_frag=wf("down_wf"))
             if self.tap is not None:
                 self.tap("llm", li, x)
 

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol(built_lib):
         assert hasattr(h, name), f"{name} declared in include/internnav_amd.h but not exported"
     from internnav_amd import _lib
 
-    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_struct_sizes_match_header(built_lib):

@@ -410,13 +410,15 @@ def test_gemm_shared_tail_selection_is_bit_equal(ops, M, N, K, glu):
     assert torch.equal(plain, ops.linear(x, w, force_cfg=-1, **kw))
 
 
-@pytest.mark.parametrize("cfg", [38, 39])
+@pytest.mark.parametrize("cfg", [38, 39, 40])
 @pytest.mark.parametrize("M,N,K,mode", [(2760, 4608, 3584, "bias"), (2100, 4096, 3584, "glu"), (777, 1024, 448, "glu"), (1000, 1000, 192, "res"),
-                                        (300, 264, 64, "bias"), (515, 520, 128, "plain"), (2761, 3592, 320, "bf16res")])
+                                        (300, 264, 64, "bias"), (515, 520, 128, "plain"), (2761, 3592, 320, "bf16res"),
+                                        (300, 272, 64, "bias"), (515, 528, 128, "plain"), (1000, 1008, 192, "res"), (2761, 3600, 320, "bf16res")])
 def test_gemm_four_wave_tile_is_bit_equal(ops, cfg, M, N, K, mode):
-    """gemm_w4.hip (tile configs 38 / 39: 256 x 256 on four waves of 128 x 128, asm-threaded K loop) accumulates K in the order of the
-    8-wave tiles: bit-equal to the ping-pong kernel (cfg 18) under every epilogue, with ragged edges and 1 / 2 / 3 / 5 / 7 / 56 K stages
-    (the loop requests two stages ahead: the last two stages take the path that requests nothing)."""
+    """gemm_w4.hip (tile configs 38 / 39: 256 x 256 on four waves of 128 x 128, asm-threaded K loop; 40: the same tile with its B fragments
+    fetched from the fragment-ordered copy of W straight into registers) accumulates K in the order of the 8-wave tiles: bit-equal to the
+    ping-pong kernel (cfg 18) under every epilogue, with ragged edges and 1 / 2 / 3 / 5 / 7 / 56 K stages (the loop requests two stages
+    ahead: the last two stages take the path that requests nothing; cfg 40 peels its first stage as well)."""
     g = torch.Generator().manual_seed(M + K)
     x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
     kw = {}
@@ -429,16 +431,54 @@ def test_gemm_four_wave_tile_is_bit_equal(ops, cfg, M, N, K, mode):
     elif mode == "bf16res":
         kw = dict(residual=_rand((M, N), g))
     ref = ops.linear(x, w, force_cfg=18, **kw)
+    if cfg == 40:
+        if N % 16:
+            with pytest.raises(RuntimeError, match="N % 16"):
+                ops.gemm_preshuffle(w)
+            return
+        kw["w_frag"] = ops.gemm_preshuffle(w)
     out = ops.linear(x, w, force_cfg=cfg, **kw)
+    torch.cuda.synchronize()
     assert torch.equal(ref, out)
     if mode in ("bias", "plain"):
         _close(out, x.float() @ w.float().t() + (kw["bias"] if "bias" in kw else 0.0))
+
+
+def test_gemm_preshuffle_layout_and_auto_selection(ops):
+    """ina_gemm_preshuffle: fragment (n // 16, k // 32) is one contiguous KiB, lane (k % 32 // 8) * 16 + n % 16 holds 8 consecutive k; with the
+    fragment-ordered copy at hand the auto selection runs config 40 exactly where it would run 39 (and the result does not change by a bit)."""
+    from internnav_amd import _lib
+    import ctypes as C
+
+    g = torch.Generator().manual_seed(40)
+    N, K = 4608, 3584
+    w = _rand((N + 3, K + 8), g)[:N, :K]                                 # row-strided source
+    wf = ops.gemm_preshuffle(w)
+    ref = w.reshape(N // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+    assert torch.equal(wf, ref)
+    x = _rand((2760, K), g)
+    bias = torch.randn(N, generator=g).to(_dev())
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C, a.M, a.N, a.K, a.lda, a.ldw, a.ldc, a.batch = x.data_ptr(), w.data_ptr(), x.data_ptr(), 2760, N, K, K, w.stride(0), N, 1
+    a.out_dtype = 0
+    k = C.c_int(0)
+    _lib.check(_lib.lib().ina_gemm_select(C.byref(a), C.byref(k)), "select")
+    assert k.value == 39
+    a.Wp = wf.data_ptr()
+    _lib.check(_lib.lib().ina_gemm_select(C.byref(a), C.byref(k)), "select")
+    assert k.value == 40
+    assert torch.equal(ops.linear(x, w, bias=bias), ops.linear(x, w, bias=bias, w_frag=wf))
+    wc = w.contiguous()
+    small = _rand((64, K), g)
+    assert torch.equal(ops.linear(small, wc), ops.linear(small, wc, w_frag=wf))     # any other tile ignores the copy
 
 
 def test_gemm_four_wave_tile_rejects_unaligned_rows(ops):
     x, w = torch.zeros(300, 64, dtype=torch.bfloat16, device=_dev()), torch.zeros(260, 64, dtype=torch.bfloat16, device=_dev())
     with pytest.raises(RuntimeError, match="38 / 39"):
         ops.linear(x, w, force_cfg=39)          # bf16 rows of 520 bytes
+    with pytest.raises(RuntimeError, match="fragment-ordered copy"):
+        ops.linear(x[:, :64], torch.zeros(256, 64, dtype=torch.bfloat16, device=_dev()), force_cfg=40)   # no w_frag
 
 
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]

@@ -31,8 +31,11 @@
 
 typedef int (*gemm_fn)(const ina_gemm_args*, void*);
 typedef const char* (*err_fn)(void);
+typedef int (*shuf_fn)(const void*, void*, int32_t, int32_t, int64_t, void*);
 static gemm_fn g_gemm;
 static err_fn g_err;
+static shuf_fn g_shuffle;
+static const void* g_Wp;   // fragment-ordered copy of the current W (tile config 40)
 
 __global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -100,6 +103,7 @@ static ina_gemm_args make(const Shape& s, const void* A, const void* W, void* C,
     a.glu = s.glu;
     a.rowscale_div = 1; a.batch = 1;
     a.force_cfg = cfg; a.group_m = group_m;
+    a.Wp = cfg == 40 ? g_Wp : nullptr;
     return a;
 }
 
@@ -131,6 +135,7 @@ int main(int argc, char** argv) {
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", lib, dlerror()); return 1; }
     g_gemm = (gemm_fn)dlsym(h, "ina_gemm_bf16");
     g_err = (err_fn)dlsym(h, "ina_last_error");
+    g_shuffle = (shuf_fn)dlsym(h, "ina_gemm_preshuffle");
     typedef int (*chk_fn)(char*, int);
     chk_fn chk = (chk_fn)dlsym(h, "ina_device_check");
     if (!g_gemm || !g_err || !chk) { fprintf(stderr, "missing symbols\n"); return 1; }
@@ -141,7 +146,8 @@ int main(int argc, char** argv) {
     const int H = 3584, I = 18944, QKV = 4608, VH = 1280, VI = 3456;
     const int rows_llm[] = {6440, 5520, 3680, 2760};         // 7 / 6 envs joint; 4 / 3 envs (the halves of the two-stream prefill)
     const int rows_vit[] = {21952, 18816, 12544, 9408};
-    Buf A, W, C0, C1, R, cnt;
+    Buf A, W, Wp, C0, C1, R, cnt;
+    Wp.alloc((size_t)2 * I * H * 2);
     A.alloc((size_t)21952 * I);                               // >= every A (bf16): 6440 x 18944 x 2 B = 244 MB, 21952 x 3456 x 2 B
     W.alloc((size_t)2 * I * H * 2);                           // gate|up weight 37888 x 3584 bf16
     C0.alloc((size_t)6440 * I * 2 + (size_t)21952 * 3840 * 4);
@@ -174,6 +180,11 @@ int main(int argc, char** argv) {
                 continue;
             }
             printf("%-13s M %5d N %5d K %5d :", name, M, N, K);
+            g_Wp = nullptr;
+            if (g_shuffle && N % 16 == 0 && K % 32 == 0) {       // the fragment-ordered copy of this line's W for config 40
+                if (g_shuffle(W.p, Wp.p, N, K, K, nullptr) != 0) { fprintf(stderr, "ina_gemm_preshuffle: %s\n", g_err()); return 3; }
+                g_Wp = Wp.p;
+            }
             const char* q = line + off;
             int cfg, gm, adv, first = 1;
             while (sscanf(q, " %d%n", &cfg, &adv) == 1) {
