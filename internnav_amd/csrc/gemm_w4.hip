@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4p_kernel(GemmArgs p) {
         const char* bb = b_base(sl2);
         for_seq<NMF>([&](auto Ic) __attribute__((always_inline)) {
             constexpr int I = decltype(Ic)::value, j = I >> 3, i = I & 7;
+            // (one wait per fragment PAIR instead - vmcnt(14 + 8 P) / vmcnt(14 + (6 - j) P + j D) at even j - measures the same: r05v)
             if constexpr (i == 0) wait_vm<(SET == 0) ? 15 + 8 * P : 15 + (7 - j) * P + j * D>();
             mfma_tied(acc[j >> 2][i][j & 3], fb[SET][j], fa[SET][i]);
             if constexpr (i == 3) lds_read16<j * 2048>(fa[SET ^ 1][j], aa);
