@@ -2,12 +2,12 @@
 #   bash tools/final_validation.sh <tag> [quick]      quick: skip the variant benches and the PMC passes
 export TMPDIR=/tmp
 R=$PWD
-TAG=${1:-r04}
+TAG=${1:-r05}
 QUICK=${2:-}
 mkdir -p $R/gpurun_out
-rm -f $R/gpurun_out/qwen_full_drift.txt $R/gpurun_out/sft_full_drift.txt $R/gpurun_out/sft_navdp_drift.txt $R/gpurun_out/s1_b64_distribution.txt
-timeout 1500 python -m pytest tests -q -m gpu > $R/gpurun_out/${TAG}_pytest_gpu.log 2>&1
-for f in qwen_full_drift sft_full_drift sft_navdp_drift s1_b64_distribution; do cp $R/gpurun_out/$f.txt $R/gpurun_out/${TAG}_$f.txt 2>/dev/null; done
+rm -f $R/gpurun_out/qwen_full_drift.txt $R/gpurun_out/qwen_outliers_drift.txt $R/gpurun_out/sft_full_drift.txt $R/gpurun_out/sft_navdp_drift.txt $R/gpurun_out/s1_b64_distribution.txt
+timeout 2400 python -m pytest tests -q -m gpu > $R/gpurun_out/${TAG}_pytest_gpu.log 2>&1
+for f in qwen_full_drift qwen_outliers_drift sft_full_drift sft_navdp_drift s1_b64_distribution; do cp $R/gpurun_out/$f.txt $R/gpurun_out/${TAG}_$f.txt 2>/dev/null; done
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/${TAG}_smoke.log 2>&1
 timeout 900 python bench.py > $R/gpurun_out/${TAG}_bench_n1_dual_b64.json 2> $R/gpurun_out/${TAG}_bench.err
 if [ -z "$QUICK" ]; then
@@ -19,7 +19,9 @@ timeout 600 python bench.py --workload navdp_s1 > $R/gpurun_out/${TAG}_bench_nav
 timeout 600 python bench.py --workload unet1d_s1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unet1d_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_sft.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline --no-prefetch > $R/gpurun_out/${TAG}_bench_sft_noprefetch.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --no-s1-merge-images > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_merge_images.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --s2-every 2 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_s2every2.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-frag-weights > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_frag_weights.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-row-chain > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_row_chain.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --workload host_stub --gpus 8 --steps 20 > $R/gpurun_out/${TAG}_bench_host_stub_8ranks.json 2>> $R/gpurun_out/${TAG}_bench.err
 fi
 timeout 300 python tools/step_breakdown.py > $R/gpurun_out/${TAG}_step_breakdown.log 2>&1
@@ -54,6 +56,9 @@ if [ -x tools/native/chain_sweep ]; then
   timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_phase_mix.txt spec > $R/gpurun_out/${TAG}_native_phase_mix.log 2>&1
   timeout 20 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
   timeout 20 tools/native/attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_attn.log 2>&1
+  timeout 120 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r05_w4p.txt > $R/gpurun_out/${TAG}_native_w4p.log 2>&1
+  timeout 60 tools/native/dit_attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_dit_attn.log 2>&1
+  timeout 60 tools/native/rowchain_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_rowchain.log 2>&1
 fi
 tail -3 $R/gpurun_out/${TAG}_pytest_gpu.log
 tail -2 $R/gpurun_out/${TAG}_smoke.log

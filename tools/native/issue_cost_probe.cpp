@@ -91,13 +91,14 @@ __device__ __forceinline__ void mem_ops(std::integer_sequence<int, M...>, u32x4*
     (mem_op<NDMA, NVEC, NDS, I, M>(ring, frag, src, goff, lds_wave, lds_lane), ...);
 }
 
-template <int NDMA, int NVEC, int NDS>
-__global__ __launch_bounds__(256, 1) void probe_kernel(const char* __restrict__ src, unsigned window_mask, int iters, float* __restrict__ out, long long* __restrict__ cyc) {
+template <int NDMA, int NVEC, int NDS, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void probe_kernel(const char* __restrict__ src, unsigned window_mask, int iters, float* __restrict__ out, long long* __restrict__ cyc) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    f32x16 acc[8];
+    constexpr int NACC = OCC == 1 ? 8 : 4;   // (two workgroups per CU: 256 registers per wave)
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     bf16x8 a, b;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* __restrict__ 
         // memory instruction m goes behind MFMA number (m + 1) * NMFMA / (NMEM + 1): an even spread, the interleave of the hand-written streams
         for_seq<NMFMA>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 7], 0, 0, 0);
+            acc[i & (NACC - 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & (NACC - 1)], 0, 0, 0);
             mem_ops<NDMA, NVEC, NDS, i>(std::make_integer_sequence<int, NMEM>{}, ring, frag, src, pos + lane_off, lds_wave, wave * 16384u + lane * 16u);
         });
         // one stage of requests stays in flight (counted wait, as the tiles do); LDS reads are retired
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* __restrict__ 
     const long long t1 = __builtin_readcyclecounter();
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][lane & 15];
+    for (int i = 0; i < NACC; ++i) s += acc[i][lane & 15];
     if constexpr (NVEC > 0) {
 #pragma unroll
         for (int i = 0; i < NVEC; ++i) s += (float)(ring[i][0] & 1u);
@@ -140,28 +141,32 @@ __global__ __launch_bounds__(256, 1) void probe_kernel(const char* __restrict__ 
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int NDMA, int NVEC, int NDS>
-static void run(const char* label, const char* src, unsigned window_mask, float* out, long long* cyc, int ncu) {
-    auto kern = probe_kernel<NDMA, NVEC, NDS>;
-    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+template <int NDMA, int NVEC, int NDS, int OCC = 1>
+static void run(const char* label, const char* src, unsigned window_mask, float* out, long long* cyc, int ncu_in) {
+    auto kern = probe_kernel<NDMA, NVEC, NDS, OCC>;
+    const int ncu = ncu_in * OCC;
+    const int LDSB = OCC == 1 ? 96 * 1024 : 64 * 1024;
+    HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));
     const int iters = 2000;
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0));
     HIP_OK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, dim3(ncu), dim3(256), 96 * 1024, 0, src, window_mask, 200, out, cyc);
+    hipLaunchKernelGGL(kern, dim3(ncu), dim3(256), LDSB, 0, src, window_mask, 200, out, cyc);
     HIP_OK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(kern, dim3(ncu), dim3(256), 96 * 1024, 0, src, window_mask, iters, out, cyc);
+    hipLaunchKernelGGL(kern, dim3(ncu), dim3(256), LDSB, 0, src, window_mask, iters, out, cyc);
     HIP_OK(hipEventRecord(e1, 0));
     HIP_OK(hipEventSynchronize(e1));
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     const double us_stage = ms * 1e3 / iters;
     // MFMA cycles of a stage at the clock the run sustained are unknown from the host: report time and the ratio to the bare-MFMA stage
-    static double bare = 0;
+    static double bare_[3] = {0, 0, 0};
+    double& bare = bare_[OCC];
     if (NDMA + NVEC + NDS == 0) bare = us_stage;
-    const double flops = 64.0 * 32768.0 * 4 * ncu;   // per stage, all SIMDs
+    const double flops = 64.0 * 32768.0 * 4 * ncu;   // (OCC workgroups per CU share its SIMDs: per-workgroup stage time doubles at the same rate)   // per stage, all SIMDs
     printf("%-58s %7.3f us / stage   x%5.3f of bare MFMAs   %7.1f TF/s   +%6.0f MFMA-cycles-equivalent\n", label, us_stage, bare > 0 ? us_stage / bare : 1.0,
            flops / us_stage * 1e-6, bare > 0 ? (us_stage / bare - 1.0) * 2048.0 : 0.0);
+    fflush(stdout);
 }
 
 int main() {
@@ -173,9 +178,9 @@ int main() {
     HIP_OK(hipMalloc(&src, (size_t)window + (1u << 20)));
     HIP_OK(hipMemset(src, 1, (size_t)window + (1u << 20)));
     float* out;
-    HIP_OK(hipMalloc(&out, (size_t)ncu * 256 * 4));
+    HIP_OK(hipMalloc(&out, (size_t)ncu * 2 * 256 * 4));
     long long* cyc;
-    HIP_OK(hipMalloc(&cyc, (size_t)ncu * 8));
+    HIP_OK(hipMalloc(&cyc, (size_t)ncu * 2 * 8));
     printf("# %s, %d CUs; stage = 64 x v_mfma_f32_32x32x16_bf16 per wave, one wave per SIMD, memory instructions spread evenly between them\n", prop.name, ncu);
     const unsigned mask = window - 1;
     run<0, 0, 0>("bare MFMAs", src, mask, out, cyc, ncu);
@@ -189,5 +194,13 @@ int main() {
     run<8, 16, 16>("pre-shuffled B: 8 pieces + 16 vector loads + 16 reads", src, mask, out, cyc, ncu);
     run<8, 8, 16>("(if the column pair could share B: 8 + 8 + 16)", src, mask, out, cyc, ncu);
     run<0, 24, 0>("(no LDS at all: 24 vector loads)", src, mask, out, cyc, ncu);
+    // the row-chain kernel's stage mix (dit_rowchain.hip: 32 rows per wave, W streamed through an LDS ring): per 64 MFMAs a wave issues 16 LDS-DMA
+    // pieces and 64 fragment reads, two workgroups per CU; against W fragments fetched straight from global memory (64 vector loads, no LDS)
+    printf("# two workgroups per CU (two waves per SIMD), the row-chain geometry:\n");
+    run<0, 0, 0, 2>("bare MFMAs, 2 waves / SIMD", src, mask, out, cyc, ncu);
+    run<0, 0, 32, 2>("32 fragment reads", src, mask, out, cyc, ncu);
+    run<0, 0, 48, 2>("48 fragment reads (the row chain issues 64 + 16 LDS-DMA pieces per 64 MFMAs)", src, mask, out, cyc, ncu);
+    run<0, 32, 0, 2>("W fragments from global: 32 vector loads (half of the 64 the kernel would need; register budget of the probe)", src, mask, out, cyc, ncu);
+    run<0, 16, 0, 2>("16 vector loads", src, mask, out, cyc, ncu);
     return 0;
 }
