@@ -299,8 +299,10 @@ def test_bench_accounting_is_consistent():
     for wl in ("n1_dual", "navdp_s1"):
         t = bench.pmc_traffic(wl, "gemm_bf16_pp_kernel<256,256,4>")          # n1_dual entries are keyed by the kernel the line names
         assert t and t["bytes_per_launch"] > 0 and (bench.ROOT / t["source"].split(" ")[0]).exists()
-    w4 = bench.pmc_traffic("n1_dual", "gemm_bf16_w4_kernel<256,1>")
-    assert w4 and w4["bytes_per_launch"] > 0 and bench.pmc_traffic("n1_dual", "no such kernel") is None
+    for k in ("gemm_bf16_w4_kernel<256,1>", "gemm_bf16_w4p_kernel<256>"):
+        w4 = bench.pmc_traffic("n1_dual", k)
+        assert w4 and w4["bytes_per_launch"] > 0 and (bench.ROOT / w4["source"].split(" ")[0]).exists()
+    assert bench.pmc_traffic("n1_dual", "no such kernel") is None
 
 
 def test_pin_host_threads_partitions_the_cores():
