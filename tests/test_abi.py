@@ -30,6 +30,14 @@ def test_library_exports_every_symbol(built_lib):
     assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 5
 
 
+def test_graft_entry_build_passes_on_the_current_abi(built_lib):
+    """__graft_entry__.build() is what the driver runs every round: it must accept the library the tree builds (an ABI bump once left a pinned
+    version number behind in it)."""
+    import __graft_entry__ as g
+
+    g.build()
+
+
 def test_struct_sizes_match_header(built_lib):
     """ctypes mirrors must have exactly the compiled C layout (ina_struct_size reports sizeof of each argument struct)."""
     from internnav_amd import _lib
