@@ -51,6 +51,24 @@ def test_decoder_layer_gemms(select, rows, plain, shared):
         assert got == want, f"rows {rows}, force_cfg {mode}"
 
 
+@pytest.mark.parametrize("rows", [6440, 5520, 3680, 2760])
+def test_decoder_layer_gemms_with_fragment_ordered_weights(select, rows):
+    """Round 5: with the fragment-ordered copy of W at hand (ina_gemm_args.Wp) the four-wave tile takes its B fragments straight from global
+    memory (config 40) wherever 39 would run, and instead of the ping-pong tile (18) on the K = 18944 down projection; a choice of the
+    192-row tile (21) or of the 16-wave tile (33: o projection) is not touched (profiles/r05u_native_w4p.log). Bit-equal either way."""
+    WP = dict(Wp=0x3000)
+    for mode in (0, -1):
+        base = (select(rows, QKV, H, force_cfg=mode), select(rows, H, H, force_cfg=mode, **RES),
+                select(rows, 2 * I, H, force_cfg=mode, **GLU), select(rows, H, I, force_cfg=mode, **RES))
+        got = (select(rows, QKV, H, force_cfg=mode, **WP), select(rows, H, H, force_cfg=mode, **RES, **WP),
+               select(rows, 2 * I, H, force_cfg=mode, **GLU, **WP), select(rows, H, I, force_cfg=mode, **RES, **WP))
+        want = tuple(40 if (b == 39 or (b == 18 and i == 3)) else b for i, b in enumerate(base))
+        assert got == want, f"rows {rows}, force_cfg {mode}: {base} -> {got}"
+    assert select(7, QKV, H, **WP) == 32 and select(rows, QKV, H, force_cfg=18, **WP) == 18      # single-token passes and forced tiles ignore the copy
+    err = select(rows, QKV, H, force_cfg=40)
+    assert err[0] == "error" and "fragment-ordered copy" in err[1]
+
+
 @pytest.mark.parametrize("rows,plain,shared", [
     (21952, (18, 33, 18, 33), (18, 33, 18, 33)),      # 7 prompts x 4 frames x 784 patches
     (18816, (18, 21, 18, 21), (18, 33, 18, 33)),
