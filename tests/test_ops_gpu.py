@@ -473,6 +473,24 @@ def test_gemm_preshuffle_layout_and_auto_selection(ops):
     assert torch.equal(ops.linear(small, wc), ops.linear(small, wc, w_frag=wf))     # any other tile ignores the copy
 
 
+@pytest.mark.parametrize("M,N,K,glu", [(3680, 37888, 3584, True), (8192, 16384, 3584, False), (2760, 3584, 18944, False)])
+def test_gemm_frag_weights_repeatable_at_prefill_size(ops, M, N, K, glu):
+    """config 40 at the sizes where its loads miss in L2 (hundreds of column tiles, nine rounds of workgroups): 25 launches, every one bit-equal
+    to config 39. Regression test of an intermittent failure of the first version: reloads still in flight behind the loop landed in registers
+    the epilogue already used - whole tiles wrong, only when the late loads had missed in L2, never at the small shapes of the test above."""
+    g = torch.Generator().manual_seed(N)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    wf = ops.gemm_preshuffle(w)
+    kw = dict(act="silu", glu=True) if glu else {}
+    ref = ops.linear(x, w, force_cfg=39, **kw)
+    out = torch.empty_like(ref)
+    for rep in range(25):
+        out.zero_()
+        ops.linear(x, w, force_cfg=40, w_frag=wf, out=out, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), f"launch {rep}: {int((out != ref).sum())} elements differ"
+
+
 def test_gemm_four_wave_tile_rejects_unaligned_rows(ops):
     x, w = torch.zeros(300, 64, dtype=torch.bfloat16, device=_dev()), torch.zeros(260, 64, dtype=torch.bfloat16, device=_dev())
     with pytest.raises(RuntimeError, match="38 / 39"):
