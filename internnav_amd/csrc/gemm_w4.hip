@@ -237,6 +237,14 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// positions (0 .. 6) of the A read and of the DMA piece inside a group of 8 MFMAs; the waits only assume that both precede the B reload at 7.
+// Six other placements measure within +-1 % of this one on every shape (tools/native/build_w4p_variants.sh, profiles/r05z_native_w4p_positions.log).
+#ifndef W4P_RD_POS
+#define W4P_RD_POS 3
+#endif
+#ifndef W4P_DMA_POS
+#define W4P_DMA_POS 5
+#endif
 template <int BM>
 __global__ __launch_bounds__(256) void gemm_bf16_w4p_kernel(GemmArgs p) {
     constexpr int BN = 256;
@@ -315,8 +323,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4p_kernel(GemmArgs p) {
             // (one wait per fragment PAIR instead - vmcnt(14 + 8 P) / vmcnt(14 + (6 - j) P + j D) at even j - measures the same: r05v)
             if constexpr (i == 0) wait_vm<(SET == 0) ? 15 + 8 * P : 15 + (7 - j) * P + j * D>();
             mfma_tied(acc[j >> 2][i][j & 3], fb[SET][j], fa[SET][i]);
-            if constexpr (i == 3) lds_read16<j * 2048>(fa[SET ^ 1][j], aa);
-            if constexpr (DMA && i == 5) dma_one(IC<j>{}, la, k0);
+            if constexpr (i == W4P_RD_POS) lds_read16<j * 2048>(fa[SET ^ 1][j], aa);
+            if constexpr (DMA && i == W4P_DMA_POS) dma_one(IC<j>{}, la, k0);
             if constexpr (i == 7) gload16_saddr(fb[SET][j], bb, boff[j]);
         });
     };
