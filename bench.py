@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--decode-cfg", type=int, default=0, help="n1_dual: force_cfg of the decode passes' weight-streaming GEMMs (60 thin, 61 four-wave uncapped)")
     ap.add_argument("--no-chain-stats", action="store_true", help="n1_dual: the DiT attention stage computes its LayerNorm statistics itself (round-4 kernel)")
     ap.add_argument("--no-frag-weights", action="store_true", help="n1_dual: prefill GEMMs without the fragment-ordered weight copies (tile config 39 / 18 instead of 40)")
+    ap.add_argument("--decode-fused", action="store_true", help="n1_dual: single-token passes on the column-owner kernels with the fused input norm (round-4 default) instead of the split-K kernel pair")
+    ap.add_argument("--split-rows-max", type=int, default=0, help="n1_dual: rows up to which --decode-cfg 31 applies (64: the latent-query pass too)")
     ap.add_argument("--nt-decode", action="store_true", help="n1_dual: non-temporal weight loads in the decode passes' GEMMs (experiment)")
     ap.add_argument("--thin-decode", action="store_true",
                     help="n1_dual: the weight-streaming GEMMs of the single-token decode passes as 4-wave / <= 96-register builds that fit on a CU beside "
@@ -115,7 +117,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, no_frag_weights=False, rest=[])
+                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, no_frag_weights=False, split_rows_max=0, decode_fused=False, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -395,10 +397,14 @@ class N1Dual:
             self.model.qwen.frag_weights = False
         if getattr(a, "nt_decode", False):
             self.model.qwen.nt_decode = True
+        if getattr(a, "decode_fused", False):
+            self.model.qwen.thin_decode = False
         if getattr(a, "thin_decode", False):
             self.model.qwen.thin_decode = True
         if getattr(a, "decode_cfg", 0):
             self.model.qwen.thin_decode = int(a.decode_cfg)
+        if getattr(a, "split_rows_max", 0):
+            self.model.qwen.split_rows_max = int(a.split_rows_max)
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
         lim = qcfg["image_token_id"] - 16
         ids = torch.randint(0, lim, (B, self.S), device=dev, generator=g)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 5
+#define INA_ABI_VERSION 6
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0
@@ -87,6 +87,13 @@ typedef struct ina_gemm_args {
     const float* norm_gamma; /* f32 [K] or NULL (no fused norm; A is bf16) */
     float norm_eps;
     int32_t a_dtype;        /* dtype of A when norm_gamma is set: INA_BF16 | INA_F32 */
+    /* the NEXT GEMM's pre-normed operand out of this GEMM's epilogue (split-K kernel pair, force_cfg 31, no GLU, N <= 4096): after C is stored,
+     * post_out[m, :] = bf16(C_f32[m, :] * rsqrt(mean(C_f32[m, :]^2) + post_eps) * post_gamma) - the RMSNorm launch between two GEMMs of a
+     * single-token pass disappears (o projection -> post-attention norm, down projection -> the next layer's input norm) */
+    const float* post_gamma; /* f32 [N] or NULL */
+    void* post_out;          /* bf16 [M, N], row stride post_ld */
+    float post_eps;
+    int32_t post_ld;
     const void* Wp;         /* NULL, or the same W in MFMA fragment order (ina_gemm_preshuffle; N % 16 == 0, K % 32 == 0): tile config 40 takes its
                              * B fragments from it straight into registers (selected where cfg 39 would run; bit-equal results) */
 } ina_gemm_args;

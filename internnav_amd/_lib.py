@@ -25,6 +25,7 @@ class GemmArgs(C.Structure):
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
         ("force_cfg", c_int32), ("group_m", c_int32),
         ("norm_gamma", c_void_p), ("norm_eps", c_float), ("a_dtype", c_int32),
+        ("post_gamma", c_void_p), ("post_out", c_void_p), ("post_eps", c_float), ("post_ld", c_int32),
         ("Wp", c_void_p),
     ]
 
@@ -337,7 +338,7 @@ SYMBOLS = {
 _lib = None
 # the struct layouts above mirror include/internnav_amd.h at THIS version of the C-ABI (INA_ABI_VERSION there): lib() refuses a shared object
 # built from another version - a stale .so would read pointers at the wrong offsets
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class EngineError(RuntimeError):

@@ -184,6 +184,7 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
     // skinny M: HBM-bound weight streaming with split-K (gemm_skinny.hip) instead of an under-filled tile grid
     if (p.norm_gamma) {
+        INA_REQUIRE(!p.post_gamma, "gemm: post_gamma is not combined with the fused input norm");
         INA_REQUIRE(p.M <= 16 && p.batch <= 1 && p.K % 8 == 0 && p.K <= 4096 && p.N >= 256,
                     "gemm: the fused input RMSNorm is built for the decode passes (M <= 16 rows, K <= 4096, one batch): M=%d K=%d N=%d batch=%d", p.M, p.K, p.N, p.batch);
         INA_REQUIRE(p.a_dtype == INA_DT_BF16 || p.a_dtype == INA_DT_F32, "gemm: a_dtype must be bf16 or f32 with norm_gamma");
@@ -193,16 +194,23 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     }
     INA_REQUIRE(p.force_cfg != 30, "gemm: kernel 30 (fused input RMSNorm) is selected by norm_gamma, not by force_cfg");
     if (p.force_cfg == 60 || p.force_cfg == 61) {      // thin weight-streaming build (4-wave workgroups, <= 96 registers): the decode passes beside System-1's row chain
-        INA_REQUIRE(p.M <= 16 && p.batch == 1 && p.N >= 256, "gemm: the thin weight-streaming kernels are built for M <= 16, batch 1 (M=%d N=%d)", p.M, p.N);
+        INA_REQUIRE(p.M <= 16 && p.batch == 1 && p.N >= 256 && !p.post_gamma, "gemm: the thin weight-streaming kernels are built for M <= 16, batch 1, no post_gamma (M=%d N=%d)", p.M, p.N);
         kernel = p.force_cfg;
         return 0;
     }
-    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) { kernel = 32; return 0; }
+    if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) {
+        INA_REQUIRE(!p.post_gamma, "gemm: post_gamma needs force_cfg = 31 (the split-K kernel pair)");
+        kernel = 32;
+        return 0;
+    }
     if (p.force_cfg == 31 || p.force_cfg == 32) {
         INA_REQUIRE(p.M <= 64 && p.batch == 1, "gemm: skinny kernels need M <= 64, batch 1 (M=%d)", p.M);
+        INA_REQUIRE(!p.post_gamma || (p.force_cfg == 31 && !p.glu && p.N <= 4096 && p.N % 4 == 0 && p.post_out && p.post_ld % 4 == 0 && ((uintptr_t)p.post_out % 8) == 0),
+                    "gemm: post_gamma (the next GEMM's pre-normed operand) is written by the epilogue launch of the split-K kernel pair only (force_cfg 31, no GLU, N <= 4096; N=%d)", p.N);
         kernel = p.force_cfg;
         return 0;
     }
+    INA_REQUIRE(!p.post_gamma, "gemm: post_gamma needs force_cfg = 31 (the split-K kernel pair)");
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     int cfg = p.force_cfg;
     if (cfg <= 0) {

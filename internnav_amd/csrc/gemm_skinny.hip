@@ -156,6 +156,64 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue(GemmArgs p, const fl
     }
 }
 
+// the same epilogue as ONE workgroup per output row (no GLU, N <= 4096), which then also holds the whole fp32 row: post_gamma -> the RMSNorm of the
+// row, i.e. the NEXT GEMM's bf16 operand, leaves with it (ina_gemm_args.post_gamma / post_out) - in a single-token decoder pass the norm launch
+// between the o projection and gate|up, and between the down projection and the next layer's q|k|v, disappears
+__global__ __launch_bounds__(1024) void gemm_skinny_epilogue_rows(GemmArgs p, const float* __restrict__ part, int splits) {
+    // one thread per 4 output columns (N <= 4096 -> at most 1024 threads): its `splits` partial loads are independent and in flight together
+    __shared__ float red[16];
+    const int m = blockIdx.x, tid = threadIdx.x, n4 = p.N >> 2, n = tid * 4;
+    const bool live = tid < n4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float sq = 0.f;
+    if (live) {
+        const float rs = p.rowscale ? p.rowscale[m / p.rowscale_div] : 1.0f;
+        for (int s = 0; s < splits; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(part + ((size_t)s * p.M + m) * p.N + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += a[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = v[r];
+            if (p.bias) x += p.bias[n + r];
+            x = ina_act(x, p.act);
+            if (p.colscale) x *= p.colscale[n + r];
+            v[r] = x * rs;
+        }
+        if (p.R) {
+            const size_t ro = (size_t)m * p.ldr + n;
+            if (p.res_dtype == INA_DT_BF16) {
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.R) + ro);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+            } else {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+            }
+        }
+        const size_t co = (size_t)m * p.ldc + n;
+        if (p.out_dtype == INA_DT_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sq = fmaf(v[r], v[r], sq);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    float tot = 0.f;
+    const int nwv = (blockDim.x + 63) >> 6;
+    for (int w = 0; w < nwv; ++w) tot += red[w];
+    const float rn = rsqrtf(tot / (float)p.N + p.post_eps);
+    if (live) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.post_gamma + n);
+        bf16* __restrict__ H = reinterpret_cast<bf16*>(p.post_out) + (size_t)m * p.post_ld;
+        *reinterpret_cast<bf16x4*>(H + n) = bf16x4{(bf16)(v[0] * rn * gm[0]), (bf16)(v[1] * rn * gm[1]), (bf16)(v[2] * rn * gm[2]), (bf16)(v[3] * rn * gm[3])};
+    }
+}
+
 // ---- column-owner variant: a group of NW waves owns NT16 x 16 output columns for ALL of K (a workgroup holds NC such groups); the
 // group's waves take interleaved 128-wide K steps, keep a DEPTH-deep register ring of loads in flight, reduce their accumulators
 // through LDS (NW > 1) and apply the epilogue in the same kernel: no partial workspace, no second launch (a decode pass of the
@@ -537,6 +595,11 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
         case 2: hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 0, stream, p, part, kslice); break;
         case 3: hipLaunchKernelGGL(gemm_skinny_kernel<3>, grid, dim3(256), 0, stream, p, part, kslice); break;
         default: hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, stream, p, part, kslice); break;
+    }
+    if (p.post_gamma) {                                    // (ina_plan_gemm: no GLU, N <= 4096)
+        hipLaunchKernelGGL(gemm_skinny_epilogue_rows, dim3(p.M), dim3(((p.N / 4 + 63) / 64) * 64), 0, stream, p, part, splits);
+        INA_HIP_CHECK(hipGetLastError());
+        return 0;
     }
     const long total = (long)p.M * (p.N / 4);
     const int eb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -61,9 +61,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
            rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
-           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None, post_norm=None) -> torch.Tensor:
     """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
 
+    post_norm=(gamma f32 [N], eps, h bf16 [M, N]) with force_cfg=31 (split-K kernel pair, M <= 64): h = bf16(rmsnorm(out_f32) * gamma), the next
+    GEMM's operand, written by this GEMM's epilogue launch.
     w_frag: the same weight in MFMA fragment order (gemm_preshuffle(w)): the wide no-residual GEMMs that would run tile config 39 then take
     their B fragments from it straight into registers (config 40, bit-equal); ignored by every other tile.
 
@@ -113,6 +115,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.rowscale_div = rowscale_div
     a.force_cfg = force_cfg if force_cfg else _AUTO_CFG
     a.group_m = group_m
+    if post_norm is not None:
+        pg, pe, ph = post_norm
+        assert not batched and pg.dtype == torch.float32 and pg.is_contiguous() and pg.numel() == n_out
+        assert ph.dtype == torch.bfloat16 and ph.shape == (M, n_out) and ph.stride(1) == 1
+        a.post_gamma, a.post_out, a.post_eps, a.post_ld = pg.data_ptr(), ph.data_ptr(), float(pe), ph.stride(0)
     if w_frag is not None:
         assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and w_frag.numel() == N * K and N % 16 == 0 and K % 32 == 0
         a.Wp = w_frag.data_ptr()

@@ -129,7 +129,12 @@ class QwenVLEngine:
         self.split_serial = False     # True: the two half micro-batches of split_prefill on ONE stream (per-launch event timing, bench.py)
         self._side = None
         self.nt_decode = False     # bench / experiments: non-temporal weight loads in the single-token passes' GEMMs (gemm_skinny.hip SK_NT_FLAG)
-        self.thin_decode = False   # bench / experiments: thin weight-streaming builds in the single-token passes (see _layers)
+        self.split_rows_max = 16   # rows up to which cfg 31 is used (64: the latent-query pass too)
+        # the GEMMs of the single-token passes: 31 (default since round 5) = the split-K kernel pair - many short 256-thread workgroups that get into the
+        # gaps System-1's workgroups leave on the CUs, where the 512-thread column-owner workgroups wait - whose row-owning epilogue launch hands the
+        # next GEMM its pre-normed operand (ina_gemm_args.post_gamma): 311.0 -> 315.3-316.0 policy steps/s (profiles/r05D_*); False / 0 = the column-owner
+        # kernels with the fused input norm (round 4; 4 % faster ALONE: 4.0 vs 4.2 ms per pass); 60 / 61 = their thin 4-wave builds (experiments)
+        self.thin_decode = 31
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
         Ip = (I + 63) // 64 * 64   # SwiGLU width padded with zero rows/cols: GLU tiles need N % 32 == 0, the LDS-DMA GEMM K % 64 == 0
@@ -312,27 +317,38 @@ class QwenVLEngine:
         fused_norm = rows <= 16 and self.fuse_decode_norm and self.tap is None
         # thin_decode: the four weight-streaming GEMMs of a single-token pass as 4-wave / <= 96-register builds (force_cfg 60) that fit on a CU
         # beside System-1's row-chain workgroups; same arithmetic (a column group of 4 waves, same K order per wave)
-        cfg = (self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (fused_norm and self.thin_decode) else 0
+        tcfg = (self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if self.thin_decode else 0
+        cfg = tcfg if (tcfg and self.tap is None and rows <= (self.split_rows_max if tcfg == 31 else 16)) else 0
+        if cfg not in (0, 60, 61):
+            fused_norm = False          # (the fused input norm exists in the column-owner kernels only: other forced kernels take the separate norm launch)
         gm = 7 if (rows <= 16 and self.nt_decode) else 0     # SK_NT_FLAG: non-temporal weight stream in the column-owner GEMMs
+        # split_decode (cfg 31): the four GEMMs of a single-token pass on the split-K kernel pair (many short 256-thread workgroups that get into
+        # the gaps System-1's workgroups leave, where the 512-thread column-owner workgroups wait), whose epilogue launch owns whole output rows
+        # and hands the NEXT GEMM its pre-normed operand (post_norm): no norm launch inside the pass except the first layer's
+        chain31 = cfg == 31
         for li, L in enumerate(self.layers):
             src = x_in if li == 0 else x
             wf = (lambda k, L=L: L.get(k)) if (self.frag_weights and rows > 64) else (lambda k: None)
             if fused_norm:
                 ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6), force_cfg=cfg, group_m=gm)
             else:
-                ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"))
+                if not (chain31 and li > 0):                 # (chain31: h = norm1(x) came out of the previous layer's down projection)
+                    ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
+                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"), force_cfg=cfg)
             # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
             ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
             ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
-            ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg, group_m=gm)
+            ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg, group_m=gm, post_norm=(L["n2"], 1e-6, h) if chain31 else None)
             if fused_norm:
                 ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg, group_m=gm)
             else:
-                ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"))
-            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm, w_frag=wf("down_wf"))
+                if not chain31:
+                    ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
+                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"), force_cfg=cfg)
+            nxt = self.layers[li + 1]["n1"] if (chain31 and li + 1 < len(self.layers)) else None
+            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm, w_frag=wf("down_wf"),
+                       post_norm=(nxt, 1e-6, h) if nxt is not None else None)
             if self.tap is not None:
                 self.tap("llm", li, x)
 

@@ -564,6 +564,38 @@ def test_gemm_skinny_fused_input_rmsnorm(ops, M, N, K, glu, xdt):
         ops.linear(torch.zeros(17, K, device=_dev()), w, prenorm=(gamma, 1e-6))      # built for <= 16 rows
 
 
+@pytest.mark.parametrize("M,N,K,res", [(7, 3584, 3584, "f32"), (7, 3584, 18944, "f32"), (35, 3584, 3584, "f32"), (5, 1024, 512, None), (1, 4096, 256, "bf16")])
+def test_gemm_split_k_epilogue_hands_over_the_next_prenorm(ops, M, N, K, res):
+    """split-K kernel pair (force_cfg 31) with post_norm: its epilogue launch owns whole output rows and writes bf16(rmsnorm(out) * gamma) beside the
+    output - the operand of the next GEMM of a single-token decoder pass. The output itself is bit-equal to the plain pair, the handed-over row
+    equals the norm launch it replaces up to bf16 flips where the row statistic's summation order rounds differently."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
+    gamma = (1.0 + 0.1 * torch.randn(N, generator=g)).to(_dev())
+    bias = torch.randn(N, generator=g).to(_dev())
+    kw = dict(bias=bias)
+    odt = torch.bfloat16
+    if res == "f32":
+        kw["residual"], odt = torch.randn(M, N, generator=g).to(_dev()) * 3.0, torch.float32
+    elif res == "bf16":
+        kw["residual"] = _rand((M, N), g)
+    plain = ops.linear(x, w, force_cfg=31, out_dtype=odt, **kw)
+    hw = torch.full((M, N + 8), 7.0, dtype=torch.bfloat16, device=_dev())
+    h = hw[:, :N]
+    out = ops.linear(x, w, force_cfg=31, out_dtype=odt, post_norm=(gamma, 1e-6, h), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain)
+    assert float(hw[:, N:].min()) == 7.0, "columns beyond the row were written"
+    y = x.float() @ w.float().t() + bias + (kw["residual"].float() if res else 0.0)
+    _close(h, y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma, rtol=1.0 / 128, atol=2e-2)
+    if res == "f32":                                                   # the launch it replaces reads the same fp32 row
+        two = ops.norm(plain, gamma, None, eps=1e-6, rms=True)
+        d = (h.float() - two.float()).abs()
+        assert d.max().item() <= 2.0 ** -6 * max(1.0, two.float().abs().max().item()) and (d > 0).float().mean().item() < 0.02
+    with pytest.raises(RuntimeError, match="post_gamma"):
+        ops.linear(x, w, post_norm=(gamma, 1e-6, h), out_dtype=odt, **kw)      # any other kernel
+
+
 DECODE = [
     # B, Lq, Lk, H, Hkv, D, causal
     (7, 1, 927, 28, 4, 128, True), (7, 5, 932, 28, 4, 128, True), (3, 1, 300, 28, 4, 128, False), (2, 2, 513, 8, 8, 64, True),

@@ -89,6 +89,32 @@ def test_prefill_logits_greedy_tokens_and_latents(setup):
         assert d3.mean() < 1e-2 * refl.pow(2).mean().sqrt()
 
 
+def test_single_token_pass_variants_agree(setup):
+    """the GEMM paths of the single-token passes - split-K kernel pair with the norm handed over by its row-owning epilogue (31, default),
+    column-owner kernels with the fused input norm (False, round 4), the same with separate norm launches - give the same greedy tokens and
+    logits that differ by bf16 summation-order noise only."""
+    gold, cfg, inp, eng = setup
+    pv = inp["pixel_values"].to(DEV, torch.bfloat16)
+    keep = (eng.thin_decode, eng.fuse_decode_norm)
+    res = {}
+    try:
+        for name, td, fuse in (("split_k_post_norm", 31, True), ("column_owner_fused_norm", False, True), ("column_owner_norm_launches", False, False)):
+            eng.thin_decode, eng.fuse_decode_norm = td, fuse
+            state = eng.prefill(inp["input_ids"], pv, inp["grid_thw"])
+            toks = eng.decode(state, 4)
+            lat = eng.latents(state, toks[:, -1:].contiguous())
+            res[name] = (toks.cpu(), eng.logits[: state["B"]].float().cpu().clone(), lat.float().cpu())
+    finally:
+        eng.thin_decode, eng.fuse_decode_norm = keep
+    base = res["column_owner_norm_launches"]
+    scale = base[1].std().item()
+    for name, (toks, logits, lat) in res.items():
+        assert torch.equal(toks, base[0]), (name, toks.tolist(), base[0].tolist())
+        d = (logits - base[1]).abs()
+        assert d.mean().item() < 2e-3 * scale and d.max().item() < 3e-2 * scale, (name, d.mean().item(), d.max().item(), scale)
+        assert (lat - base[2]).abs().mean().item() < 4e-3 * base[2].pow(2).mean().sqrt().item(), name
+
+
 def test_generate_surface(setup):
     gold, cfg, inp, eng = setup
     seqs = eng.generate(inp["input_ids"], inp["pixel_values"].to(DEV, torch.bfloat16), inp["grid_thw"], max_new_tokens=3)
