@@ -580,6 +580,7 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
     const int tiles = (p.N + SK_BN - 1) / SK_BN;
     int splits = 1;
     const int ksteps = (p.K + SK_BK - 1) / SK_BK;
+    // (a launch aims at >= 1024 workgroups; inside the policy step 512 / 2048 / 4096 measure 314.0 / 316.3 / 316.4 vs 317.3 policy steps/s, profiles/r05F_*)
     while (tiles * splits < 1024 && splits * 2 <= ksteps && splits < 32) splits *= 2;
     const int kslice = ((ksteps + splits - 1) / splits) * SK_BK;
     splits = (p.K + kslice - 1) / kslice;

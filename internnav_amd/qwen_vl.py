@@ -334,7 +334,7 @@ class QwenVLEngine:
             else:
                 if not (chain31 and li > 0):                 # (chain31: h = norm1(x) came out of the previous layer's down projection)
                     ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"), force_cfg=cfg)
+                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"), force_cfg=cfg, group_m=gm)
             # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
             ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
@@ -345,7 +345,7 @@ class QwenVLEngine:
             else:
                 if not chain31:
                     ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"), force_cfg=cfg)
+                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"), force_cfg=cfg, group_m=gm)
             nxt = self.layers[li + 1]["n1"] if (chain31 and li + 1 < len(self.layers)) else None
             ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm, w_frag=wf("down_wf"),
                        post_norm=(nxt, 1e-6, h) if nxt is not None else None)
