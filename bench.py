@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--no-chain-stats", action="store_true", help="n1_dual: the DiT attention stage computes its LayerNorm statistics itself (round-4 kernel)")
     ap.add_argument("--no-frag-weights", action="store_true", help="n1_dual: prefill GEMMs without the fragment-ordered weight copies (tile config 39 / 18 instead of 40)")
     ap.add_argument("--decode-fused", action="store_true", help="n1_dual: single-token passes on the column-owner kernels with the fused input norm (round-4 default) instead of the split-K kernel pair")
+    ap.add_argument("--decode-attn-kernel", type=int, default=0, help="n1_dual: ina_attn_args.kernel of the single-token passes (1 = split + combine launches, 3 = 4-wave one-launch kernel)")
+    ap.add_argument("--lm-head-cfg", type=int, default=-2, help="n1_dual: force_cfg of the lm_head GEMM (0 = column-owner kernel; default: as the single-token passes)")
     ap.add_argument("--split-rows-max", type=int, default=0, help="n1_dual: rows up to which --decode-cfg 31 applies (64: the latent-query pass too)")
     ap.add_argument("--nt-decode", action="store_true", help="n1_dual: non-temporal weight loads in the decode passes' GEMMs (experiment)")
     ap.add_argument("--thin-decode", action="store_true",
@@ -117,7 +119,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, no_frag_weights=False, split_rows_max=0, decode_fused=False, rest=[])
+                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, no_frag_weights=False, split_rows_max=0, decode_fused=False, decode_attn_kernel=0, lm_head_cfg=-2, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -403,6 +405,10 @@ class N1Dual:
             self.model.qwen.thin_decode = True
         if getattr(a, "decode_cfg", 0):
             self.model.qwen.thin_decode = int(a.decode_cfg)
+        if getattr(a, "decode_attn_kernel", 0):
+            self.model.qwen.decode_attn_kernel = int(a.decode_attn_kernel)
+        if getattr(a, "lm_head_cfg", -2) != -2:
+            self.model.qwen.lm_head_cfg = int(a.lm_head_cfg)
         if getattr(a, "split_rows_max", 0):
             self.model.qwen.split_rows_max = int(a.split_rows_max)
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)

@@ -129,6 +129,8 @@ class QwenVLEngine:
         self.split_serial = False     # True: the two half micro-batches of split_prefill on ONE stream (per-launch event timing, bench.py)
         self._side = None
         self.nt_decode = False     # bench / experiments: non-temporal weight loads in the single-token passes' GEMMs (gemm_skinny.hip SK_NT_FLAG)
+        self.decode_attn_kernel = 0   # ina_attn_args.kernel of the single-token passes (0 auto = the 8-wave one-launch kernel; 1 = split + combine pair; 3 = 4-wave one-launch)
+        self.lm_head_cfg = None   # force_cfg of the lm_head GEMM (None: as the single-token passes)
         self.split_rows_max = 16   # rows up to which cfg 31 is used (64: the latent-query pass too)
         # the GEMMs of the single-token passes: 31 (default since round 5) = the split-K kernel pair - many short 256-thread workgroups that get into the
         # gaps System-1's workgroups leave on the CUs, where the 512-thread column-owner workgroups wait - whose row-owning epilogue launch hands the
@@ -338,7 +340,8 @@ class QwenVLEngine:
             # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
             ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
-            ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"])
+            ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"],
+                          kernel=self.decode_attn_kernel if rows <= 16 else 0)
             ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg, group_m=gm, post_norm=(L["n2"], 1e-6, h) if chain31 else None)
             if fused_norm:
                 ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg, group_m=gm)
@@ -360,7 +363,8 @@ class QwenVLEngine:
             ops.norm(self.xl[:B], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B)
         else:
             ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
-        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], group_m=(7 if (self.nt_decode and B <= 16) else 0), force_cfg=((self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (self.thin_decode and B <= 16) else 0))
+        head_cfg = ((self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (self.thin_decode and B <= 16) else 0) if self.lm_head_cfg is None else self.lm_head_cfg
+        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], group_m=(7 if (self.nt_decode and B <= 16) else 0), force_cfg=head_cfg)
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)
