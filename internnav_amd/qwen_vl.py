@@ -135,7 +135,7 @@ class QwenVLEngine:
         # the GEMMs of the single-token passes: 31 (default since round 5) = the split-K kernel pair - many short 256-thread workgroups that get into the
         # gaps System-1's workgroups leave on the CUs, where the 512-thread column-owner workgroups wait - whose row-owning epilogue launch hands the
         # next GEMM its pre-normed operand (ina_gemm_args.post_gamma): 311.0 -> 315.3-316.0 policy steps/s (profiles/r05D_*); False / 0 = the column-owner
-        # kernels with the fused input norm (round 4; 4 % faster ALONE: 4.0 vs 4.2 ms per pass); 60 / 61 = their thin 4-wave builds (experiments)
+        # kernels with the fused input norm (round 4; 1.5 % faster ALONE: decode + latent graph 41.1 vs 41.7 ms); 60 / 61 = their thin 4-wave builds (experiments)
         self.thin_decode = 31
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
