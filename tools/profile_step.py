@@ -13,7 +13,7 @@ kw = {}
 for i, x in enumerate(sys.argv):
     if x == "--chain-waves":
         kw["chain_waves"] = int(sys.argv[i + 1])
-    elif x in ("--thin-decode", "--no-row-chain", "--no-chain-stats"):
+    elif x in ("--thin-decode", "--no-row-chain", "--no-chain-stats", "--decode-fused"):
         kw[x[2:].replace("-", "_")] = True
 wl = bench.N1Dual(bench.default_args(**kw), torch.device("cuda:0"), 0)
 wl.capture()

@@ -13,7 +13,7 @@ argv = sys.argv[1:]
 for i, x in enumerate(argv):        # e.g. `python tools/step_breakdown.py --chain-waves 8 --thin-decode --no-row-chain`
     if x == "--chain-waves":
         kw["chain_waves"] = int(argv[i + 1])
-    elif x in ("--thin-decode", "--no-row-chain", "--no-chain-stats"):
+    elif x in ("--thin-decode", "--no-row-chain", "--no-chain-stats", "--decode-fused"):
         kw[x[2:].replace("-", "_")] = True
 a = bench.default_args(**kw)
 print("# variant:", kw or "default")
