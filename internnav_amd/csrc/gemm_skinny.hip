@@ -159,58 +159,75 @@ __global__ __launch_bounds__(256) void gemm_skinny_epilogue(GemmArgs p, const fl
 // the same epilogue as ONE workgroup per output row (no GLU, N <= 4096), which then also holds the whole fp32 row: post_gamma -> the RMSNorm of the
 // row, i.e. the NEXT GEMM's bf16 operand, leaves with it (ina_gemm_args.post_gamma / post_out) - in a single-token decoder pass the norm launch
 // between the o projection and gate|up, and between the down projection and the next layer's q|k|v, disappears
+template <int CH>   // 4-column chunks per thread: the row's N / 4 chunks on ceil(N / 4 / CH) threads
 __global__ __launch_bounds__(1024) void gemm_skinny_epilogue_rows(GemmArgs p, const float* __restrict__ part, int splits) {
-    // one thread per 4 output columns (N <= 4096 -> at most 1024 threads): its `splits` partial loads are independent and in flight together
+    // every thread's CH x `splits` partial loads are independent and in flight together
     __shared__ float red[16];
-    const int m = blockIdx.x, tid = threadIdx.x, n4 = p.N >> 2, n = tid * 4;
-    const bool live = tid < n4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int m = blockIdx.x, tid = threadIdx.x, n4 = p.N >> 2, nthr = blockDim.x;
+    const float rs = p.rowscale ? p.rowscale[m / p.rowscale_div] : 1.0f;
+    float v[CH][4];
     float sq = 0.f;
-    if (live) {
-        const float rs = p.rowscale ? p.rowscale[m / p.rowscale_div] : 1.0f;
-        for (int s = 0; s < splits; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(part + ((size_t)s * p.M + m) * p.N + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += a[r];
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[c][r] = 0.f;
+        const int i4 = tid + c * nthr;
+        if (i4 < n4) {
+            const int n = i4 * 4;
+            for (int s = 0; s < splits; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(part + ((size_t)s * p.M + m) * p.N + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[c][r] += a[r];
+            }
         }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i4 = tid + c * nthr;
+        if (i4 >= n4) continue;
+        const int n = i4 * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float x = v[r];
+            float x = v[c][r];
             if (p.bias) x += p.bias[n + r];
             x = ina_act(x, p.act);
             if (p.colscale) x *= p.colscale[n + r];
-            v[r] = x * rs;
+            v[c][r] = x * rs;
         }
         if (p.R) {
             const size_t ro = (size_t)m * p.ldr + n;
             if (p.res_dtype == INA_DT_BF16) {
                 const bf16x4 rr = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.R) + ro);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                for (int r = 0; r < 4; ++r) v[c][r] += (float)rr[r];
             } else {
                 const f32x4 rr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + ro);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                for (int r = 0; r < 4; ++r) v[c][r] += rr[r];
             }
         }
         const size_t co = (size_t)m * p.ldc + n;
-        if (p.out_dtype == INA_DT_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = f32x4{v[0], v[1], v[2], v[3]};
+        if (p.out_dtype == INA_DT_BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.C) + co) = bf16x4{(bf16)v[c][0], (bf16)v[c][1], (bf16)v[c][2], (bf16)v[c][3]};
+        else *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + co) = f32x4{v[c][0], v[c][1], v[c][2], v[c][3]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sq = fmaf(v[r], v[r], sq);
+        for (int r = 0; r < 4; ++r) sq = fmaf(v[c][r], v[c][r], sq);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
     float tot = 0.f;
-    const int nwv = (blockDim.x + 63) >> 6;
+    const int nwv = (nthr + 63) >> 6;
     for (int w = 0; w < nwv; ++w) tot += red[w];
     const float rn = rsqrtf(tot / (float)p.N + p.post_eps);
-    if (live) {
+    bf16* __restrict__ H = reinterpret_cast<bf16*>(p.post_out) + (size_t)m * p.post_ld;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i4 = tid + c * nthr;
+        if (i4 >= n4) continue;
+        const int n = i4 * 4;
         const f32x4 gm = *reinterpret_cast<const f32x4*>(p.post_gamma + n);
-        bf16* __restrict__ H = reinterpret_cast<bf16*>(p.post_out) + (size_t)m * p.post_ld;
-        *reinterpret_cast<bf16x4*>(H + n) = bf16x4{(bf16)(v[0] * rn * gm[0]), (bf16)(v[1] * rn * gm[1]), (bf16)(v[2] * rn * gm[2]), (bf16)(v[3] * rn * gm[3])};
+        *reinterpret_cast<bf16x4*>(H + n) = bf16x4{(bf16)(v[c][0] * rn * gm[0]), (bf16)(v[c][1] * rn * gm[1]), (bf16)(v[c][2] * rn * gm[2]), (bf16)(v[c][3] * rn * gm[3])};
     }
 }
 
@@ -598,7 +615,8 @@ int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
         default: hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 0, stream, p, part, kslice); break;
     }
     if (p.post_gamma) {                                    // (ina_plan_gemm: no GLU, N <= 4096)
-        hipLaunchKernelGGL(gemm_skinny_epilogue_rows, dim3(p.M), dim3(((p.N / 4 + 63) / 64) * 64), 0, stream, p, part, splits);
+        // one chunk per thread (16-wave workgroups at N = 3584): 2 / 4 chunks on 8- / 4-wave workgroups measure 312.8 / 305.6 vs 315.0 policy steps/s (profiles/r05K_*)
+        hipLaunchKernelGGL(gemm_skinny_epilogue_rows<1>, dim3(p.M), dim3(((p.N / 4 + 63) / 64) * 64), 0, stream, p, part, splits);
         INA_HIP_CHECK(hipGetLastError());
         return 0;
     }
