@@ -381,6 +381,49 @@ def test_engine_twin_shares_weights_and_owns_buffers():
     assert tw.plan(inp["input_ids"], inp["grid_thw"])["S_run"] == eng.plan(inp["input_ids"], inp["grid_thw"])["S_run"]
 
 
+def test_single_token_pass_launch_sequence_per_variant(monkeypatch):
+    """which launches a single-token decoder pass issues, per GEMM path (recording stand-in for `ops`, CPU-resident engine, nothing is computed):
+    split-K kernel pair (31, default): ONE norm launch per pass (the first layer's input norm) - the o projection hands the post-attention norm
+    to gate|up and the down projection the next layer's input norm to q|k|v (`post_norm`), every GEMM forced to 31; column-owner kernels: no
+    norm launch, q|k|v and gate|up carry `prenorm`; column-owner kernels with norm launches: two per layer. The prefill (many rows) takes none of it."""
+    from internnav_amd import qwen_vl
+    from internnav_amd import synthetic as S
+
+    cfg = dict(S.QWEN_TEST_CFG, v_depth=1, v_fullatt=(0,), t_layers=3)
+    eng = qwen_vl.QwenVLEngine(S.qwen_state_dict(seed=1, cfg=cfg), cfg, "cpu", max_seqs=2, max_seq_len=256, max_patches=2 * 784)
+    inp = S.qwen_inputs(2, 1, seed=1, cfg=cfg, n_text=20, n_tail=8)
+    P = eng.plan(inp["input_ids"], inp["grid_thw"], n_decode=3)
+    calls = []
+
+    class Rec:
+        def __getattr__(self, name):
+            def f(*a, **kw):
+                calls.append((name, kw))
+            return f
+
+    monkeypatch.setattr(qwen_vl, "ops", Rec())
+
+    def run(ph, thin, fuse):
+        calls.clear()
+        eng.thin_decode, eng.fuse_decode_norm = thin, fuse
+        eng._layers(ph)
+        lin = [kw for n, kw in calls if n == "linear"]
+        return dict(norms=sum(n == "norm" for n, _ in calls), linears=len(lin), cfgs={kw.get("force_cfg", 0) for kw in lin},
+                    post=sum(kw.get("post_norm") is not None for kw in lin), pre=sum(kw.get("prenorm") is not None for kw in lin))
+
+    L = cfg["t_layers"]
+    one = P["decode"][0]
+    assert eng.thin_decode == 31                                         # the shipped default
+    assert run(one, 31, True) == dict(norms=1, linears=4 * L, cfgs={31}, post=2 * L - 1, pre=0)
+    assert run(one, False, True) == dict(norms=0, linears=4 * L, cfgs={0}, post=0, pre=2 * L)
+    assert run(one, False, False) == dict(norms=2 * L, linears=4 * L, cfgs={0}, post=0, pre=0)
+    assert run(one, 60, True) == dict(norms=0, linears=4 * L, cfgs={60}, post=0, pre=2 * L)
+    for thin in (31, False, 60):                                         # prefill rows: plain launches whatever the decode switch says
+        assert run(P["prefill"], thin, True) == dict(norms=2 * L, linears=4 * L, cfgs={0}, post=0, pre=0)
+    eng.tap = lambda *a: None                                            # a parity tap reads the stream after every layer: unfused launches
+    assert run(one, 31, True)["post"] == 0 and run(one, 31, True)["norms"] == 2 * L
+
+
 def test_prefix_kv_plan_host_logic_on_cpu():
     """QwenVLEngine.plan(prefix_len=...) is integer work (which images are skipped, which rows run, position ids, cache rows, key lengths):
     checked here on a CPU-resident engine without any kernel launch. The arithmetic of the feature is tested on the GPU
