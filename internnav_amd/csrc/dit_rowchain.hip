@@ -21,6 +21,9 @@
 //           epilogue uses for its 16-byte stores (the merged 8 columns ARE a fragment) - H never exists in memory;
 //   GEMM 2  the row-panel main loop on those fragments; its first W stages are already in the ring (the DMA ring runs through both GEMMs).
 // gamma1 / tanh(gate) / gamma2 / (1 + mod_scale2) of the workgroup's environment are tabulated in LDS once (a workgroup's rows share b).
+// seg_stats (plain second GEMM): the epilogue of GEMM 2 also sums every 384-wide segment of the row it stores and writes (mean, rstd) per
+// segment - the LayerNorm statistics the attention stage of the NEXT block needs for q1 / k1 / q2 (dit_attention.hip: dit_attn_stats_kernel),
+// which then reads every projection row once instead of twice.
 // Numerics: the same roundings as the unfused chain (bf16 projection, fp32 statistics and residual, bf16 H); the K summation runs in
 // 16-wide MFMA steps (as gemm_rowpanel.hip), so results differ from the tiled kernels in the last bits.
 #include <type_traits>

@@ -8,9 +8,12 @@
 //     the natural MFMA k order). The first version gave every lane 64 contiguous bytes instead, i.e. 4 scattered 16-byte pieces
 //     per row per instruction: 3.3 -> 4.0 TB/s on the gate/up projection, 3.8 -> 4.9 TB/s on lm_head from this change alone;
 //   * the activation rows (M x K bf16, <= 2.4 MB, L2 resident) are read directly as the second MFMA operand.
-// gemm_skinny_fused_kernel (default): a group of waves owns its output columns for all of K, reduces through LDS and applies the
-//   epilogue itself. gemm_skinny_kernel + gemm_skinny_epilogue (cfg 31): grid = (N / 64 column tiles) x SPLITK K-slices, fp32
-//   partial tiles in a workspace [SPLITK][M][N], second kernel sums the slices and applies the epilogue.
+// gemm_skinny_fused_kernel (the library's automatic choice at M <= 64): a group of waves owns its output columns for all of K, reduces
+//   through LDS and applies the epilogue itself. gemm_skinny_kernel + gemm_skinny_epilogue (cfg 31): grid = (N / 64 column tiles) x SPLITK
+//   K-slices, fp32 partial tiles in a workspace [SPLITK][M][N], second kernel sums the slices and applies the epilogue. Round 5: the engine
+//   forces cfg 31 for the single-token decoder passes - alone the pair is 1.5 % slower, inside the policy step its many short 256-thread
+//   workgroups get into the gaps System-1's long workgroups leave on the CUs (+ 1.5 % policy steps/s) - and its epilogue has a row-owning form
+//   (gemm_skinny_epilogue_rows) that also writes the NEXT GEMM's RMS-normed operand (ina_gemm_args.post_gamma).
 // Algorithmic bytes per launch = 2*N*K (weights) + 2*M*K + out; roofline = HBM (measured 3.6 - 4.7 TB/s on the LLM shapes,
 // profiles/r01i_skinny_gemm_streaming.log; the 25 - 33 MB projections are latency-bound at ~2 TB/s).
 #include "common.h"

@@ -1,4 +1,5 @@
-// 256 x 256 bf16 MFMA GEMM tile on FOUR waves (wave tile 128 x 128) with LDS-DMA staging - tile config 38 of ina_gemm_bf16.
+// 256 x 256 bf16 MFMA GEMM tile on FOUR waves (wave tile 128 x 128) - tile configs 38 / 39 (both operands through LDS-DMA staging) and 40 (round 5:
+// LDS-DMA for A only, the B fragments straight from a fragment-ordered copy of W into registers; further down) of ina_gemm_bf16.
 // Same stage layout, source-side XOR swizzle, K order and fused epilogue as the 8-wave kernels of gemm_glds.hip (bit-equal results).
 //
 // Why four waves: a 32-wide K slice costs a 128 x 128 wave tile 16 ds_read_b128 for 64 MFMAs - 64 KiB of LDS reads per workgroup and
