@@ -123,3 +123,65 @@ def test_rowpanel_contract_through_gemm_select(built_lib):
     assert sel(65536, 1536, 512, 34) is None and sel(65536, 1500, 384, 34) is None and sel(100, 1536, 384, 35) is None
     assert sel(65536, 1536, 384, 34, out_dtype=1) is None and sel(65536, 2048, 384, 34, glu=1, act=0) is None and sel(65536, 2048, 384, 34, glu=1, act=4, bias=0x3000) is None
     assert sel(49152, 1152, 384, 34, bias=0x3000) == 34 and sel(49152, 1536, 384, 35, bias=0x3000, act=1) == 35 and sel(49152, 1152, 384, 0, bias=0x3000) == 27
+
+
+def test_w4p_counted_waits_cover_their_loads():
+    """Tile config 40 (csrc/gemm_w4.hip) retires its B-fragment loads and LDS-DMA pieces with counted `s_waitcnt vmcnt(N)` over ONE in-order
+    counter. This replays the kernel's fixed instruction stream on the host - prologue, first stage, steady state, the last two stages that
+    request nothing - for several K depths and checks every wait: `vmcnt(N)` retires a request iff at least N requests were issued after it.
+    The constants are read out of the source (a change there must be made here as well)."""
+    import re
+    from pathlib import Path
+
+    src = (Path(__file__).resolve().parent.parent / "internnav_amd" / "csrc" / "gemm_w4.hip").read_text()
+    assert "wait_vm<(SET == 0) ? 15 + 8 * P : 15 + (7 - j) * P + j * D>();" in src          # B fragment j of slice 0 / slice 1
+    assert "wait_vm<9>();" in src and "wait_vm<8 + 16>();" in src                              # DMA share of stage t + 1; prologue: stage 0 of A
+    rd, dma_pos = (int(re.search(rf"#define {n} (\d)", src).group(1)) for n in ("W4P_RD_POS", "W4P_DMA_POS"))
+    assert 0 <= rd < 7 and 0 <= dma_pos < 7                                                   # both precede the B reload at position 7
+    assert "for (; t < 1 && t + 2 < nk; ++t) stage_body(IC<1>{}, IC<0>{}, t);" in src and "for (; t + 2 < nk; ++t) stage_body(IC<1>{}, IC<1>{}, t);" in src
+    assert "for (; t < nk; ++t) stage_body(IC<0>{}, IC<0>{}, t);" in src
+
+    def n_b(slice_par, j, D, P):
+        return 15 + 8 * P if slice_par == 0 else 15 + (7 - j) * P + j * D
+
+    for nk in (1, 2, 3, 4, 5, 9):
+        issued = []                                            # the VMEM requests in issue order: ("A", stage, piece) | ("B", slice, fragment)
+
+        def retired(req, n):                                   # would `s_waitcnt vmcnt(n)` issued NOW have waited for req?
+            return len(issued) - 1 - issued.index(req) >= n
+
+        for st in (0, 1):
+            issued.extend(("A", st, d) for d in range(8))
+        for sl in (0, 1):
+            issued.extend(("B", sl, j) for j in range(8))
+        assert all(retired(("A", 0, d), 8 + 16) for d in range(8))
+        for t in range(nk):
+            D, P = (1, 0) if (t == 0 and nk > 2) else (1, 1) if t + 2 < nk else (0, 0)
+            real_D = int(t + 2 < nk)
+            assert D == real_D                                  # (P may under-state the truth in the last stages: a stricter wait)
+            for par in (0, 1):
+                sl = 2 * t + par
+                for j in range(8):
+                    assert retired(("B", sl, j), n_b(par, j, D, P)), (nk, t, par, j)
+                    # the 8 MFMAs of fragment j: positions 0 .. 7; the DMA piece (slice 1 of a requesting stage) precedes the B reload
+                    if par == 1 and real_D:
+                        issued.append(("A", t + 2, j))
+                    issued.append(("B", sl + 2, j))            # (clamped to the last slice behind the end: still one request)
+                if par == 0 and t + 1 < nk:
+                    assert all(retired(("A", t + 1, d), 9) for d in range(8)), (nk, t)
+        # exactness in the steady state: one request fewer after the awaited load and the wait would no longer cover it
+        if nk >= 5:
+            issued2, checks = [], []
+            for st in (0, 1):
+                issued2.extend(("A", st, d) for d in range(8))
+            for sl in (0, 1):
+                issued2.extend(("B", sl, j) for j in range(8))
+            for t in range(nk):
+                for par in (0, 1):
+                    for j in range(8):
+                        if 2 <= t and t + 2 < nk:
+                            checks.append(len(issued2) - 1 - issued2.index(("B", 2 * t + par, j)) - n_b(par, j, 1, 1))
+                        if par == 1 and t + 2 < nk:
+                            issued2.append(("A", t + 2, j))
+                        issued2.append(("B", 2 * t + par + 2, j))
+            assert checks and set(checks) == {0}
