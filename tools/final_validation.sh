@@ -22,6 +22,7 @@ timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseli
 timeout 600 python bench.py --no-cpu-baseline --s2-every 2 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_s2every2.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --no-frag-weights > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_frag_weights.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --no-row-chain > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_row_chain.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --decode-fused > $R/gpurun_out/${TAG}_bench_n1_dual_b64_decode_fused.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --workload host_stub --gpus 8 --steps 20 > $R/gpurun_out/${TAG}_bench_host_stub_8ranks.json 2>> $R/gpurun_out/${TAG}_bench.err
 fi
 timeout 300 python tools/step_breakdown.py > $R/gpurun_out/${TAG}_step_breakdown.log 2>&1
@@ -59,6 +60,7 @@ if [ -x tools/native/chain_sweep ]; then
   timeout 120 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r05_w4p.txt > $R/gpurun_out/${TAG}_native_w4p.log 2>&1
   timeout 60 tools/native/dit_attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_dit_attn.log 2>&1
   timeout 60 tools/native/rowchain_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_rowchain.log 2>&1
+  timeout 60 tools/native/issue_cost_probe > $R/gpurun_out/${TAG}_native_issue_cost.log 2>&1
 fi
 tail -3 $R/gpurun_out/${TAG}_pytest_gpu.log
 tail -2 $R/gpurun_out/${TAG}_smoke.log
