@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--lookdown", action="store_true",
                     help="n1_dual / s2_only: the look-down turn's prompt - previous turn + answer + the UN-RESIZED 640x480 look-down frame "
                          "(internvla_n1_policy.py:113-116,140)")
+    ap.add_argument("--dit-ffn", type=int, default=1536, choices=[1536, 1024],
+                    help="n1_dual: FFN width of the NextDiT trajectory head - 1536 = the reference's `LuminaFeedForward(dim, inner_dim=4 * dim)` under its "
+                         "pinned diffusers 0.33.1 (default), 1024 = the same call under diffusers <= 0.32 (what rounds 1-5 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
@@ -117,7 +120,7 @@ def parse():
 
 def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
-    a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True,
+    a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True, dit_ffn=1536,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
                            fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, no_frag_weights=False, split_rows_max=0, decode_fused=False, decode_attn_kernel=0, lm_head_cfg=-2, rest=[])
     for k, v in kw.items():
@@ -335,7 +338,7 @@ class N1Dual:
         self.lookdown = bool(a.lookdown)
         tag = ("" if self.cadence == "nominal" else f"_{self.cadence}") + ("" if a.num_history == 3 else f"_h{a.num_history}") + ("_lookdown" if self.lookdown else "")
         self.name = (f"n1_s2_only_b{B}" if self.cadence == "s2_only" else f"n1_dual_b{B}") + tag.replace("_s2_only", "")
-        qcfg, scfg = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_CFG
+        qcfg, scfg = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_VARIANTS[f"ffn{int(getattr(a, 'dit_ffn', 1536))}"]
         self.qcfg, self.scfg = qcfg, scfg
         per = self.GRID[1] * self.GRID[2]
         hb, wb = smart_resize(480, 640)                                   # the look-down frame enters the HF processor at camera size
@@ -378,7 +381,7 @@ class N1Dual:
         self.idxA_host = side
         self.with_s1 = self.cadence != "s2_only"
         s1_max = max(len(side[j]) + self.mb[j] for j in range(P_)) if self.with_s1 else 1     # (the single-stream schedule runs both groups in one call)
-        spec = synthetic.n1_full_spec(qcfg, "nextdit_async")
+        spec = synthetic.n1_full_spec(qcfg, "nextdit_async", s1_cfg=scfg)
         weights = synthetic.LazyDeviceWeights(spec, dev, seed=0)
         S_max = (self.S + self.N_DECODE + 8 + 63) // 64 * 64
         self.model = InternVLAN1ForCausalLM(weights, qcfg, "nextdit_async", scfg, device=dev, max_envs=(B if self.cadence == "nominal" else s1_max),
@@ -451,6 +454,9 @@ class N1Dual:
                                if self.raw else "pre-processed pixel_values / 224x224 frames resident in HBM"),
                      "s2": f"{self.N_IMG} frames x 784 patches" + (f" + the un-resized look-down frame ({per_ld} patches)" if self.lookdown else "") +
                            f" + {self.N_INSTR}-token instruction, S={self.S}, {self.N_DECODE} greedy tokens + 4 latent queries",
+                     "s1_dit": (f"NextDiT {scfg['dit_layers']} blocks x dim {scfg['dit_dim']}, {scfg['dit_heads']} heads, FFN {scfg['dit_ffn']} "
+                                + ("(= the reference's LuminaFeedForward(dim, inner_dim=4*dim) under its pinned diffusers 0.33.1; unverified against a released checkpoint)"
+                                   if scfg["dit_ffn"] == 1536 else "(= the diffusers <= 0.32 convention of LuminaFeedForward; rounds 1-5 timed this width)")) if self.with_s1 else "none",
                      "s1": ("2 look-down frames @224x224, 32 samples x 10 flow-matching steps" + ("" if getattr(a, "no_row_chain", False) else
                             f"; row-local chain of every DiT block in two launches (dit_rowchain, {int(getattr(a, 'chain_waves', 4)) * 32}-row panels)")) if self.with_s1 else "none",
                      "s2_microbatches_per_period": self.mb, "s2_every": self.s2_every, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
@@ -807,10 +813,11 @@ class N1Dual:
         return f"one System-2 call over {m} envs"
 
     def cpu_baseline(self):
-        return n1_cpu_baseline(self.qcfg, self.grids_seq, self.pv_rows_seq, self.ids[:1].cpu().long(), self.N_DECODE, self.cadence, self.with_s1, self.unit)
+        return n1_cpu_baseline(self.qcfg, self.grids_seq, self.pv_rows_seq, self.ids[:1].cpu().long(), self.N_DECODE, self.cadence, self.with_s1, self.unit,
+                               scfg=self.scfg)
 
 
-def n1_cpu_baseline(qc, grids, pv_rows, ids, n_decode, cadence, with_s1, unit, depth_cycle: int = 2):
+def n1_cpu_baseline(qc, grids, pv_rows, ids, n_decode, cadence, with_s1, unit, depth_cycle: int = 2, scfg=None):
     """the reference PyTorch path on the host cores = the CPU oracle, ONE env, bf16 (weights held in bf16 as the reference loads them,
     torch.autocast for the activations), at FULL depth and AS THE REFERENCE EXECUTES a pixel-goal System-2 call
     (internvla_n1_policy.py:163-199): ViT (v_depth blocks) + prefill (t_layers layers, lm_head on every position, internvla_n1.py:220) +
@@ -828,7 +835,7 @@ def n1_cpu_baseline(qc, grids, pv_rows, ids, n_decode, cadence, with_s1, unit, d
     out = {}
     t_s1 = 0.0
     if with_s1:
-        sd = synthetic.n1_nextdit_state_dict(0)
+        sd = synthetic.n1_nextdit_state_dict(0, cfg=scfg or synthetic.N1_NEXTDIT_CFG)
         inp = synthetic.n1_nextdit_inputs(1, 0)
         s1 = lambda: o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])  # noqa: E731
         t32, t16 = _median_time(s1, 3), _median_time(s1, 2, autocast=True)

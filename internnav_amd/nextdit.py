@@ -18,7 +18,7 @@ Hoisted out of the sampler loop without changing results:
 HBM layout (B envs, S = 32 samples, T = 32 tokens, C = 384):
   z      bf16 [B*36, 768]   condition tokens per env: 32 QFormer memory tokens | 4 projected VLM latents
   enc    bf16 [B*36, 384]   caption_projection(z);  kv2[l] bf16 [B*36, 768] per-layer cross-attention K|V
-  x      f32  [B*S*T, 384]  DiT residual stream;  qkvq bf16 [B*S*T, 1536] = q1|k1|v1|q2;  ff bf16 [B*S*T, 1024]
+  x      f32  [B*S*T, 384]  DiT residual stream;  qkvq bf16 [B*S*T, 1536] = q1|k1|v1|q2;  ff bf16 [B*S*T, dit_ffn]
   mod    f32  [B, 12*1536 + 384] adaLN scale/gate vectors of all layers + norm_out scale, refreshed per step
   sample f32  [B*S*T, 3]    trajectories being integrated (updated in place)
 """
@@ -57,7 +57,11 @@ class NextDiTSystem1:
         # [attn2.to_out + norm2 / gate / residual + ffn_norm1 + linear_1/3 SwiGLU] and [linear_2 + ffn_norm2 / gate / residual + the next block's
         # norm1 + its fused q1|k1|v1|q2 projection]; the bf16 projection and the pre-normed GEMM operand stay in registers. Used from 16 k rows
         # (16 envs) on - below that the one-workgroup-per-128-rows grid leaves the chip empty, as for the row-panel GEMMs it is built from.
-        self.row_chain = bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] == 1024 and not fuse_rownorm and not fuse_ffn
+        # The chain is built for dim 384 and the two FFN widths the reference's block can have (1536 under its pinned diffusers 0.33.1, 1024
+        # under <= 0.32: synthetic.lumina_ffn_width); its 128-row panels must not straddle two environments (S * T % 128 == 0). Any other
+        # geometry takes the GEMM + chained-norm launches below - same results, more launches.
+        self.row_chain = (bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] in (1024, 1536) and not fuse_rownorm and not fuse_ffn
+                          and (cfg["sample_num"] * cfg["predict_size"]) % (chain_waves * 32) == 0)
         self.chain_waves = chain_waves
         self.chain_min_rows = 16384
         # the chain's second launch also hands the attention stage the LayerNorm statistics of the projection rows it writes (blocks 1 ...):

@@ -202,7 +202,11 @@ class InternVLAN1ForCausalLM:
         self.qwen = QwenVLEngine(weights, qwen_cfg, device, max_seqs=n_s2, max_seq_len=max_seq_len or cap_seq,
                                  max_patches=max_patches or n_s2 * cap_patches)
         if "nextdit" in system1:
-            self.s1 = NextDiTSystem1(_Prefixed(weights, "model."), s1_cfg or synthetic.N1_NEXTDIT_CFG, device, max_envs, use_async="async" in system1)
+            # the DiT's geometry (width, depth, heads, FFN width) is not in config.json - NextDiTCrossAttnConfig is constructed in code
+            # (internvla_n1_arch.py:127-131) and its FFN width depends on the diffusers release (synthetic.lumina_ffn_width): read it off
+            # the checkpoint's tensor shapes
+            s1w = _Prefixed(weights, "model.")
+            self.s1 = NextDiTSystem1(s1w, s1_cfg or synthetic.n1_nextdit_cfg_from_weights(s1w), device, max_envs, use_async="async" in system1)
         else:
             self.s1 = NavDPPolicyDAT(_Prefixed(weights, "model.navdp."), s1_cfg or synthetic.N1_NAVDP_CFG, device, max_envs, use_async="async" in system1)
         self._noise_gen = torch.Generator(device=self.device).manual_seed(0)
@@ -225,10 +229,21 @@ class InternVLAN1ForCausalLM:
         cfgj = json.loads((p / "config.json").read_text()) if (p / "config.json").exists() else {}
         device = (device_map or {"": "cuda:0"})[""]
         weights = _ShardedCheckpoint(files)
-        missing = [k for k in synthetic.n1_full_spec(qwen_cfg_from_hf(cfgj), cfgj.get("system1", "nextdit_async")) if k not in weights]
+        system1 = cfgj.get("system1", "nextdit_async")
+        s1_cfg = None
+        if "nextdit" in system1:
+            probe = "model.traj_dit.model.layers.0.feed_forward.linear_1.weight"
+            if probe not in weights:
+                raise KeyError(f"checkpoint {p} has no {probe}: not an InternVLA-N1 '{system1}' checkpoint")
+            s1_cfg = synthetic.n1_nextdit_cfg_from_weights(_Prefixed(weights, "model."))
+        spec = synthetic.n1_full_spec(qwen_cfg_from_hf(cfgj), system1, s1_cfg=s1_cfg)
+        missing = [k for k in spec if k not in weights]
         if missing:
             raise KeyError(f"checkpoint {p} lacks {len(missing)} parameters the engines need, e.g. {missing[:4]}")
-        return cls(weights, qwen_cfg_from_hf(cfgj), system1=cfgj.get("system1", "nextdit_async"), device=device, **kw)
+        bad = [(k, weights.shape_of(k), shp) for k, (shp, _) in spec.items() if k.startswith("model.traj_dit.") and tuple(weights.shape_of(k)) != tuple(shp)]
+        if bad:
+            raise ValueError(f"checkpoint {p}: {len(bad)} NextDiT tensors do not have the shapes its own geometry implies, e.g. {bad[:3]}")
+        return cls(weights, qwen_cfg_from_hf(cfgj), system1=system1, s1_cfg=s1_cfg, device=device, **kw)
 
     def eval(self):
         return self
@@ -385,11 +400,11 @@ class _Prefixed:
             return default
 
     def __contains__(self, k):
-        try:
-            self.base[self.prefix + k]
-            return True
-        except KeyError:
-            return False
+        return (self.prefix + k) in self.base
+
+    def shape_of(self, k):
+        b = self.base
+        return tuple(b.shape_of(self.prefix + k)) if hasattr(b, "shape_of") else tuple(b[self.prefix + k].shape)
 
 
 class _ShardedCheckpoint:
@@ -416,6 +431,13 @@ class _ShardedCheckpoint:
 
         with safe_open(self._where[k], framework="pt", device="cpu") as sf:
             return sf.get_tensor(k)
+
+    def shape_of(self, k):
+        """tensor shape from the shard header (no tensor data is read)."""
+        from safetensors import safe_open
+
+        with safe_open(self._where[k], framework="pt", device="cpu") as sf:
+            return tuple(sf.get_slice(k).get_shape())
 
 
 # ------------------------------------------------------------------------------------------------------ policy wrapper

@@ -69,6 +69,9 @@ class LazyDeviceWeights:
     def keys(self):
         return self.spec.keys()
 
+    def shape_of(self, key: str):
+        return tuple(self.spec[key][0])
+
     def __getitem__(self, key: str) -> torch.Tensor:
         shape, kind = self.spec[key]
         g = torch.Generator(device=self.device).manual_seed((zlib.crc32(key.encode()) ^ (self.seed * 0x9E3779B1)) & 0x7FFFFFFF)
@@ -305,10 +308,55 @@ def n1_navdp_spec(cfg=N1_NAVDP_CFG) -> Spec:
     return s
 
 
-N1_NEXTDIT_CFG = dict(n_query=4, vlm_token_dim=3584, latent_dim=768, dit_dim=384, dit_layers=12, dit_heads=6, dit_ffn=1024,
+def lumina_ffn_width(dim: int, multiple_of: int = 256, ffn_dim_multiplier=None, legacy_two_thirds: bool = False) -> int:
+    """width of `LuminaFeedForward(dim, inner_dim=4 * dim, multiple_of, ffn_dim_multiplier)` as the reference's in-tree block builds it
+    (nextdit_traj.py:102-107). diffusers >= 0.33.0 (the reference pins 0.33.1, requirements/internvla_n1.txt:3) takes inner_dim as given:
+    256 * ceil(1536 / 256) = 1536 for dim 384; diffusers <= 0.32 shrank it inside the class (int(2 * inner_dim / 3) -> 1024). A checkpoint's
+    own `feed_forward.linear_1.weight` shape is the authority (`n1_nextdit_cfg_from_weights`); this formula only sizes synthetic weights."""
+    inner = 4 * dim
+    if legacy_two_thirds:
+        inner = int(2 * inner / 3)
+    if ffn_dim_multiplier is not None:
+        inner = int(ffn_dim_multiplier * inner)
+    return multiple_of * ((inner + multiple_of - 1) // multiple_of)
+
+
+N1_NEXTDIT_CFG = dict(n_query=4, vlm_token_dim=3584, latent_dim=768, dit_dim=384, dit_layers=12, dit_heads=6, dit_ffn=lumina_ffn_width(384),
                       predict_size=32, sample_num=32, num_inference_steps=10, memory_frames=2)
 """DualVLN System-1 (`nextdit_async`): NextDiTCrossAttnConfig defaults (nextdit_crossattn_traj.py:12-30) with
-latent_embedding_size 768 (internvla_n1_arch.py:6,22), generate_traj defaults (internvla_n1.py:354-357)."""
+latent_embedding_size 768 (internvla_n1_arch.py:6,22), generate_traj defaults (internvla_n1.py:354-357). FFN width 1536 = the reference's
+`inner_dim=4 * dim` under its pinned diffusers==0.33.1; UNVERIFIED until a 0.33.1 wheel or the released checkpoint's key list is seen."""
+
+N1_NEXTDIT_CFG_FFN1024 = dict(N1_NEXTDIT_CFG, dit_ffn=lumina_ffn_width(384, legacy_two_thirds=True))
+"""the same head under the diffusers <= 0.32 convention (FFN 1024): what rounds 1-5 built and measured; kept pinned and benchmarkable."""
+
+N1_NEXTDIT_VARIANTS = {"ffn1536": N1_NEXTDIT_CFG, "ffn1024": N1_NEXTDIT_CFG_FFN1024}
+
+
+def n1_nextdit_cfg_from_weights(weights, prefix: str = "", base=None) -> dict:
+    """System-1 geometry read off the checkpoint's own tensor shapes (nothing about the DiT is in config.json: NextDiTCrossAttnConfig is
+    constructed in code, internvla_n1_arch.py:127-131). `weights`: mapping name -> tensor-like with `.shape` (or a `shape_of(name)` method)."""
+    def shape(k):
+        k = prefix + k
+        if hasattr(weights, "shape_of"):
+            return tuple(weights.shape_of(k))
+        return tuple(weights[k].shape)
+
+    def has(k):
+        return (prefix + k) in weights
+
+    cfg = dict(base or N1_NEXTDIT_CFG)
+    p = "traj_dit.model.layers."
+    ffn, D = shape(p + "0.feed_forward.linear_1.weight")
+    nl = 0
+    while has(f"{p}{nl}.attn1.to_q.weight"):
+        nl += 1
+    heads = shape(p + "0.gate")[0]
+    L, V = shape("cond_projector.0.weight")
+    assert shape(p + "0.attn1.to_q.weight") == (D, D) and shape(p + "0.feed_forward.linear_2.weight") == (D, ffn), "inconsistent NextDiT tensor shapes"
+    assert shape("traj_dit.model.caption_projection.linear_1.weight") == (D, L) and D % heads == 0
+    cfg.update(dit_dim=D, dit_ffn=ffn, dit_layers=nl, dit_heads=heads, latent_dim=L, vlm_token_dim=V)
+    return cfg
 
 
 def n1_nextdit_spec(cfg=N1_NEXTDIT_CFG) -> Spec:
@@ -410,10 +458,10 @@ def unet1d_inputs(B: int, seed: int = 0, cfg=UNET1D_CFG):
                 x_init=torch.randn(B, cfg["sample_num"], cfg["predict_size"], cfg["input_dim"], generator=g))
 
 
-def n1_full_spec(qwen_cfg=None, system1: str = "nextdit_async") -> Spec:
+def n1_full_spec(qwen_cfg=None, system1: str = "nextdit_async", s1_cfg=None) -> Spec:
     """every parameter of an InternVLA-N1 checkpoint: Qwen2.5-VL (visual.*, model.*, lm_head) + the System-1 modules under `model.`."""
     s = qwen_spec(qwen_cfg or QWEN_N1_CFG)
-    s1 = n1_nextdit_spec() if "nextdit" in system1 else {("navdp." + k): v for k, v in n1_navdp_spec().items()}
+    s1 = n1_nextdit_spec(s1_cfg or N1_NEXTDIT_CFG) if "nextdit" in system1 else {("navdp." + k): v for k, v in n1_navdp_spec().items()}
     if "async" not in system1:
         # the plain 'nextdit' / 'navdp' types condition on the VLM latents alone (internvla_n1.py:382-383, navdp.py:255-289): the look-down
         # memory modules are not part of the engines' needs

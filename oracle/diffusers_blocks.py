@@ -73,13 +73,47 @@ class LuminaLayerNormContinuous(nn.Module):
         return x
 
 
-class LuminaFeedForward(nn.Module):
-    def __init__(self, dim, inner_dim, multiple_of=256, ffn_dim_multiplier=None):
-        super().__init__()
+# Which LuminaFeedForward the in-tree `LuminaNextDiTBlock` is built on decides the width of the trajectory DiT's FFN, and it changed
+# between diffusers releases (restated from the published sources - the package is absent here, DESIGN.md 2 "FFN width"):
+#   * up to 0.32.x  the CLASS shrinks its argument: inner_dim = int(2 * inner_dim / 3) -> the reference's `inner_dim=4 * dim`
+#                   (nextdit_traj.py:102-107) gives 256 * ceil(1024 / 256) = 1024;
+#   * from 0.33.0   (the Lumina2 refactor) the factor moved out of the class into diffusers' own LuminaNextDiTBlock call site
+#                   (`inner_dim=int(4 * 2 * dim / 3)`), so the reference's unchanged in-tree call gives 256 * ceil(1536 / 256) = 1536.
+# The reference pins diffusers==0.33.1 (requirements/internvla_n1.txt:3): the pinned reading is 1536 and is the default here. The other
+# convention stays selectable so both widths are pinned through the reference's own block wiring (tests/golden/n1_nextdit*.pt).
+LEGACY_TWO_THIRDS = False
+
+
+class ffn_convention:
+    """`with ffn_convention(legacy_two_thirds=True): ...` builds LuminaFeedForward as diffusers <= 0.32 did (width 1024 for dim 384)."""
+
+    def __init__(self, legacy_two_thirds: bool):
+        self.legacy = bool(legacy_two_thirds)
+
+    def __enter__(self):
+        global LEGACY_TWO_THIRDS
+        self.prev, LEGACY_TWO_THIRDS = LEGACY_TWO_THIRDS, self.legacy
+        return self
+
+    def __exit__(self, *exc):
+        global LEGACY_TWO_THIRDS
+        LEGACY_TWO_THIRDS = self.prev
+        return False
+
+
+def lumina_ffn_width(inner_dim: int, multiple_of: int = 256, ffn_dim_multiplier=None, legacy_two_thirds: bool = False) -> int:
+    if legacy_two_thirds:
         inner_dim = int(2 * inner_dim / 3)
-        if ffn_dim_multiplier is not None:
-            inner_dim = int(ffn_dim_multiplier * inner_dim)
-        inner_dim = multiple_of * ((inner_dim + multiple_of - 1) // multiple_of)
+    if ffn_dim_multiplier is not None:
+        inner_dim = int(ffn_dim_multiplier * inner_dim)
+    return multiple_of * ((inner_dim + multiple_of - 1) // multiple_of)
+
+
+class LuminaFeedForward(nn.Module):
+    def __init__(self, dim, inner_dim, multiple_of=256, ffn_dim_multiplier=None, legacy_two_thirds=None):
+        super().__init__()
+        legacy = LEGACY_TWO_THIRDS if legacy_two_thirds is None else legacy_two_thirds
+        inner_dim = lumina_ffn_width(inner_dim, multiple_of, ffn_dim_multiplier, legacy)
         self.linear_1 = nn.Linear(dim, inner_dim, bias=False)
         self.linear_2 = nn.Linear(inner_dim, dim, bias=False)
         self.linear_3 = nn.Linear(dim, inner_dim, bias=False)

@@ -193,7 +193,22 @@ def gold_n1_navdp(B=2):
     return dict(B=B, seed=1, trajectories=ref, trajectories_plain=plain, oracle_max_abs_diff=d)
 
 
-def gold_n1_nextdit(B=2):
+def _ffn_variant(variant: str):
+    """(engine / weight config, context manager selecting the matching LuminaFeedForward convention of the fake diffusers package) for one of
+    the two FFN widths the reference's in-tree block can have: 'ffn1536' = diffusers 0.33.1 as pinned, 'ffn1024' = diffusers <= 0.32."""
+    from . import diffusers_blocks as blk
+
+    cfg = W.N1_NEXTDIT_VARIANTS[variant]
+    return cfg, blk.ffn_convention(legacy_two_thirds=(variant == "ffn1024"))
+
+
+def _check_ffn_width(m, cfg):
+    """the reference's own constructor must have produced the width the weight table assumes"""
+    got = m.traj_dit.model.layers[0].feed_forward.linear_1.weight.shape[0]
+    assert got == cfg["dit_ffn"], (got, cfg["dit_ffn"])
+
+
+def gold_n1_nextdit(B=2, variant="ffn1536"):
     """The reference's System-1 component modules (NextDiTCrossAttn incl. the in-tree LuminaNextDiTBlock wiring, MemoryEncoder,
     QFormer, DINOv2) driven by a line-by-line transcription of generate_traj's nextdit_async branch (internvla_n1.py:359-432):
     `InternVLAN1ForCausalLM` itself cannot be constructed here (it subclasses the transformers-4.51 Qwen2.5-VL layout)."""
@@ -203,8 +218,8 @@ def gold_n1_nextdit(B=2):
     from . import nextdit as o_nd
 
     nd, arch = R.nextdit_module(), R.n1_arch_module()
-    cfg = W.N1_NEXTDIT_CFG
-    sd = W.n1_nextdit_state_dict(seed=4)
+    cfg, convention = _ffn_variant(variant)
+    sd = W.n1_nextdit_state_dict(seed=4, cfg=cfg)
 
     class S1(nn.Module):  # attribute names of InternVLAN1MetaModel.__init__ (internvla_n1_arch.py:127-141)
         def __init__(self):
@@ -218,7 +233,10 @@ def gold_n1_nextdit(B=2):
             self.memory_encoder = arch.MemoryEncoder()
             self.rgb_resampler = arch.QFormer()
 
-    m = _load_strict(S1(), sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.", "rgb_resampler.visual_proj."))
+    with convention:
+        m = S1()
+    _check_ffn_width(m, cfg)
+    m = _load_strict(m, sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.", "rgb_resampler.visual_proj."))
     inp = W.n1_nextdit_inputs(B, seed=4)
     from .schedulers import FlowMatchEulerDiscreteScheduler
 
@@ -271,7 +289,7 @@ def gold_n1_nextdit(B=2):
         ref = torch.stack(outs)
         mine = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
     worst = max([(ref - mine).abs().max().item()] + [v["oracle_max_abs_diff"] for v in variants.values()])
-    return dict(B=B, seed=4, latents=ref, variants=variants, oracle_max_abs_diff=worst)
+    return dict(B=B, seed=4, dit_ffn=cfg["dit_ffn"], latents=ref, variants=variants, oracle_max_abs_diff=worst)
 
 
 def gold_qwen(B=2, n_img=2):
@@ -541,7 +559,7 @@ def _count_dropout_sites(module, fn):
     return counts
 
 
-def gold_sft(B=1, T=2):
+def gold_sft(B=1, T=2, variant="ffn1536"):
     """SFT loss of the nextdit_async branch (internvla_n1.py:222-286) through the reference's own System-1 modules under autograd
     (dropout off: .eval()), transcribed line by line; the noise / time-step draws of :261-264 are seeded inputs. Saves the loss, the
     gradient w.r.t. the trajectory hidden states and, per parameter, the gradient norm + 32 sampled entries."""
@@ -552,7 +570,8 @@ def gold_sft(B=1, T=2):
     from .schedulers import FlowMatchEulerDiscreteScheduler
 
     nd, arch = R.nextdit_module(), R.n1_arch_module()
-    sd = W.n1_nextdit_state_dict(seed=6)
+    cfg, convention = _ffn_variant(variant)
+    sd = W.n1_nextdit_state_dict(seed=6, cfg=cfg)
 
     class S1(nn.Module):
         def __init__(self):
@@ -567,7 +586,10 @@ def gold_sft(B=1, T=2):
             self.memory_encoder = arch.MemoryEncoder()
             self.rgb_resampler = arch.QFormer()
 
-    m = _load_strict(S1(), sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.", "rgb_resampler.visual_proj."))
+    with convention:
+        m = S1()
+    _check_ffn_width(m, cfg)
+    m = _load_strict(m, sd, allow_missing_prefixes=("traj_dit.model.patch_embedder.", "rgb_resampler.visual_proj."))
     g = torch.Generator().manual_seed(6)
     hidden_q = torch.randn(B, 4, 3584, generator=g).requires_grad_(True)
     traj_images = torch.rand(B, T, 224, 224, 3, generator=g)
@@ -634,7 +656,7 @@ def gold_sft(B=1, T=2):
     no_grad = sorted(k for k, p in m.named_parameters() if p.grad is None)
     sites = _count_dropout_sites(m, lambda: m.traj_dit(x=action_features, timestep=timesteps, z_latents=torch.cat(
         [m.rgb_resampler(torch.cat([images_dp_feat.flatten(1, 2), m.memory_encoder(images_dp_feat.flatten(1, 2))], dim=-1)), ths], dim=1)))
-    return dict(B=B, T=T, seed=6, weights_seed=6, dropout_sites=sites, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples, params_without_grad=no_grad,
+    return dict(B=B, T=T, seed=6, weights_seed=6, dit_ffn=cfg["dit_ffn"], dropout_sites=sites, loss=loss.item(), d_hidden=hidden_q.grad.clone(), grads=samples, params_without_grad=no_grad,
                 inputs=dict(hidden_q=hidden_q.detach(), traj_images=traj_images, traj_poses=traj_poses, video_frame_num=video_frame_num,
                             noise=noise, t_index=indices),
                 oracle_max_abs_diff=worst)
@@ -802,7 +824,16 @@ def gold_sft_navdp(B=1, T=2):
                 oracle_max_abs_diff=worst)
 
 
-UNITS = {"sft_navdp": gold_sft_navdp, "sft": gold_sft, "sft_nextdit_plain": gold_sft_plain, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "navdpnet_nogoal": gold_navdpnet_nogoal, "n1_navdp": gold_n1_navdp}
+def _variant(fn, variant):
+    def run():
+        return fn(variant=variant)
+    return run
+
+
+# the NextDiT fixtures exist for both FFN widths the reference's block can have (oracle/diffusers_blocks.py: LEGACY_TWO_THIRDS): the default
+# files are the pinned diffusers==0.33.1 reading (1536), *_ffn1024 the diffusers <= 0.32 one
+UNITS = {"n1_nextdit_ffn1024": _variant(gold_n1_nextdit, "ffn1024"), "sft_ffn1024": _variant(gold_sft, "ffn1024"),
+         "sft_navdp": gold_sft_navdp, "sft": gold_sft, "sft_nextdit_plain": gold_sft_plain, "unet1d": gold_unet1d, "preprocess": gold_preprocess, "vln_utils": gold_vln_utils, "qwen_lookdown": gold_qwen_lookdown, "dinov2": gold_dinov2, "n1_nextdit": gold_n1_nextdit, "qwen": gold_qwen, "navdpnet": gold_navdpnet, "navdpnet_nogoal": gold_navdpnet_nogoal, "n1_navdp": gold_n1_navdp}
 
 
 def main():

@@ -103,15 +103,19 @@ def test_navdpnet_b64_distribution(built_lib, gold):
         assert torch.allclose(neg[b].cpu(), traj[b][cr[b].argsort()[:8]], atol=1e-5)
 
 
-def test_nextdit_b64_distribution(built_lib, gold):
-    """DualVLN System-1 at 64 envs per call (the bench's batch): 10 flow-matching steps, 32 samples."""
+@pytest.mark.parametrize("section,cfg", [("nextdit", W.N1_NEXTDIT_CFG), ("nextdit_ffn1024", W.N1_NEXTDIT_CFG_FFN1024)])
+def test_nextdit_b64_distribution(built_lib, gold, section, cfg):
+    """DualVLN System-1 at 64 envs per call (the bench's batch): 10 flow-matching steps, 32 samples - for both FFN widths of the reference's
+    block (1536: diffusers 0.33.1 as pinned; 1024: <= 0.32). 64 envs = 65 536 rows: the row-chain launches (dit_rowchain) run here."""
     from internnav_amd.nextdit import NextDiTSystem1
 
-    g = gold["nextdit"]
-    B, cfg = gold["B"], W.N1_NEXTDIT_CFG
-    sd = W.n1_nextdit_state_dict(seed=g["seed"])
+    g = gold[section]
+    assert g["dit_ffn"] == cfg["dit_ffn"]
+    B = gold["B"]
+    sd = W.n1_nextdit_state_dict(seed=g["seed"], cfg=cfg)
     inp = W.n1_nextdit_inputs(B, seed=g["seed"])
     eng = NextDiTSystem1(sd, cfg, DEV, max_envs=B)
+    assert eng.row_chain
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), inp["images"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV))
     mine = _per_env(out.view(B, *g["latents"].shape[1:]), g["latents"])
     r = _report("NextDiT B=64 trajectory latents", mine, g["yard"])

@@ -1,5 +1,5 @@
 """GPU parity of the DualVLN System-1 engine (internnav_amd.nextdit) against the fixture produced by the reference's own
-NextDiT / MemoryEncoder / QFormer / DINOv2 modules (tests/golden/n1_nextdit.pt, oracle/make_golden.py).
+NextDiT / MemoryEncoder / QFormer / DINOv2 modules (tests/golden/n1_nextdit.pt + n1_nextdit_ffn1024.pt, oracle/make_golden.py).
 Tolerance: latents are x4-scaled waypoint increments of O(1); mean abs error <= 1e-3 (BASELINE.json), max abs bounded."""
 from pathlib import Path
 
@@ -27,17 +27,31 @@ def test_pool_act(built_lib):
     assert torch.allclose(o2.float(), torch.nn.functional.silu(t + pos), atol=2e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("fuse_rownorm,fuse_ffn", [(False, False), (True, False), (False, True), (True, True)])
-def test_nextdit_generate_traj_vs_reference_fixture(built_lib, fuse_rownorm, fuse_ffn):
-    """fuse_rownorm: attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + pre-norm epilogue (gemm_rownorm);
-    fuse_ffn: the whole SwiGLU feed-forward + its gated norm / residual / next pre-norm as one launch (dit_ffn; correct but slower, off by default)."""
+FFN = {"ffn1536": ("n1_nextdit.pt", W.N1_NEXTDIT_CFG), "ffn1024": ("n1_nextdit_ffn1024.pt", W.N1_NEXTDIT_CFG_FFN1024)}
+"""both FFN widths the reference's LuminaNextDiTBlock can have (oracle/diffusers_blocks.py: 1536 under the pinned diffusers 0.33.1, 1024 under
+<= 0.32), each with a fixture from the reference's own block wiring"""
+
+
+def _load(ffn):
+    name, cfg = FFN[ffn]
+    gold = torch.load(Path(__file__).resolve().parent / "golden" / name, weights_only=True)
+    assert gold["dit_ffn"] == cfg["dit_ffn"]
+    return gold, cfg
+
+
+@pytest.mark.parametrize("ffn", list(FFN))
+def test_nextdit_generate_traj_vs_reference_fixture(built_lib, ffn):
+    from internnav_amd import synthetic
     from internnav_amd.nextdit import NextDiTSystem1
 
-    gold = torch.load(Path(__file__).resolve().parent / "golden" / "n1_nextdit.pt", weights_only=True)
+    gold, cfg = _load(ffn)
     B = gold["B"]
-    sd = W.n1_nextdit_state_dict(seed=gold["seed"])
+    sd = W.n1_nextdit_state_dict(seed=gold["seed"], cfg=cfg)
     inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
-    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B, fuse_rownorm=fuse_rownorm, fuse_ffn=fuse_ffn)
+    # the engine's geometry is read off the weights (as from_pretrained does), not handed in
+    derived = synthetic.n1_nextdit_cfg_from_weights(sd)
+    assert derived == cfg, (derived, cfg)
+    eng = NextDiTSystem1(sd, derived, DEV, max_envs=B)
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), inp["images"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV))
     d = (out.float().cpu() - gold["latents"]).abs()
     ref = gold["latents"].abs().max().item()
@@ -50,21 +64,22 @@ def test_nextdit_generate_traj_vs_reference_fixture(built_lib, fuse_rownorm, fus
     assert (o1[0] - out2[1]).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("ffn", list(FFN))
 @pytest.mark.parametrize("variant", ["cfg_2p5", "plain", "plain_cfg_0p5"])
-def test_nextdit_other_generate_traj_branches_vs_reference_fixture(built_lib, variant):
+def test_nextdit_other_generate_traj_branches_vs_reference_fixture(built_lib, variant, ffn):
     """the branches of generate_traj the released DualVLN checkpoint does not take (internvla_n1.py:382-387,425-427): classifier-free guidance
     with a weight != 1 (conditional + all-zero-condition DiT pass per step) and the plain 'nextdit' System-1 type (condition = projected
     latents alone, no look-down memory) - fixtures from the reference's own modules (oracle/make_golden.py gold_n1_nextdit variants)."""
     from internnav_amd.nextdit import NextDiTSystem1
 
-    gold = torch.load(Path(__file__).resolve().parent / "golden" / "n1_nextdit.pt", weights_only=True)
+    gold, cfg = _load(ffn)
     v = gold["variants"][variant]
     B = gold["B"]
-    sd = W.n1_nextdit_state_dict(seed=gold["seed"])
+    sd = W.n1_nextdit_state_dict(seed=gold["seed"], cfg=cfg)
     if not v["use_async"]:          # a plain 'nextdit' checkpoint has none of the memory modules: the engine must not ask for them
         sd = {k: t for k, t in sd.items() if not k.startswith(("rgb_model.", "memory_encoder.", "rgb_resampler."))}
     inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
-    eng = NextDiTSystem1(sd, W.N1_NEXTDIT_CFG, DEV, max_envs=B, use_async=v["use_async"])
+    eng = NextDiTSystem1(sd, cfg, DEV, max_envs=B, use_async=v["use_async"])
     img = inp["images"].to(DEV, torch.bfloat16) if v["use_async"] else None
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), img, inp["x_init"].to(DEV), guidance_scale=v["guidance_scale"])
     d = (out.float().cpu() - v["latents"]).abs()

@@ -903,7 +903,9 @@ def test_gemm_rowpanel_bias_activation_epilogue(ops, cfg, M, N, act):
 
 @pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("M,K1,N2,glu", [(256, 384, 2048, True), (2048, 1024, 1536, False), (1024 + 256, 384, 256, True), (512, 1024, 0, False),
-                                         (768, 384, 0, False)])
+                                         (768, 384, 0, False),
+                                         # FFN width 1536 (the reference's block under its pinned diffusers 0.33.1): SwiGLU N2 = 2 x 1536, linear_2 K1 = 1536
+                                         (512, 384, 3072, True), (1024, 1536, 1536, False), (256, 1536, 0, False)])
 def test_dit_rowchain(ops, waves, M, K1, N2, glu):
     """csrc/dit_rowchain.hip: GEMM 1 (N = 384) + gated rmsnorm + residual + next pre-norm + GEMM 2 of a NextDiT block in one launch, against
     (a) the fp32 formula of the chain with the unfused chain's rounding points (bf16 projection, bf16 pre-normed operand), (b) the three

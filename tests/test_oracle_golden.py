@@ -107,13 +107,36 @@ def test_flow_match_euler_scheduler():
     assert torch.allclose(x, torch.zeros(2, 3), atol=1e-6)  # integrates v = 1 from sigma 1 to 0
 
 
-def test_n1_nextdit_matches_reference():
+FFN_FIXTURES = [("", W.N1_NEXTDIT_CFG), ("_ffn1024", W.N1_NEXTDIT_CFG_FFN1024)]
+"""the NextDiT fixtures exist for both FFN widths the reference's in-tree block can have: 1536 (LuminaFeedForward of the pinned
+diffusers 0.33.1) and 1024 (diffusers <= 0.32) - oracle/diffusers_blocks.py: LEGACY_TWO_THIRDS"""
+
+
+def test_lumina_ffn_width_conventions():
+    from internnav_amd import synthetic
+    from oracle import diffusers_blocks as blk
+
+    assert blk.LuminaFeedForward(384, 4 * 384, 256, None).linear_1.weight.shape == (1536, 384)          # 0.33.1 (pinned): inner_dim as given
+    with blk.ffn_convention(legacy_two_thirds=True):
+        assert blk.LuminaFeedForward(384, 4 * 384, 256, None).linear_1.weight.shape == (1024, 384)      # <= 0.32: int(2 * inner_dim / 3)
+    assert blk.LEGACY_TWO_THIRDS is False
+    assert synthetic.lumina_ffn_width(384) == 1536 and synthetic.lumina_ffn_width(384, legacy_two_thirds=True) == 1024
+    assert W.N1_NEXTDIT_CFG["dit_ffn"] == 1536 and W.N1_NEXTDIT_CFG_FFN1024["dit_ffn"] == 1024
+    for cfg in (W.N1_NEXTDIT_CFG, W.N1_NEXTDIT_CFG_FFN1024):      # geometry read back off the tensor shapes (what from_pretrained does)
+        spec = synthetic.n1_nextdit_spec(cfg)
+        shapes = {k: torch.empty(v[0], device="meta") for k, v in spec.items()}
+        assert synthetic.n1_nextdit_cfg_from_weights(shapes) == cfg
+
+
+@pytest.mark.parametrize("suffix,cfg", FFN_FIXTURES)
+def test_n1_nextdit_matches_reference(suffix, cfg):
     """generate_traj (nextdit_async) driven through the reference's own NextDiT / MemoryEncoder / QFormer / DINOv2 modules."""
     from oracle import nextdit as o_nd
 
-    gold = _load("n1_nextdit")
+    gold = _load("n1_nextdit" + suffix)
+    assert gold["dit_ffn"] == cfg["dit_ffn"]
     B = gold["B"]
-    sd = W.n1_nextdit_state_dict(seed=gold["seed"])
+    sd = W.n1_nextdit_state_dict(seed=gold["seed"], cfg=cfg)
     inp = W.n1_nextdit_inputs(B, seed=gold["seed"])
     with torch.no_grad():
         out = o_nd.generate_traj(sd, inp["traj_latents"], inp["images"], inp["x_init"])
@@ -187,13 +210,15 @@ def test_ddim_scheduler_known_properties():
     assert torch.allclose(sch.step(eps, 40, big, use_clipped_model_output=True).prev_sample, a_p.sqrt() * x0c + (1 - a_p).sqrt() * eps_c, atol=1e-5)
 
 
-def test_sft_loss_and_gradients_match_reference_autograd():
+@pytest.mark.parametrize("suffix,cfg", FFN_FIXTURES)
+def test_sft_loss_and_gradients_match_reference_autograd(suffix, cfg):
     """SFT loss of the nextdit_async branch (internvla_n1.py:222-286): torch autograd of the oracle restatement against the fixture made
     by back-propagating through the reference's own NextDiT / MemoryEncoder / QFormer / DINOv2 modules (oracle/make_golden.py gold_sft)."""
     from oracle import sft as o_sft
 
-    gold = _load("sft")
-    sd = {k: v.float().clone().requires_grad_(True) for k, v in W.n1_nextdit_state_dict(seed=gold["weights_seed"]).items()}
+    gold = _load("sft" + suffix)
+    assert gold["dit_ffn"] == cfg["dit_ffn"]
+    sd = {k: v.float().clone().requires_grad_(True) for k, v in W.n1_nextdit_state_dict(seed=gold["weights_seed"], cfg=cfg).items()}
     inp = gold["inputs"]
     hq = inp["hidden_q"].clone().requires_grad_(True)
     loss = o_sft.nextdit_sft_loss(sd, hq, inp["traj_images"], inp["traj_poses"], inp["video_frame_num"], inp["noise"], inp["t_index"])

@@ -36,12 +36,14 @@ def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
 
 
-@pytest.fixture(scope="module")
-def case(dev):
+@pytest.fixture(scope="module", params=["ffn1536", "ffn1024"])
+def case(dev, request):
+    """both FFN widths the reference's LuminaNextDiTBlock can have (1536: diffusers 0.33.1 as pinned, 1024: <= 0.32); the head reads its
+    geometry off the weights"""
     from internnav_amd import sft as E
     from internnav_amd import synthetic as S
 
-    sd0 = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(), 3).items()}
+    sd0 = {k: v.float() for k, v in S.materialize(S.n1_nextdit_spec(S.N1_NEXTDIT_VARIANTS[request.param]), 3).items()}
     inp = _inputs(2, 2)
     ref = _oracle(sd0, inp, False)
     yard = _oracle(sd0, inp, True)
