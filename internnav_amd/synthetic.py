@@ -604,7 +604,7 @@ def n1_navdp_inputs(B: int, seed: int = 0, cfg=N1_NAVDP_CFG):
     return dict(vlm_tokens=vlm, images=images, depths=depths, x_init=x_init, step_noise=step_noise)
 
 
-def write_checkpoint(path, qwen_cfg=None, system1: str = "nextdit_async", seed: int = 0, shards: int = 2):
+def write_checkpoint(path, qwen_cfg=None, system1: str = "nextdit_async", seed: int = 0, shards: int = 2, s1_cfg=None):
     """A synthetic InternVLA-N1 checkpoint ON DISK in the layout of a real one (HF safetensors shards with the reference's parameter
     names + config.json in the Qwen2.5-VL / InternVLAN1ModelConfig layout): what `InternVLAN1ForCausalLM.from_pretrained` and the
     agent's config-only construction are tested against (no real checkpoint is available offline). bf16 tensors, like the release."""
@@ -616,7 +616,8 @@ def write_checkpoint(path, qwen_cfg=None, system1: str = "nextdit_async", seed: 
     cfg = qwen_cfg or QWEN_TEST_CFG
     p = Path(path)
     p.mkdir(parents=True, exist_ok=True)
-    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in materialize(n1_full_spec(cfg, system1), seed).items()}
+    # (s1_cfg: the NextDiT geometry the tensors are written at - it is NOT recorded in config.json, as in the reference's checkpoints)
+    sd = {k: v.to(torch.bfloat16).contiguous() for k, v in materialize(n1_full_spec(cfg, system1, s1_cfg=s1_cfg), seed).items()}
     keys = sorted(sd)
     per = (len(keys) + shards - 1) // shards
     for i in range(shards):

@@ -119,6 +119,38 @@ def test_from_pretrained_equals_direct_construction(ckpt):
         InternVLAN1ForCausalLM.from_pretrained(str(d / "nowhere"))
 
 
+@pytest.mark.parametrize("s1_cfg", [S.N1_NEXTDIT_CFG, S.N1_NEXTDIT_CFG_FFN1024, dict(S.N1_NEXTDIT_CFG, dit_layers=3, dit_ffn=768)],
+                         ids=["ffn1536", "ffn1024", "3-layer-ffn768"])
+def test_from_pretrained_reads_the_dit_geometry_off_the_checkpoint(built_lib, tmp_path, s1_cfg):
+    """nothing about the trajectory DiT is in config.json (NextDiTCrossAttnConfig is built in code, internvla_n1_arch.py:127-131) and its FFN
+    width depends on the diffusers release the checkpoint was trained under: a checkpoint written at either width - or any other geometry -
+    loads with no configuration edit, and computes what a directly constructed engine with that geometry computes."""
+    from internnav_amd.nextdit import NextDiTSystem1
+    from internnav_amd.policy import InternVLAN1ForCausalLM
+
+    sd = S.write_checkpoint(tmp_path, S.QWEN_TEST_CFG, "nextdit_async", seed=11, s1_cfg=s1_cfg)
+    m = InternVLAN1ForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16, device_map={"": DEV}, max_envs=2, max_seq_len=512, max_patches=1568)
+    assert m.s1.cfg == s1_cfg, (m.s1.cfg, s1_cfg)
+    assert m.s1.layers[0]["w2"].shape == (s1_cfg["dit_dim"], s1_cfg["dit_ffn"]) and len(m.s1.layers) == s1_cfg["dit_layers"]
+    s1 = S.n1_nextdit_inputs(2, seed=3)
+    lat = s1["traj_latents"].to(DEV, torch.bfloat16)
+    traj = m.generate_traj(lat, s1["images"].to(DEV), None, noise=dict(x_init=s1["x_init"].to(DEV))).float().cpu()
+    direct = NextDiTSystem1({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, s1_cfg, DEV, max_envs=2)
+    ref = direct.generate_traj(lat, s1["images"].to(DEV), s1["x_init"].to(DEV)).float().cpu()
+    assert torch.isfinite(traj).all() and torch.equal(traj.view_as(ref), ref)
+    # a checkpoint whose tensors disagree with each other is refused by name, not loaded into the wrong geometry
+    from safetensors.torch import load_file, save_file
+    f = sorted(tmp_path.glob("*.safetensors"))
+    for shard in f:
+        t = load_file(str(shard))
+        k = "model.traj_dit.model.layers.1.feed_forward.linear_2.weight"
+        if k in t:
+            t[k] = t[k][:, :-128].contiguous()
+            save_file(t, str(shard))
+    with pytest.raises(ValueError, match="NextDiT"):
+        InternVLAN1ForCausalLM.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16, device_map={"": DEV}, max_envs=2, max_seq_len=512, max_patches=1568)
+
+
 def test_agent_from_config_alone_steps_two_envs(ckpt, monkeypatch):
     from internnav_amd.agent import InternVLAN1Agent
     from internnav_amd.policy import InternVLAN1Net

@@ -74,7 +74,8 @@ def test_every_parameter_gradient(case):
         e, y = _rel(got, ref), _rel(g16[k], ref)
         errs.append(e)
         yards.append(y)
-        if e > 2.5 * y + 2e-3 or e > 3e-2:
+        # absolute cap 3e-2, except where bf16 PyTorch autograd itself sits at that level (the 6-element tanh gates: 2.9e-2 at FFN 1536)
+        if e > 2.5 * y + 2e-3 or e > max(3e-2, 1.5 * y):
             bad.append((k, e, y))
     assert not bad, bad[:10]
     assert sum(errs) / len(errs) <= sum(yards) / len(yards), (sum(errs) / len(errs), sum(yards) / len(yards))
