@@ -82,31 +82,10 @@ def parse():
                          "15 GB of decoder weights 9 times per TWO steps instead of per step. Trades step-latency uniformity for throughput; reported next to the default.")
     ap.add_argument("--no-split-prefill", action="store_true",
                     help="n1_dual: System-2 prefill as ONE launch sequence instead of two half micro-batches on two streams")
-    ap.add_argument("--no-fuse-decode-norm", action="store_true", help="n1_dual: separate RMSNorm launches in the decode passes (round-2 chain)")
-    ap.add_argument("--fuse-rownorm", action="store_true",
-                    help="n1_dual: NextDiT attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue")
-    ap.add_argument("--s1-delay-passes", type=int, default=0,
-                    help="n1_dual: the side stream's System-1 call starts after the first k single-token decode passes of the System-2 micro-batch instead of "
-                         "right behind the prefill (the decode chain is the longer one beside System-1: a head start balances the two chains' end times)")
-    ap.add_argument("--decode-cfg", type=int, default=0, help="n1_dual: force_cfg of the decode passes' weight-streaming GEMMs (60 thin, 61 four-wave uncapped)")
-    ap.add_argument("--no-chain-stats", action="store_true", help="n1_dual: the DiT attention stage computes its LayerNorm statistics itself (round-4 kernel)")
     ap.add_argument("--no-frag-weights", action="store_true", help="n1_dual: prefill GEMMs without the fragment-ordered weight copies (tile config 39 / 18 instead of 40)")
-    ap.add_argument("--decode-fused", action="store_true", help="n1_dual: single-token passes on the column-owner kernels with the fused input norm (round-4 default) instead of the split-K kernel pair")
-    ap.add_argument("--decode-attn-kernel", type=int, default=0, help="n1_dual: ina_attn_args.kernel of the single-token passes (1 = split + combine launches, 3 = 4-wave one-launch kernel)")
-    ap.add_argument("--lm-head-cfg", type=int, default=-2, help="n1_dual: force_cfg of the lm_head GEMM (0 = column-owner kernel; default: as the single-token passes)")
-    ap.add_argument("--split-rows-max", type=int, default=0, help="n1_dual: rows up to which --decode-cfg 31 applies (64: the latent-query pass too)")
-    ap.add_argument("--nt-decode", action="store_true", help="n1_dual: non-temporal weight loads in the decode passes' GEMMs (experiment)")
-    ap.add_argument("--thin-decode", action="store_true",
-                    help="n1_dual: the weight-streaming GEMMs of the single-token decode passes as 4-wave / <= 96-register builds that fit on a CU beside "
-                         "System-1's 256-row row-chain workgroups (use with --chain-waves 8)")
+    ap.add_argument("--no-fuse-decode-rope", action="store_true", help="n1_dual: the single-token passes with the rope + KV-append launch of their own (6 launches per layer instead of 5)")
     ap.add_argument("--no-row-chain", action="store_true",
                     help="n1_dual: the round-4 launches for the row-local part of the NextDiT blocks (GEMM, norm, GEMM) instead of the row-chain kernel")
-    ap.add_argument("--chain-waves", type=int, default=4, choices=[4, 8], help="n1_dual: row panels of the row-chain kernel (4 waves = 128 rows, 8 = 256)")
-    ap.add_argument("--no-s1-merge-images", action="store_true",
-                    help="n1_dual: encode the look-down frames of the System-2 envs in the small System-1 call behind the decode chain (round-3 schedule) "
-                         "instead of inside the side stream's batched encoder pass over all 64 envs")
-    ap.add_argument("--no-raw-frames", action="store_true",
-                    help="n1_dual: start the timed step at resident pixel_values / 224x224 frames (round-1 boundary) instead of raw uint8 640x480 camera frames")
     # (round-3 schedule experiments - stream priorities, System-1 started with the prefill, early look-down encoding, a split side-stream
     #  call - were all measured neutral or negative, profiles/r03d/e/f/u_*; their switches are gone)
     a, rest = ap.parse_known_args()
@@ -121,8 +100,8 @@ def parse():
 def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True, dit_ffn=1536,
-                           no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, no_fuse_decode_norm=False,
-                           fuse_rownorm=False, no_raw_frames=False, no_s1_merge_images=False, s2_every=1, no_row_chain=False, chain_waves=4, s1_delay_passes=0, thin_decode=False, decode_cfg=0, nt_decode=False, no_chain_stats=False, no_frag_weights=False, split_rows_max=0, decode_fused=False, decode_attn_kernel=0, lm_head_cfg=-2, rest=[])
+                           no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, s2_every=1, no_row_chain=False,
+                           no_frag_weights=False, no_fuse_decode_rope=False, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -386,34 +365,14 @@ class N1Dual:
         S_max = (self.S + self.N_DECODE + 8 + 63) // 64 * 64
         self.model = InternVLAN1ForCausalLM(weights, qcfg, "nextdit_async", scfg, device=dev, max_envs=(B if self.cadence == "nominal" else s1_max),
                                             max_seq_len=max(1024, S_max), max_patches=mmax * self.pv_rows_seq, max_s2_seqs=mmax)
-        if getattr(a, "fuse_rownorm", False):
-            self.model.s1.fuse_rownorm = True
-            self.model.s1.row_chain = False
         if getattr(a, "no_row_chain", False):
             self.model.s1.row_chain = False
-        self.model.s1.chain_waves = int(getattr(a, "chain_waves", 4))
-        if getattr(a, "no_chain_stats", False):
-            self.model.s1.chain_stats = False
-        if getattr(a, "no_fuse_decode_norm", False):
-            self.model.qwen.fuse_decode_norm = False
         if getattr(a, "no_split_prefill", False):
             self.model.qwen.split_prefill = False
         if getattr(a, "no_frag_weights", False):
             self.model.qwen.frag_weights = False
-        if getattr(a, "nt_decode", False):
-            self.model.qwen.nt_decode = True
-        if getattr(a, "decode_fused", False):
-            self.model.qwen.thin_decode = False
-        if getattr(a, "thin_decode", False):
-            self.model.qwen.thin_decode = True
-        if getattr(a, "decode_cfg", 0):
-            self.model.qwen.thin_decode = int(a.decode_cfg)
-        if getattr(a, "decode_attn_kernel", 0):
-            self.model.qwen.decode_attn_kernel = int(a.decode_attn_kernel)
-        if getattr(a, "lm_head_cfg", -2) != -2:
-            self.model.qwen.lm_head_cfg = int(a.lm_head_cfg)
-        if getattr(a, "split_rows_max", 0):
-            self.model.qwen.split_rows_max = int(a.split_rows_max)
+        if getattr(a, "no_fuse_decode_rope", False):
+            self.model.qwen.fuse_decode_rope = False
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
         lim = qcfg["image_token_id"] - 16
         ids = torch.randint(0, lim, (B, self.S), device=dev, generator=g)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 6
+#define INA_ABI_VERSION 7
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0
@@ -87,13 +87,6 @@ typedef struct ina_gemm_args {
     const float* norm_gamma; /* f32 [K] or NULL (no fused norm; A is bf16) */
     float norm_eps;
     int32_t a_dtype;        /* dtype of A when norm_gamma is set: INA_BF16 | INA_F32 */
-    /* the NEXT GEMM's pre-normed operand out of this GEMM's epilogue (split-K kernel pair, force_cfg 31, no GLU, N <= 4096): after C is stored,
-     * post_out[m, :] = bf16(C_f32[m, :] * rsqrt(mean(C_f32[m, :]^2) + post_eps) * post_gamma) - the RMSNorm launch between two GEMMs of a
-     * single-token pass disappears (o projection -> post-attention norm, down projection -> the next layer's input norm) */
-    const float* post_gamma; /* f32 [N] or NULL */
-    void* post_out;          /* bf16 [M, N], row stride post_ld */
-    float post_eps;
-    int32_t post_ld;
     const void* Wp;         /* NULL, or the same W in MFMA fragment order (ina_gemm_preshuffle; N % 16 == 0, K % 32 == 0): tile config 40 takes its
                              * B fragments from it straight into registers (selected where cfg 39 would run; bit-equal results) */
 } ina_gemm_args;
@@ -105,7 +98,7 @@ int ina_gemm_preshuffle(const void* W, void* Wp, int32_t N, int32_t K, int64_t l
  * (the selection is host arithmetic on M / N / K, the epilogue and force_cfg): *kernel = 1-8 register-staged tiles, 11-29 / 33 LDS-DMA tiles
  * (18 = 256x256 ping-pong, 21 = 192x256 ping-pong, 22 / 26 / 27 single-buffer tiles of the d = 384 heads, 33 = 256x256 with 16 waves),
  * 34-37 row-panel kernels (K = 384), 38 / 39 / 40 the 256x256 tile on four waves of 128x128 (39 is selected for wide no-residual K = 2048 .. 4096 GEMMs, 40 instead of it when Wp is given),
- * 30 = weight streaming with the fused input RMSNorm, 31 / 32 = weight streaming (M <= 64). Returns non-zero (and sets ina_last_error)
+ * 30 = weight streaming with the fused input RMSNorm, 32 = weight streaming (M <= 64). Returns non-zero (and sets ina_last_error)
  * exactly when ina_gemm_bf16 would reject the arguments. */
 int ina_gemm_select(const ina_gemm_args* args, int* kernel);
 
@@ -149,6 +142,16 @@ typedef struct ina_attn_args {
     int32_t _pad0;
     const uint32_t* drop_salt; /* training, optional: one device word ADDED to drop_seed when the kernel starts - a launch sequence captured in a
                                 * hipGraph draws fresh masks on every replay (the host bumps the word between replays); NULL = drop_seed alone */
+    /* single-token decoder passes (d = 128, causal, 256 <= Lk <= 1024, Lq <= 8: the one-launch decode kernel): the rotary embedding of the NEW tokens
+     * and their KV-cache append inside the attention launch - what ina_rope_bf16 with KV set does in a launch of its own. Q holds the UN-rotated
+     * query heads; k_new / v_new the un-rotated key / raw value heads of the Lq new tokens (element strides kn_bs per sequence, kn_rs per token,
+     * kn_hs per kv head - the q|k|v projection buffer); the kernel rotates q in registers, writes rotate(k_new) and v_new into rows
+     * len_k - Lq .. len_k - 1 of K / V (the cache) and then attends. Same arithmetic and rounding as the separate launch. NULL: Q / K / V as given. */
+    const float* rope_cos;     /* f32 [B * Lq, 128] or NULL */
+    const float* rope_sin;
+    const void* k_new;
+    const void* v_new;
+    int64_t kn_bs, kn_rs, kn_hs;
 } ina_attn_args;
 int ina_attention_bf16(const ina_attn_args* args, void* stream);
 

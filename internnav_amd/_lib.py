@@ -25,7 +25,6 @@ class GemmArgs(C.Structure):
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
         ("force_cfg", c_int32), ("group_m", c_int32),
         ("norm_gamma", c_void_p), ("norm_eps", c_float), ("a_dtype", c_int32),
-        ("post_gamma", c_void_p), ("post_out", c_void_p), ("post_eps", c_float), ("post_ld", c_int32),
         ("Wp", c_void_p),
     ]
 
@@ -44,6 +43,8 @@ class AttnArgs(C.Structure):
         ("cu_q", c_void_p), ("cu_k", c_void_p), ("head_gate", c_void_p), ("k_len", c_void_p),
         ("accumulate", c_int32), ("drop_seed", C.c_uint32), ("drop_thresh", C.c_uint32), ("drop_scale", c_float),
         ("kernel", c_int32), ("_pad0", c_int32), ("drop_salt", c_void_p),
+        ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("k_new", c_void_p), ("v_new", c_void_p),
+        ("kn_bs", c_int64), ("kn_rs", c_int64), ("kn_hs", c_int64),
     ]
 
 
@@ -338,7 +339,7 @@ SYMBOLS = {
 _lib = None
 # the struct layouts above mirror include/internnav_amd.h at THIS version of the C-ABI (INA_ABI_VERSION there): lib() refuses a shared object
 # built from another version - a stale .so would read pointers at the wrong offsets
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class EngineError(RuntimeError):

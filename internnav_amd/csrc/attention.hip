@@ -602,6 +602,58 @@ __global__ __launch_bounds__(DEC8_WAVES * 64) void attn_decode_fused8_kernel(Att
         const int d = kk * 32 + g * 8;
         qf[kk] = (live && d < p.D) ? *reinterpret_cast<const bf16x8*>(Q + d) : zero8;
     }
+    if constexpr (DP == 128 && DV == 128) {
+        if (p.rope_cos) {
+            // ---- rotary embedding + KV-cache append of the NEW tokens in this launch (ina_attn_args.rope_cos: the single-token passes of the
+            // decoder - no rope launch between the q|k|v projection and the attention). The Lq query tokens are the last Lq keys: token r sits at
+            // cache row len_k - Lq + r. Arithmetic and rounding of rope.hip's rope_kernel (bf16 in, fp32 rotation, bf16 out).
+            // q: a lane's fragments kk and kk + 2 are the two halves of the same 8 dims - the rotation is lane-local
+            if (live) {
+                const float* cr = p.rope_cos + ((size_t)b * p.Lq + qpos) * DP + g * 8;
+                const float* sr = p.rope_sin + ((size_t)b * p.Lq + qpos) * DP + g * 8;
+#pragma unroll
+                for (int kk = 0; kk < NKK / 2; ++kk) {
+                    const bf16x8 lo = qf[kk], hi = qf[kk + NKK / 2];
+                    bf16x8 olo, ohi;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int d = kk * 32 + i;
+                        olo[i] = (bf16)ina_rope_lo((float)lo[i], (float)hi[i], cr[d], sr[d]);
+                        ohi[i] = (bf16)ina_rope_hi((float)lo[i], (float)hi[i], cr[d + DP / 2], sr[d + DP / 2]);
+                    }
+                    qf[kk] = olo;
+                    qf[kk + NKK / 2] = ohi;
+                }
+            }
+            // k / v of kv head kh: even waves rotate a token's key row into the cache (8 lanes x 8 dims of each half), odd waves copy its value row
+            for (int r = wave >> 1; r < p.Lq; r += DEC8_WAVES / 2) {
+                const size_t src = (size_t)b * p.kn_bs + (size_t)r * p.kn_rs + (size_t)kh * p.kn_hs;
+                const size_t row = (size_t)(len_k - p.Lq + r);
+                if ((wave & 1) == 0) {
+                    if (lane < 8) {
+                        const bf16* kn = reinterpret_cast<const bf16*>(p.k_new) + src + lane * 8;
+                        const bf16x8 lo = *reinterpret_cast<const bf16x8*>(kn), hi = *reinterpret_cast<const bf16x8*>(kn + DP / 2);
+                        const float* cr = p.rope_cos + ((size_t)b * p.Lq + r) * DP + lane * 8;
+                        const float* sr = p.rope_sin + ((size_t)b * p.Lq + r) * DP + lane * 8;
+                        bf16x8 olo, ohi;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            olo[i] = (bf16)ina_rope_lo((float)lo[i], (float)hi[i], cr[i], sr[i]);
+                            ohi[i] = (bf16)ina_rope_hi((float)lo[i], (float)hi[i], cr[i + DP / 2], sr[i + DP / 2]);
+                        }
+                        bf16* kd = const_cast<bf16*>(K) + row * p.k_rs + lane * 8;
+                        *reinterpret_cast<bf16x8*>(kd) = olo;
+                        *reinterpret_cast<bf16x8*>(kd + DP / 2) = ohi;
+                    }
+                } else if (lane < 16) {
+                    *reinterpret_cast<bf16x8*>(const_cast<bf16*>(V) + row * p.v_rs + lane * 8) =
+                        *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.v_new) + src + lane * 8);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the appended rows have left this CU before any wave of the workgroup reads them back
+            __syncthreads();
+        }
+    }
     constexpr int NVI = KVB * VCPR / 64;
     static_assert((KVB * VCPR) % 64 == 0, "chunk pieces must divide evenly over the wave");
     bf16x8 kf[NST][NKK], vreg[NVI];
@@ -757,6 +809,9 @@ int launch_decode(const AttnArgs& p, hipStream_t stream) {
     if constexpr (DV == 128 && DP == 128) {
         // the 8-wave / 72 KiB kernel (round 5) for the decoder's d = 128 heads; ina_attn_args.kernel = 3 pins the 4-wave kernel below
         if (nsplit <= DEC_FUSED_MAX_CHUNKS && p.kernel != 1 && p.kernel != 3) {
+            INA_REQUIRE(!p.rope_cos || (p.rope_sin && p.k_new && p.v_new && p.D == 128 && p.causal && p.kn_rs % 8 == 0 && p.kn_hs % 8 == 0 && p.kn_bs % 8 == 0 &&
+                                        ((uintptr_t)p.k_new % 16) == 0 && ((uintptr_t)p.v_new % 16) == 0 && p.k_rs % 8 == 0 && p.v_rs % 8 == 0),
+                        "attention(rope): needs rope_sin, k_new, v_new, d = 128, causal decode and 16-byte aligned rows");
             constexpr size_t LDS8 = (size_t)DEC8_WAVES * (DV / 2) * (64 + 8) * sizeof(bf16);
             auto kern8 = attn_decode_fused8_kernel<DP, DV>;
             static bool attr8_done = false;
@@ -847,6 +902,14 @@ int ina_launch_attention(const AttnArgs& p_in, hipStream_t stream) {
                 "attention: strides must keep 16-byte row alignment");
     INA_REQUIRE(((uintptr_t)p.Q % 16) == 0 && ((uintptr_t)p.K % 16) == 0 && ((uintptr_t)p.V % 16) == 0 && ((uintptr_t)p.O % 8) == 0,
                 "attention: misaligned pointer");
+    if (p.rope_cos) {
+        // the rotary embedding + KV append of the new tokens exists in the one-launch decode kernel of the d = 128 heads only: refuse - never ignore - it elsewhere
+        const bool decode = !p.cu_q && !p.cu_k && p.kv_bdiv == 1 && p.kv_start == 0 && !p.accumulate && !p.head_gate && !p.drop_thresh && p.Lk >= 256 &&
+                            (p.H / p.Hkv) * p.Lq <= 48 && p.Lq <= 8;
+        INA_REQUIRE(decode && p.D == 128 && (p.Lk + DEC_CHUNK - 1) / DEC_CHUNK <= DEC_FUSED_MAX_CHUNKS && p.kernel == 0,
+                    "attention(rope): the fused rotary embedding + KV append needs the one-launch decode kernel (d = 128, 256 <= Lk <= %d, Lq <= 8, kernel 0): Lq=%d Lk=%d D=%d",
+                    DEC_CHUNK * DEC_FUSED_MAX_CHUNKS, p.Lq, p.Lk, p.D);
+    }
     switch (p.D) {
         case 48: return launch_d<64, 48>(p, stream);
         case 64: return launch_d<64, 64>(p, stream);

@@ -58,6 +58,11 @@ __device__ __forceinline__ uint32_t ina_hash(uint32_t seed, uint64_t idx) {
     return ina_fmix32(h + 0x9E3779B9u * (uint32_t)(idx >> 32) + 0x7F4A7C15u);
 }
 
+// rotary embedding of a (first half, second half) pair, x * cos + rotate_half(x) * sin: ONE definition (explicit fma) for rope.hip's kernel and
+// the decode attention kernel's prologue (attention.hip), so the fused and the unfused path round identically
+__device__ __forceinline__ float ina_rope_lo(float lo, float hi, float c, float s) { return fmaf(lo, c, -(hi * s)); }
+__device__ __forceinline__ float ina_rope_hi(float lo, float hi, float c, float s) { return fmaf(hi, c, lo * s); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -104,7 +109,7 @@ void ina_set_error(const char* fmt, ...);
 // is current when they are issued (ina_set_workspace_slot, default 0); the pointer is baked into a captured graph, so graphs that
 // may be replayed CONCURRENTLY on different streams must be captured under different slots. Buffers grow on demand outside capture.
 constexpr int INA_WS_SLOTS = 8;
-constexpr int INA_WS_KINDS = 2;   // 0 skinny-GEMM split-K partials, 1 decode-attention partials
+constexpr int INA_WS_KINDS = 2;   // 0 (unused since round 6), 1 decode-attention partials
 int ina_workspace(int kind, size_t bytes, hipStream_t stream, float** out);
 
 // Optional per-launch timing (ina_prof_enable): every launch function opens a scope that records a hipEvent pair on the

@@ -168,8 +168,7 @@ int launch_cfg(const GemmArgs& p, hipStream_t stream) {
 
 // Validation + kernel selection of one GEMM call, without launching anything (host arithmetic only: also reachable as ina_gemm_select so
 // that the selection can be inspected / tested without a GPU). `kernel`: 1-8 register-staged tiles (gemm_bf16_nt_kernel), 11-29 / 33
-// LDS-DMA tiles (gemm_glds.hip), 38 / 39 the four-wave 256 x 256 tile (gemm_w4.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 31 = split-K weight streaming, 32 = fused
-// weight streaming (gemm_skinny.hip).
+// LDS-DMA tiles (gemm_glds.hip), 38 / 39 the four-wave 256 x 256 tile (gemm_w4.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 32 = weight streaming (gemm_skinny.hip).
 int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     p = p_in;
     if (p.rowscale_div <= 0) p.rowscale_div = 1;
@@ -184,33 +183,24 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
     // skinny M: HBM-bound weight streaming with split-K (gemm_skinny.hip) instead of an under-filled tile grid
     if (p.norm_gamma) {
-        INA_REQUIRE(!p.post_gamma, "gemm: post_gamma is not combined with the fused input norm");
         INA_REQUIRE(p.M <= 16 && p.batch <= 1 && p.K % 8 == 0 && p.K <= 4096 && p.N >= 256,
                     "gemm: the fused input RMSNorm is built for the decode passes (M <= 16 rows, K <= 4096, one batch): M=%d K=%d N=%d batch=%d", p.M, p.K, p.N, p.batch);
         INA_REQUIRE(p.a_dtype == INA_DT_BF16 || p.a_dtype == INA_DT_F32, "gemm: a_dtype must be bf16 or f32 with norm_gamma");
         INA_REQUIRE(((uintptr_t)p.norm_gamma % 16) == 0 && (p.lda % (p.a_dtype == INA_DT_F32 ? 4 : 8)) == 0, "gemm(prenorm): misaligned gamma / lda");
-        kernel = (p.force_cfg == 60 || p.force_cfg == 61) ? p.force_cfg : 30;
+        INA_REQUIRE(p.force_cfg <= 0, "gemm: the fused input RMSNorm exists in the automatic weight-streaming kernel only (force_cfg %d)", p.force_cfg);
+        kernel = 30;
         return 0;
     }
     INA_REQUIRE(p.force_cfg != 30, "gemm: kernel 30 (fused input RMSNorm) is selected by norm_gamma, not by force_cfg");
-    if (p.force_cfg == 60 || p.force_cfg == 61) {      // thin weight-streaming build (4-wave workgroups, <= 96 registers): the decode passes beside System-1's row chain
-        INA_REQUIRE(p.M <= 16 && p.batch == 1 && p.N >= 256 && !p.post_gamma, "gemm: the thin weight-streaming kernels are built for M <= 16, batch 1, no post_gamma (M=%d N=%d)", p.M, p.N);
-        kernel = p.force_cfg;
-        return 0;
-    }
     if (p.force_cfg <= 0 && p.M <= 64 && p.batch == 1 && p.N >= 256) {
-        INA_REQUIRE(!p.post_gamma, "gemm: post_gamma needs force_cfg = 31 (the split-K kernel pair)");
         kernel = 32;
         return 0;
     }
-    if (p.force_cfg == 31 || p.force_cfg == 32) {
-        INA_REQUIRE(p.M <= 64 && p.batch == 1, "gemm: skinny kernels need M <= 64, batch 1 (M=%d)", p.M);
-        INA_REQUIRE(!p.post_gamma || (p.force_cfg == 31 && !p.glu && p.N <= 4096 && p.N % 4 == 0 && p.post_out && p.post_ld % 4 == 0 && ((uintptr_t)p.post_out % 8) == 0),
-                    "gemm: post_gamma (the next GEMM's pre-normed operand) is written by the epilogue launch of the split-K kernel pair only (force_cfg 31, no GLU, N <= 4096; N=%d)", p.N);
-        kernel = p.force_cfg;
+    if (p.force_cfg == 32) {
+        INA_REQUIRE(p.M <= 64 && p.batch == 1, "gemm: the weight-streaming kernels need M <= 64, batch 1 (M=%d)", p.M);
+        kernel = 32;
         return 0;
     }
-    INA_REQUIRE(!p.post_gamma, "gemm: post_gamma needs force_cfg = 31 (the split-K kernel pair)");
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch;
     int cfg = p.force_cfg;
     if (cfg <= 0) {
@@ -273,6 +263,12 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
             if ((cfg == 39 || (cfg == 18 && p.K >= 8192 && ina_gemm_w4_contract(p))) && p.Wp && p.N % 16 == 0 && p.batch == 1) cfg = 40;
         }
     }
+    {
+        static const int known[] = {1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 29, 33, 34, 35, 36, 37, 38, 39, 40};
+        bool ok = false;
+        for (int k : known) ok = ok || k == cfg;
+        INA_REQUIRE(ok, "gemm: unknown tile config %d", cfg);
+    }
     if (cfg == 40) INA_REQUIRE(p.Wp && p.N % 16 == 0 && p.batch == 1, "gemm: tile config 40 needs the fragment-ordered copy of W (Wp), N %% 16 == 0, no batch (N=%d)", p.N);
     if (cfg == 38 || cfg == 39 || cfg == 40)
         INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 38 / 39 / 40 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
@@ -289,8 +285,6 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
     int cfg = 0;
     if (int rc = ina_plan_gemm(p_in, p, cfg)) return rc;
     if (cfg == 30) return ina_launch_gemm_skinny_prenorm(p, stream);
-    if (cfg == 60 || cfg == 61) return ina_launch_gemm_skinny_thin(p, stream);
-    if (cfg == 31) return ina_launch_gemm_skinny(p, stream);
     if (cfg == 32) return ina_launch_gemm_skinny_fused(p, stream);
     ina_prof_set_sub(cfg);
     switch (cfg) {
@@ -304,9 +298,6 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
         case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: case 38: case 39: case 40: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
         case 34: case 35: case 36: case 37: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
-#ifdef INA_RP_EXPERIMENTS
-        case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: case 59: return ina_launch_gemm_rowpanel(p, stream, cfg);
-#endif
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

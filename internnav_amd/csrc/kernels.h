@@ -45,10 +45,8 @@ using AttnBwdArgs = ina_attn_bwd_args;
 
 int ina_launch_gemm(const GemmArgs& p, hipStream_t stream);
 int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel);   // validation + kernel selection only (no launch)
-int ina_launch_gemm_skinny_thin(const GemmArgs& p, hipStream_t stream);      // M <= 16, 4-wave / <= 96-register builds (with or without the fused input RMSNorm)
 int ina_launch_gemm_skinny_prenorm(const GemmArgs& p, hipStream_t stream);   // M <= 16 with the input RMSNorm fused in front (gemm_skinny.hip)
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
-int ina_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming split-K path
 int ina_launch_gemm_skinny_fused(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming, workgroup owns its columns for all K, fused epilogue
 int ina_launch_gemm_rowpanel(const GemmArgs& p, hipStream_t stream, int cfg);  // gemm_rowpanel.hip: K = 384, register-resident row panels (cfg 34-37)
 bool ina_gemm_rowpanel_contract(const GemmArgs& p);

@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void rope_kernel(RopeArgs p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float a = (float)lo[j], b = (float)hi[j];
-                    olo[j] = (bf16)(a * c0[j] - b * s0[j]);        // x*cos + (-x2)*sin
-                    ohi[j] = (bf16)(b * c1[j] + a * s1[j]);        // x2*cos + x1*sin
+                    olo[j] = (bf16)ina_rope_lo(a, b, c0[j], s0[j]);        // x*cos + (-x2)*sin
+                    ohi[j] = (bf16)ina_rope_hi(a, b, c1[j], s1[j]);        // x2*cos + x1*sin
                 }
                 lo = olo;
                 hi = ohi;

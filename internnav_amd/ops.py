@@ -61,11 +61,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
            rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
-           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None, post_norm=None) -> torch.Tensor:
+           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
 
-    post_norm=(gamma f32 [N], eps, h bf16 [M, N]) with force_cfg=31 (split-K kernel pair, M <= 64): h = bf16(rmsnorm(out_f32) * gamma), the next
-    GEMM's operand, written by this GEMM's epilogue launch.
     w_frag: the same weight in MFMA fragment order (gemm_preshuffle(w)): the wide no-residual GEMMs that would run tile config 39 then take
     their B fragments from it straight into registers (config 40, bit-equal); ignored by every other tile.
 
@@ -115,11 +113,6 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.rowscale_div = rowscale_div
     a.force_cfg = force_cfg if force_cfg else _AUTO_CFG
     a.group_m = group_m
-    if post_norm is not None:
-        pg, pe, ph = post_norm
-        assert not batched and pg.dtype == torch.float32 and pg.is_contiguous() and pg.numel() == n_out
-        assert ph.dtype == torch.bfloat16 and ph.shape == (M, n_out) and ph.stride(1) == 1
-        a.post_gamma, a.post_out, a.post_eps, a.post_ld = pg.data_ptr(), ph.data_ptr(), float(pe), ph.stride(0)
     if w_frag is not None:
         assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and w_frag.numel() == N * K and N % 16 == 0 and K % 32 == 0
         a.Wp = w_frag.data_ptr()
@@ -143,14 +136,22 @@ def gemm_preshuffle(w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torc
     return out
 
 
+def attention_rope_ok(Lq: int, Lk: int, H: int, Hkv: int, D: int) -> bool:
+    """shapes whose attention launch can carry the rotary embedding + KV append of its new tokens (the one-launch decode kernel of the d = 128
+    heads; csrc/attention.hip ina_launch_attention)"""
+    return D == 128 and 256 <= Lk <= 1024 and Lq <= 8 and (H // Hkv) * Lq <= 48
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, causal: bool = False,
               kv_start: int = 0, kv_bdiv: int = 1, cu_q: Optional[torch.Tensor] = None,
               cu_k: Optional[torch.Tensor] = None, max_q: int = 0, max_k: int = 0,
               head_gate: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               accumulate: bool = False, k_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
-              kernel: int = 0, drop_salt: Optional[torch.Tensor] = None) -> torch.Tensor:
+              kernel: int = 0, drop_salt: Optional[torch.Tensor] = None, rope=None) -> torch.Tensor:
     """softmax(q k^T * scale [+ masks]) v.   kernel: 0 = automatic, 1 = the 16-rows-per-wave kernel, 2 = the 32-rows-per-wave kernel
     (ina_attn_args.kernel; the parity tests compare the two).
+    rope=(cos f32 [B * Lq, 128], sin, k_new bf16 [B, Lq, Hkv, 128], v_new) - single-token decoder passes (see `attention_rope_ok`): q, k_new are
+    UN-rotated; the launch rotates them, appends rotate(k_new) | v_new to the last Lq rows of k / v (the cache views) and attends.
 
     Dense: q [B, Lq, H, D], k/v [Bk, Lk, Hkv, D] (arbitrary strides, last dim contiguous; Bk = B / kv_bdiv).
     Varlen: q [T, H, D], k/v [Tk, Hkv, D] packed with int32 cu_q / cu_k offsets and max_q / max_k.
@@ -193,6 +194,12 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional
         assert k_len.dtype == torch.int32 and k_len.is_contiguous() and cu_q is None
         a.k_len = k_len.data_ptr()
     a.accumulate = 1 if accumulate else 0
+    if rope is not None:
+        cos, sin, k_new, v_new = rope
+        assert cu_q is None and cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape[-1] == 128 and cos.numel() >= B * Lq * 128
+        assert k_new.dtype == torch.bfloat16 and k_new.shape == (B, Lq, Hkv, D) and v_new.shape == k_new.shape and k_new.stride() == v_new.stride() and k_new.stride(-1) == 1
+        a.rope_cos, a.rope_sin, a.k_new, a.v_new = cos.data_ptr(), sin.data_ptr(), k_new.data_ptr(), v_new.data_ptr()
+        a.kn_bs, a.kn_rs, a.kn_hs = k_new.stride(0), k_new.stride(1), k_new.stride(2)
     a.kernel = kernel
     if drop_p > 0.0:       # training only: attention-probability dropout, mask = counter hash of (seed, element index)
         assert cu_q is None, "dropout: dense layouts only"

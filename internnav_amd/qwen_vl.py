@@ -128,15 +128,7 @@ class QwenVLEngine:
         self.split_prefill = True
         self.split_serial = False     # True: the two half micro-batches of split_prefill on ONE stream (per-launch event timing, bench.py)
         self._side = None
-        self.nt_decode = False     # bench / experiments: non-temporal weight loads in the single-token passes' GEMMs (gemm_skinny.hip SK_NT_FLAG)
-        self.decode_attn_kernel = 0   # ina_attn_args.kernel of the single-token passes (0 auto = the 8-wave one-launch kernel; 1 = split + combine pair; 3 = 4-wave one-launch)
-        self.lm_head_cfg = None   # force_cfg of the lm_head GEMM (None: as the single-token passes)
-        self.split_rows_max = 16   # rows up to which cfg 31 is used (64: the latent-query pass too)
-        # the GEMMs of the single-token passes: 31 (default since round 5) = the split-K kernel pair - many short 256-thread workgroups that get into the
-        # gaps System-1's workgroups leave on the CUs, where the 512-thread column-owner workgroups wait - whose row-owning epilogue launch hands the
-        # next GEMM its pre-normed operand (ina_gemm_args.post_gamma): 311.0 -> 315.3-316.0 policy steps/s (profiles/r05D_*); False / 0 = the column-owner
-        # kernels with the fused input norm (round 4; 1.5 % faster ALONE: decode + latent graph 41.1 vs 41.7 ms); 60 / 61 = their thin 4-wave builds (experiments)
-        self.thin_decode = 31
+        self.fuse_decode_rope = True   # single-token passes: rotary embedding + KV-cache append inside the attention launch instead of a launch of their own
         self.tap = None   # debug / parity hook: tap(kind, index, residual_stream) after every ViT block ("vit") and decoder layer ("llm"); eager runs only
         D, I = cfg["v_hidden"], cfg["v_inter"]
         Ip = (I + 63) // 64 * 64   # SwiGLU width padded with zero rows/cols: GLU tiles need N % 32 == 0, the LDS-DMA GEMM K % 64 == 0
@@ -304,6 +296,8 @@ class QwenVLEngine:
                   rows=torch.from_numpy(rows).to(dev), Lk=int(pos0.max()) + S, k_len=None, b0=b0, r0=b0 * S)
         if k_len is not None:
             ph["k_len"] = torch.from_numpy(np.asarray(k_len, dtype=np.int32)).to(dev)
+        # the new tokens of every sequence are its LAST S keys (what the attention launch assumes when it appends them itself, ina_attn_args.rope_cos)
+        ph["new_are_last"] = bool(np.all((np.asarray(k_len).reshape(-1) if k_len is not None else ph["Lk"]) == pos0[:, 0] + S))
         return ph
 
     def _layers(self, ph: dict):
@@ -315,43 +309,35 @@ class QwenVLEngine:
         ops.mrope_table(ph["pos"], self.inv_freq, self.axis_of, cos, sin)
         q4 = qkv[:, : nh * hd].view(B, S, nh, hd)
         # single-token decode passes (<= 16 rows): the two RMSNorms of a layer run inside the weight-streaming GEMMs that consume them
-        # (ina_gemm_bf16 norm_gamma): 2 of the 9 launches per layer disappear from a chain that is launch / latency bound
-        fused_norm = rows <= 16 and self.fuse_decode_norm and self.tap is None
-        # thin_decode: the four weight-streaming GEMMs of a single-token pass as 4-wave / <= 96-register builds (force_cfg 60) that fit on a CU
-        # beside System-1's row-chain workgroups; same arithmetic (a column group of 4 waves, same K order per wave)
-        tcfg = (self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if self.thin_decode else 0
-        cfg = tcfg if (tcfg and self.tap is None and rows <= (self.split_rows_max if tcfg == 31 else 16)) else 0
-        if cfg not in (0, 60, 61):
-            fused_norm = False          # (the fused input norm exists in the column-owner kernels only: other forced kernels take the separate norm launch)
-        gm = 7 if (rows <= 16 and self.nt_decode) else 0     # SK_NT_FLAG: non-temporal weight stream in the column-owner GEMMs
-        # split_decode (cfg 31): the four GEMMs of a single-token pass on the split-K kernel pair (many short 256-thread workgroups that get into
-        # the gaps System-1's workgroups leave, where the 512-thread column-owner workgroups wait), whose epilogue launch owns whole output rows
-        # and hands the NEXT GEMM its pre-normed operand (post_norm): no norm launch inside the pass except the first layer's
-        chain31 = cfg == 31
+        # (ina_gemm_bf16 norm_gamma) and the rotary embedding + KV-cache append of the new token inside the attention launch
+        # (ina_attn_args.rope_cos): 5 launches per layer - q|k|v, attention, o, gate|up, down - in a chain that is launch / latency bound
+        single = rows <= 16 and self.tap is None
+        fused_norm = single and self.fuse_decode_norm
+        fuse_rope = single and self.fuse_decode_rope and ph.get("new_are_last", False) and ops.attention_rope_ok(S, ph["Lk"], nh, nkv, hd)
+        if fuse_rope:
+            kn4 = qkv[:, nh * hd:(nh + nkv) * hd].view(B, S, nkv, hd)
+            vn4 = qkv[:, (nh + nkv) * hd:].view(B, S, nkv, hd)
         for li, L in enumerate(self.layers):
             src = x_in if li == 0 else x
             wf = (lambda k, L=L: L.get(k)) if (self.frag_weights and rows > 64) else (lambda k: None)
             if fused_norm:
-                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6), force_cfg=cfg, group_m=gm)
+                ops.linear(src, L["qkv_w"], bias=L["qkv_b"], out=qkv, prenorm=(L["n1"], 1e-6))
             else:
-                if not (chain31 and li > 0):                 # (chain31: h = norm1(x) came out of the previous layer's down projection)
-                    ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"), force_cfg=cfg, group_m=gm)
-            # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
-            ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
+                ops.norm(src, L["n1"], None, eps=1e-6, rms=True, out=h)
+                ops.linear(h, L["qkv_w"], bias=L["qkv_b"], out=qkv, w_frag=wf("qkv_wf"))
+            if not fuse_rope:
+                # m-rope on q (in place) and k, and the KV-cache append (rotated k | v -> cache row of every token) in ONE launch
+                ops.rope(qkv, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=rows, kv_out=L["kv"], kv_dst=ph["rows"], kv_head0=nh, v_heads=nkv)
             kv4 = L["kv"].view(self.B_max, Smax, 2, nkv, hd)[b0:b0 + B, : ph["Lk"]]
             ops.attention(q4, kv4[:, :, 0], kv4[:, :, 1], causal=True, out=att.view(B, S, nh, hd), k_len=ph["k_len"],
-                          kernel=self.decode_attn_kernel if rows <= 16 else 0)
-            ops.linear(att, L["o_w"], residual=src, out=x, force_cfg=cfg, group_m=gm, post_norm=(L["n2"], 1e-6, h) if chain31 else None)
+                          rope=(cos, sin, kn4, vn4) if fuse_rope else None)
+            ops.linear(att, L["o_w"], residual=src, out=x)
             if fused_norm:
-                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6), force_cfg=cfg, group_m=gm)
+                ops.linear(x, L["gu_w"], act="silu", glu=True, out=ff, prenorm=(L["n2"], 1e-6))
             else:
-                if not chain31:
-                    ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
-                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"), force_cfg=cfg, group_m=gm)
-            nxt = self.layers[li + 1]["n1"] if (chain31 and li + 1 < len(self.layers)) else None
-            ops.linear(ff, L["down_w"], residual=x, out=x, force_cfg=cfg, group_m=gm, w_frag=wf("down_wf"),
-                       post_norm=(nxt, 1e-6, h) if nxt is not None else None)
+                ops.norm(x, L["n2"], None, eps=1e-6, rms=True, out=h)
+                ops.linear(h, L["gu_w"], act="silu", glu=True, out=ff, w_frag=wf("gu_wf"))
+            ops.linear(ff, L["down_w"], residual=x, out=x, w_frag=wf("down_wf"))
             if self.tap is not None:
                 self.tap("llm", li, x)
 
@@ -363,8 +349,7 @@ class QwenVLEngine:
             ops.norm(self.xl[:B], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B)
         else:
             ops.norm(self.x[: B * S], self.norm_w, None, eps=1e-6, rms=True, out=self.hl[:B], rows=B, in_map=(1, S, row_in_seq))
-        head_cfg = ((self.thin_decode if isinstance(self.thin_decode, int) and self.thin_decode > 1 else 60) if (self.thin_decode and B <= 16) else 0) if self.lm_head_cfg is None else self.lm_head_cfg
-        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B], group_m=(7 if (self.nt_decode and B <= 16) else 0), force_cfg=head_cfg)
+        ops.linear(self.hl[:B], self.lm_head, out=self.logits[:B])     # (152064 columns: one wave per 16-column tile owns all of K)
         ops.argmax_rows(self.logits[:B], self.next_tok[:B])
 
     # ---- plan / run: all host work up front, then a pure launch sequence (hipGraph capturable)

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol(built_lib):
         assert hasattr(h, name), f"{name} declared in include/internnav_amd.h but not exported"
     from internnav_amd import _lib
 
-    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_graft_entry_build_passes_on_the_current_abi(built_lib):

@@ -101,7 +101,6 @@ def test_d384_heads_and_odd_shapes(select):
 def test_weight_streaming_paths(select):
     assert select(7, QKV, H) == 32                                    # decode: fused weight-streaming kernel
     assert select(7, QKV, H, norm_gamma=0x3000, a_dtype=1) == 30      # with the input RMSNorm inside
-    assert select(7, QKV, H, force_cfg=31) == 31                      # split-K variant on request
     assert select(64, 152064, H) == 32 and select(65, 152064, H) == 11    # lm_head: 64 rows is the boundary
     assert select(7, QKV, H, force_cfg=-1) == 32                      # the shared-tail mode does not touch this path
 
@@ -114,21 +113,6 @@ def test_forced_configs_and_rejections(select):
     bad = select(300, 260, 64, force_cfg=39)               # bf16 rows of 520 bytes
     assert isinstance(bad, tuple) and "38 / 39" in bad[1]
     for bad in (select(100, 100, 63), select(7, QKV, H, force_cfg=30), select(100, 48, 64, glu=1), select(0, 4, 8),
-                select(100, 102, 64), select(17, QKV, H, norm_gamma=0x3000, a_dtype=1), select(100, 512, 64, force_cfg=31)):
+                select(100, 102, 64), select(17, QKV, H, norm_gamma=0x3000, a_dtype=1), select(100, 512, 64, force_cfg=32), select(7, QKV, H, force_cfg=31), select(7, QKV, H, force_cfg=60),
+                select(7, QKV, H, force_cfg=18, norm_gamma=0x3000, a_dtype=1)):
         assert isinstance(bad, tuple) and bad[0] == "error" and bad[1].startswith("gemm")
-
-
-def test_post_norm_hand_over_is_a_property_of_the_split_k_pair(select):
-    """ina_gemm_args.post_gamma (the next GEMM's pre-normed operand out of this GEMM's epilogue) exists in the row-owning epilogue launch of the
-    split-K kernel pair only: accepted with force_cfg = 31 (no GLU, N <= 4096), refused - not ignored - everywhere else."""
-    POST = dict(post_gamma=0x4000, post_out=0x5000, post_ld=H, out_dtype=1, R=0x2000)
-    assert select(7, H, H, force_cfg=31, **POST) == 31                     # o projection of a single-token pass
-    assert select(7, H, I, force_cfg=31, **POST) == 31                     # down projection
-    assert select(35, H, H, force_cfg=31, **POST) == 31                    # the latent-query pass' rows fit too (M <= 64)
-    for kw in (dict(force_cfg=0), dict(force_cfg=32), dict(force_cfg=60), dict(force_cfg=18)):
-        got = select(7, H, H, **kw, **POST)
-        assert got[0] == "error" and "post_gamma" in got[1], (kw, got)
-    assert select(7, 2 * I, H, force_cfg=31, post_gamma=0x4000, post_out=0x5000, post_ld=I, **GLU)[0] == "error"      # GLU epilogue
-    assert select(7, 8192, H, force_cfg=31, post_gamma=0x4000, post_out=0x5000, post_ld=8192)[0] == "error"           # wider than one workgroup's row
-    assert select(7, H, H, force_cfg=31, post_gamma=0x4000, post_ld=H)[0] == "error"                                   # no destination
-    assert select(3680, H, H, force_cfg=-1, **POST)[0] == "error"          # a prefill GEMM

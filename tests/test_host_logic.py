@@ -277,12 +277,16 @@ def test_bench_accounting_is_consistent():
     bench = importlib.import_module("bench")
     from internnav_amd import flops, synthetic
 
-    q, s = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_CFG
+    q, s = synthetic.QWEN_N1_CFG, synthetic.N1_NEXTDIT_CFG_FFN1024
     f2 = flops.s2_call_flops(920, [(1, 28, 28)] * 4, 8, q)["total"]
     f1 = flops.nextdit_s1_flops_per_env(s)["total"]
-    assert abs(f2 / 1e12 - 16.46) < 0.1 and abs(f1 / 1e12 - 0.53) < 0.02          # 16.46 / 0.53 TFLOP
+    # SURVEY 8d priced the DiT at FFN 1024 (the diffusers <= 0.32 convention): 16.46 / 0.53 TFLOP, 2.18 per policy step
+    assert abs(f2 / 1e12 - 16.46) < 0.1 and abs(f1 / 1e12 - 0.53) < 0.02
     assert abs((f1 + f2 / 10) / 1e12 - 2.18) < 0.03                                # policy step 2.18 TFLOP per env
     assert abs((f2 + 2 * f1) / 8 / 1e12 - 2.19) < 0.03                             # reference cadence: (1 S2 + 2 S1) per 8 actions
+    # FFN 1536 (diffusers 0.33.1 as pinned, the default): 12 blocks x 10 steps x 1024 rows x 3 x 2 x 384 x 512 more FLOPs per env = + 0.145 TFLOP
+    f1p = flops.nextdit_s1_flops_per_env(synthetic.N1_NEXTDIT_CFG)["total"]
+    assert abs((f1p - f1) - 12 * 10 * 1024 * 3 * 2 * 384 * 512) < 1e6 and abs((f1p + f2 / 10) / 1e12 - 2.31) < 0.03
     # the harness shape (num_history 8 + current frame, then the look-down turn with the un-resized frame): S and FLOPs grow as the prompt
     from internnav_amd.preprocess import smart_resize
     hb, wb = smart_resize(480, 640)
@@ -382,46 +386,54 @@ def test_engine_twin_shares_weights_and_owns_buffers():
 
 
 def test_single_token_pass_launch_sequence_per_variant(monkeypatch):
-    """which launches a single-token decoder pass issues, per GEMM path (recording stand-in for `ops`, CPU-resident engine, nothing is computed):
-    split-K kernel pair (31, default): ONE norm launch per pass (the first layer's input norm) - the o projection hands the post-attention norm
-    to gate|up and the down projection the next layer's input norm to q|k|v (`post_norm`), every GEMM forced to 31; column-owner kernels: no
-    norm launch, q|k|v and gate|up carry `prenorm`; column-owner kernels with norm launches: two per layer. The prefill (many rows) takes none of it."""
+    """which launches a single-token decoder pass issues (recording stand-in for `ops`, CPU-resident engine, nothing is computed). Default: 5 per
+    layer - q|k|v and gate|up carry `prenorm` (no norm launch), the attention launch carries `rope` (no rope launch); prompts shorter than the
+    decode kernel's 256 keys keep the rope launch (6); without the fused norms two more. The prefill (many rows) takes none of it."""
     from internnav_amd import qwen_vl
     from internnav_amd import synthetic as S
 
     cfg = dict(S.QWEN_TEST_CFG, v_depth=1, v_fullatt=(0,), t_layers=3)
-    eng = qwen_vl.QwenVLEngine(S.qwen_state_dict(seed=1, cfg=cfg), cfg, "cpu", max_seqs=2, max_seq_len=256, max_patches=2 * 784)
-    inp = S.qwen_inputs(2, 1, seed=1, cfg=cfg, n_text=20, n_tail=8)
+    eng = qwen_vl.QwenVLEngine(S.qwen_state_dict(seed=1, cfg=cfg), cfg, "cpu", max_seqs=2, max_seq_len=512, max_patches=2 * 784)
+    inp = S.qwen_inputs(2, 1, seed=1, cfg=cfg, n_text=60, n_tail=8)                     # 196 image tokens + text: > 256 keys from the first decode pass on
+    short = S.qwen_inputs(2, 0, seed=1, cfg=cfg, n_text=20, n_tail=8)
     P = eng.plan(inp["input_ids"], inp["grid_thw"], n_decode=3)
+    Ps = eng.plan(short["input_ids"], short["grid_thw"], n_decode=3)
     calls = []
 
     class Rec:
         def __getattr__(self, name):
+            if name == "attention_rope_ok":
+                from internnav_amd import ops
+                return ops.attention_rope_ok
+
             def f(*a, **kw):
                 calls.append((name, kw))
             return f
 
     monkeypatch.setattr(qwen_vl, "ops", Rec())
 
-    def run(ph, thin, fuse):
+    def run(ph, fuse_norm=True, fuse_rope=True):
         calls.clear()
-        eng.thin_decode, eng.fuse_decode_norm = thin, fuse
+        eng.fuse_decode_norm, eng.fuse_decode_rope = fuse_norm, fuse_rope
         eng._layers(ph)
         lin = [kw for n, kw in calls if n == "linear"]
-        return dict(norms=sum(n == "norm" for n, _ in calls), linears=len(lin), cfgs={kw.get("force_cfg", 0) for kw in lin},
-                    post=sum(kw.get("post_norm") is not None for kw in lin), pre=sum(kw.get("prenorm") is not None for kw in lin))
+        return dict(norms=sum(n == "norm" for n, _ in calls), ropes=sum(n == "rope" for n, _ in calls), linears=len(lin),
+                    cfgs={kw.get("force_cfg", 0) for kw in lin}, fused_rope=sum(kw.get("rope") is not None for n, kw in calls if n == "attention"),
+                    pre=sum(kw.get("prenorm") is not None for kw in lin), per_layer=(len(calls) - 1) / cfg["t_layers"])   # (one mrope_table launch per pass)
 
     L = cfg["t_layers"]
     one = P["decode"][0]
-    assert eng.thin_decode == 31                                         # the shipped default
-    assert run(one, 31, True) == dict(norms=1, linears=4 * L, cfgs={31}, post=2 * L - 1, pre=0)
-    assert run(one, False, True) == dict(norms=0, linears=4 * L, cfgs={0}, post=0, pre=2 * L)
-    assert run(one, False, False) == dict(norms=2 * L, linears=4 * L, cfgs={0}, post=0, pre=0)
-    assert run(one, 60, True) == dict(norms=0, linears=4 * L, cfgs={60}, post=0, pre=2 * L)
-    for thin in (31, False, 60):                                         # prefill rows: plain launches whatever the decode switch says
-        assert run(P["prefill"], thin, True) == dict(norms=2 * L, linears=4 * L, cfgs={0}, post=0, pre=0)
+    assert one["Lk"] >= 256 and eng.fuse_decode_rope and eng.fuse_decode_norm                                         # the shipped default
+    assert run(one) == dict(norms=0, ropes=0, linears=4 * L, cfgs={0}, fused_rope=L, pre=2 * L, per_layer=5)
+    assert run(one, fuse_rope=False) == dict(norms=0, ropes=L, linears=4 * L, cfgs={0}, fused_rope=0, pre=2 * L, per_layer=6)
+    assert run(Ps["decode"][0]) == dict(norms=0, ropes=L, linears=4 * L, cfgs={0}, fused_rope=0, pre=2 * L, per_layer=6)   # < 256 keys: not the decode kernel
+    assert run(one, fuse_norm=False, fuse_rope=False) == dict(norms=2 * L, ropes=L, linears=4 * L, cfgs={0}, fused_rope=0, pre=0, per_layer=8)
+    r = run(P["prefill"])                                                # many rows: norm launches, automatic tiles, rope launch
+    assert r["pre"] == 0 and r["fused_rope"] == 0 and r["norms"] == 2 * L and r["ropes"] == L
+    eng.fuse_decode_norm, eng.fuse_decode_rope = True, True
     eng.tap = lambda *a: None                                            # a parity tap reads the stream after every layer: unfused launches
-    assert run(one, 31, True)["post"] == 0 and run(one, 31, True)["norms"] == 2 * L
+    r = run(one)
+    assert r["norms"] == 2 * L and r["fused_rope"] == 0 and r["ropes"] == L
 
 
 def test_prefix_kv_plan_host_logic_on_cpu():

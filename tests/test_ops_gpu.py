@@ -502,11 +502,11 @@ def test_gemm_four_wave_tile_rejects_unaligned_rows(ops):
 SKINNY = [(7, 4608, 3584), (1, 3584, 18944), (35, 3584, 3584), (64, 18816, 384), (5, 1000, 1176), (16, 256, 128), (48, 152064, 256)]
 
 
-@pytest.mark.parametrize("cfg", [0, 31, 32])
+@pytest.mark.parametrize("cfg", [0, 32])
 @pytest.mark.parametrize("M,N,K", SKINNY)
-def test_gemm_skinny_split_k(ops, M, N, K, cfg):
-    """M <= 64 goes through the weight-streaming kernels (0 = auto = 32: column-owner kernel with fused epilogue; 31: split-K
-    partials + epilogue kernel): all epilogue terms, bf16 and f32 outputs."""
+def test_gemm_skinny_weight_streaming(ops, M, N, K, cfg):
+    """M <= 64 goes through the weight-streaming kernels (0 = auto = 32: column-owner kernel with fused epilogue): all epilogue terms, bf16 and
+    f32 outputs."""
     g = torch.Generator().manual_seed(M + N + K)
     x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
     bias, cs = torch.randn(N, generator=g).to(_dev()), torch.randn(N, generator=g).to(_dev())
@@ -520,7 +520,7 @@ def test_gemm_skinny_split_k(ops, M, N, K, cfg):
     _close(same, out_b.float(), rtol=1.0 / 64, atol=3e-2)
 
 
-@pytest.mark.parametrize("cfg,M", [(0, 7), (31, 7), (32, 7), (32, 35), (32, 64)])
+@pytest.mark.parametrize("cfg,M", [(0, 7), (32, 7), (32, 35), (32, 64)])
 def test_gemm_skinny_glu(ops, cfg, M):
     g = torch.Generator().manual_seed(66)
     K, I = 3584, 2048
@@ -564,36 +564,35 @@ def test_gemm_skinny_fused_input_rmsnorm(ops, M, N, K, glu, xdt):
         ops.linear(torch.zeros(17, K, device=_dev()), w, prenorm=(gamma, 1e-6))      # built for <= 16 rows
 
 
-@pytest.mark.parametrize("M,N,K,res", [(7, 3584, 3584, "f32"), (7, 3584, 18944, "f32"), (35, 3584, 3584, "f32"), (5, 1024, 512, None), (1, 4096, 256, "bf16")])
-def test_gemm_split_k_epilogue_hands_over_the_next_prenorm(ops, M, N, K, res):
-    """split-K kernel pair (force_cfg 31) with post_norm: its epilogue launch owns whole output rows and writes bf16(rmsnorm(out) * gamma) beside the
-    output - the operand of the next GEMM of a single-token decoder pass. The output itself is bit-equal to the plain pair, the handed-over row
-    equals the norm launch it replaces up to bf16 flips where the row statistic's summation order rounds differently."""
-    g = torch.Generator().manual_seed(M + N + K)
-    x, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
-    gamma = (1.0 + 0.1 * torch.randn(N, generator=g)).to(_dev())
-    bias = torch.randn(N, generator=g).to(_dev())
-    kw = dict(bias=bias)
-    odt = torch.bfloat16
-    if res == "f32":
-        kw["residual"], odt = torch.randn(M, N, generator=g).to(_dev()) * 3.0, torch.float32
-    elif res == "bf16":
-        kw["residual"] = _rand((M, N), g)
-    plain = ops.linear(x, w, force_cfg=31, out_dtype=odt, **kw)
-    hw = torch.full((M, N + 8), 7.0, dtype=torch.bfloat16, device=_dev())
-    h = hw[:, :N]
-    out = ops.linear(x, w, force_cfg=31, out_dtype=odt, post_norm=(gamma, 1e-6, h), **kw)
+@pytest.mark.parametrize("B,Lq,Lk", [(7, 1, 921), (1, 1, 300), (16, 1, 1024), (2, 4, 500)])
+def test_decode_attention_with_rope_and_kv_append(ops, B, Lq, Lk):
+    """single-token decoder passes: the attention launch rotates q, rotates the new tokens' keys into the cache, copies their values there and
+    attends (ina_attn_args.rope_cos) - outputs and cache rows bit-equal to rope launch (ops.rope kv_out) + attention launch."""
+    nh, nkv, hd, Smax = 28, 4, 128, 1100
+    g = torch.Generator().manual_seed(B * 100 + Lq + Lk)
+    qkv = _rand((B * Lq, (nh + 2 * nkv) * hd), g)
+    cache = _rand((B * Smax, 2 * nkv * hd), g)
+    ang = torch.rand(B * Lq, hd // 2, generator=g) * 6.28
+    cos, sin = torch.cat([ang.cos(), ang.cos()], 1).to(_dev()).contiguous(), torch.cat([ang.sin(), ang.sin()], 1).to(_dev()).contiguous()
+    dst = (torch.arange(B)[:, None] * Smax + (Lk - Lq) + torch.arange(Lq)[None]).reshape(-1).to(torch.int32).to(_dev())
+    # two launches
+    qkv_a, cache_a = qkv.clone(), cache.clone()
+    ops.rope(qkv_a, cos, sin, heads=nh + nkv, D=hd, col0=0, rows=B * Lq, kv_out=cache_a, kv_dst=dst, kv_head0=nh, v_heads=nkv)
+    kv_a = cache_a.view(B, Smax, 2, nkv, hd)[:, :Lk]
+    out_a = ops.attention(qkv_a[:, : nh * hd].view(B, Lq, nh, hd), kv_a[:, :, 0], kv_a[:, :, 1], causal=True)
+    # one launch
+    assert ops.attention_rope_ok(Lq, Lk, nh, nkv, hd)
+    qkv_b, cache_b = qkv.clone(), cache.clone()
+    kv_b = cache_b.view(B, Smax, 2, nkv, hd)[:, :Lk]
+    out_b = ops.attention(qkv_b[:, : nh * hd].view(B, Lq, nh, hd), kv_b[:, :, 0], kv_b[:, :, 1], causal=True,
+                          rope=(cos, sin, qkv_b[:, nh * hd:(nh + nkv) * hd].view(B, Lq, nkv, hd), qkv_b[:, (nh + nkv) * hd:].view(B, Lq, nkv, hd)))
     torch.cuda.synchronize()
-    assert torch.equal(out, plain)
-    assert float(hw[:, N:].min()) == 7.0, "columns beyond the row were written"
-    y = x.float() @ w.float().t() + bias + (kw["residual"].float() if res else 0.0)
-    _close(h, y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma, rtol=1.0 / 128, atol=2e-2)
-    if res == "f32":                                                   # the launch it replaces reads the same fp32 row
-        two = ops.norm(plain, gamma, None, eps=1e-6, rms=True)
-        d = (h.float() - two.float()).abs()
-        assert d.max().item() <= 2.0 ** -6 * max(1.0, two.float().abs().max().item()) and (d > 0).float().mean().item() < 0.02
-    with pytest.raises(RuntimeError, match="post_gamma"):
-        ops.linear(x, w, post_norm=(gamma, 1e-6, h), out_dtype=odt, **kw)      # any other kernel
+    assert torch.equal(cache_b, cache_a), f"cache rows differ in {(cache_b != cache_a).sum().item()} elements"
+    assert torch.equal(out_b, out_a), (out_b.float() - out_a.float()).abs().max().item()
+    assert torch.equal(qkv_b, qkv)                                       # the projection buffer is read only
+    with pytest.raises(Exception, match="rope"):                         # a shape that is not the one-launch decode kernel's: refused, not ignored
+        ops.attention(qkv_b[:, : nh * hd].view(B, Lq, nh, hd), kv_b[:, :100, 0], kv_b[:, :100, 1], causal=True,
+                      rope=(cos, sin, qkv_b[:, nh * hd:(nh + nkv) * hd].view(B, Lq, nkv, hd), qkv_b[:, (nh + nkv) * hd:].view(B, Lq, nkv, hd)))
 
 
 DECODE = [
@@ -993,36 +992,3 @@ def test_dit_rowchain_rejects_what_it_does_not_compute(ops):
         ops.dit_rowchain(a, w1, g1, torch.zeros(200, 384, device=_dev()))
 
 
-@pytest.mark.parametrize("M,N,K,glu,prenorm", [(7, 4608, 3584, False, True), (7, 37888, 3584, True, True), (7, 3584, 3584, False, False), (7, 3584, 18944, False, False),
-                                                (5, 3584, 3584, False, False), (16, 512, 1024, False, True), (1, 4608, 3584, False, True)])
-def test_gemm_skinny_thin_builds(ops, M, N, K, glu, prenorm):
-    """force_cfg 60: the decode passes' weight-streaming GEMMs as 4-wave / <= 96-register builds (they fit on a CU beside System-1's row-chain
-    workgroups). Same operation as the default builds: against the fp32 formula and against the default kernel on the same problem, with
-    and without the fused input RMSNorm, bias / fp32 residual epilogues, the SwiGLU form."""
-    g = torch.Generator().manual_seed(M * 7 + N + K)
-    w = _rand((N, K), g, scale=K ** -0.5)
-    if prenorm:
-        x = (torch.randn(M, K, generator=g) * 3.0).to(_dev())
-        gamma = (1.0 + 0.1 * torch.randn(K, generator=g)).to(_dev())
-        kw = dict(prenorm=(gamma, 1e-6))
-        xn = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma).bfloat16().float()
-    else:
-        x = _rand((M, K), g)
-        kw = {}
-        xn = x.float()
-    y = xn @ w.float().t()
-    if glu:
-        y4 = y.view(M, N // 32, 2, 16)
-        ref = (torch.nn.functional.silu(y4[:, :, 0]) * y4[:, :, 1]).reshape(M, N // 2)
-        thin = ops.linear(x, w, act="silu", glu=True, force_cfg=60, **kw)
-        dflt = ops.linear(x, w, act="silu", glu=True, **kw)
-    else:
-        bias, res = torch.randn(N, generator=g).to(_dev()), torch.randn(M, N, generator=g).to(_dev())
-        ref = y + bias + res
-        thin = ops.linear(x, w, bias=bias, residual=res, out_dtype=torch.float32, force_cfg=60, **kw)
-        dflt = ops.linear(x, w, bias=bias, residual=res, out_dtype=torch.float32, **kw)
-    torch.cuda.synchronize()
-    _close(thin, ref, rtol=4e-3, atol=1e-2)
-    assert (thin.float() - dflt.float()).abs().max().item() <= 2e-2        # another split of K over the waves: fp32 summation order only
-    with pytest.raises(Exception):
-        ops.linear(_rand((17, K), g), w, force_cfg=60)                      # built for <= 16 rows

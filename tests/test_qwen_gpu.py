@@ -90,29 +90,34 @@ def test_prefill_logits_greedy_tokens_and_latents(setup):
 
 
 def test_single_token_pass_variants_agree(setup):
-    """the GEMM paths of the single-token passes - split-K kernel pair with the norm handed over by its row-owning epilogue (31, default),
-    column-owner kernels with the fused input norm (False, round 4), the same with separate norm launches - give the same greedy tokens and
-    logits that differ by bf16 summation-order noise only."""
+    """the single-token passes with the rotary embedding + KV-cache append inside the attention launch (default) and with the rope launch of their
+    own are BIT-IDENTICAL - same arithmetic, same rounding points - in tokens, logits, latent queries and the appended cache rows. The variant
+    with separate norm launches differs by rounding noise only (same tokens)."""
     gold, cfg, inp, eng = setup
     pv = inp["pixel_values"].to(DEV, torch.bfloat16)
-    keep = (eng.thin_decode, eng.fuse_decode_norm)
+    keep = (eng.fuse_decode_norm, eng.fuse_decode_rope)
     res = {}
     try:
-        for name, td, fuse in (("split_k_post_norm", 31, True), ("column_owner_fused_norm", False, True), ("column_owner_norm_launches", False, False)):
-            eng.thin_decode, eng.fuse_decode_norm = td, fuse
+        for name, fuse, rope in (("rope_in_attention", True, True), ("rope_launch", True, False), ("norm_launches", False, False)):
+            eng.fuse_decode_norm, eng.fuse_decode_rope = fuse, rope
             state = eng.prefill(inp["input_ids"], pv, inp["grid_thw"])
             toks = eng.decode(state, 4)
             lat = eng.latents(state, toks[:, -1:].contiguous())
-            res[name] = (toks.cpu(), eng.logits[: state["B"]].float().cpu().clone(), lat.float().cpu())
+            S = inp["input_ids"].shape[1]
+            assert S >= 256, "the fixture's prompts reach the decode attention kernel"
+            kv = torch.stack([L["kv"].view(eng.B_max, eng.S_max, -1)[: state["B"], S:S + 3].float().cpu() for L in eng.layers])
+            res[name] = (toks.cpu(), eng.logits[: state["B"]].float().cpu().clone(), lat.float().cpu(), kv)
     finally:
-        eng.thin_decode, eng.fuse_decode_norm = keep
-    base = res["column_owner_norm_launches"]
+        eng.fuse_decode_norm, eng.fuse_decode_rope = keep
+    base = res["rope_launch"]
+    for what, x, y in zip(("tokens", "logits", "latents", "decoded K/V rows"), res["rope_in_attention"], base):
+        assert torch.equal(x, y), f"rope inside the attention launch: {what} differ (max |d| {(x.float() - y.float()).abs().max().item():.3e})"
     scale = base[1].std().item()
-    for name, (toks, logits, lat) in res.items():
-        assert torch.equal(toks, base[0]), (name, toks.tolist(), base[0].tolist())
-        d = (logits - base[1]).abs()
-        assert d.mean().item() < 2e-3 * scale and d.max().item() < 3e-2 * scale, (name, d.mean().item(), d.max().item(), scale)
-        assert (lat - base[2]).abs().mean().item() < 4e-3 * base[2].pow(2).mean().sqrt().item(), name
+    toks, logits, lat, _ = res["norm_launches"]
+    assert torch.equal(toks, base[0])
+    d = (logits - base[1]).abs()
+    assert d.mean().item() < 2e-3 * scale and d.max().item() < 3e-2 * scale, (d.mean().item(), d.max().item(), scale)
+    assert (lat - base[2]).abs().mean().item() < 4e-3 * base[2].pow(2).mean().sqrt().item()
 
 
 def test_generate_surface(setup):
