@@ -67,6 +67,9 @@ def parse():
                     help="n1_dual: FFN width of the NextDiT trajectory head - 1536 = the reference's `LuminaFeedForward(dim, inner_dim=4 * dim)` under its "
                          "pinned diffusers 0.33.1 (default), 1024 = the same call under diffusers <= 0.32 (what rounds 1-5 timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="n1_dual, N = 1: skip the 10-step timings of the exact schedule variants (--prefix-kv, --s2-every 2) and of the other FFN width "
+                         "that follow the headline measurement and are reported under `variants` of the same JSON line")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (debug)")
     ap.add_argument("--no-overlap", action="store_true", help="n1_dual: run System-2 and System-1 back to back on one stream")
     ap.add_argument("--vit-cache", action="store_true",
@@ -101,7 +104,7 @@ def default_args(**kw):
     """the parsed defaults as a namespace (tools/ construct workloads without a command line)"""
     a = argparse.Namespace(gpus=1, steps=20, warmup=3, envs=64, workload="n1_dual", cadence="nominal", num_history=3, lookdown=False, no_cpu_baseline=True, dit_ffn=1536,
                            no_graph=False, no_overlap=False, vit_cache=False, prefix_kv=False, no_split_prefill=False, s2_every=1, no_row_chain=False,
-                           no_frag_weights=False, no_fuse_decode_rope=False, rest=[])
+                           no_frag_weights=False, no_fuse_decode_rope=False, no_variants=True, rest=[])
     for k, v in kw.items():
         assert hasattr(a, k), k
         setattr(a, k, v)
@@ -417,7 +420,7 @@ class N1Dual:
                                 + ("(= the reference's LuminaFeedForward(dim, inner_dim=4*dim) under its pinned diffusers 0.33.1; unverified against a released checkpoint)"
                                    if scfg["dit_ffn"] == 1536 else "(= the diffusers <= 0.32 convention of LuminaFeedForward; rounds 1-5 timed this width)")) if self.with_s1 else "none",
                      "s1": ("2 look-down frames @224x224, 32 samples x 10 flow-matching steps" + ("" if getattr(a, "no_row_chain", False) else
-                            f"; row-local chain of every DiT block in two launches (dit_rowchain, {int(getattr(a, 'chain_waves', 4)) * 32}-row panels)")) if self.with_s1 else "none",
+                            "; row-local chain of every DiT block in two launches (dit_rowchain, 128-row panels)")) if self.with_s1 else "none",
                      "s2_microbatches_per_period": self.mb, "s2_every": self.s2_every, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
         self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
@@ -482,7 +485,7 @@ class N1Dual:
             from internnav_amd.nextdit import NextDiTSystem1
             from internnav_amd.policy import _Prefixed
 
-            self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax, fuse_rownorm=bool(getattr(a, "fuse_rownorm", False)))
+            self.s1_small = NextDiTSystem1(_Prefixed(weights, "model."), scfg, dev, max_envs=mmax)
             # the look-down pairs of the System-2 envs go through the side stream's encoder pass (DINOv2, MemoryEncoder, QFormer over all 64 envs at
             # once) and only their 32 memory tokens travel to the small engine: the latency-bound encoder chain (~180 launches) leaves the main
             # chain, 302.5 / 303.0 -> 305.6 policy steps/s on one box (profiles/r04o_bench_s1_variants.log; the row-norm epilogue in the small
@@ -880,6 +883,42 @@ def n1_cpu_baseline(qc, grids, pv_rows, ids, n_decode, cadence, with_s1, unit, d
                            + f"; combined as {how}"}, **out)
 
 
+def n1_variants(a, dev, steps: int = 10, warmup: int = 3) -> dict:
+    """the headline workload under its two EXACT schedule variants and at the other FFN width, `steps` timed steps each on this same box, for
+    the driver's record (the headline `value` is not touched): prefix_kv = K/V of template + instruction + frame 0 from a per-env cache
+    (--prefix-kv: causal attention, bit-exact), s2_every2 = System-2 micro-batches of 12-14 envs on every other step (--s2-every 2: same calls per
+    env, the single-token passes stream the decoder weights half as often; worse step-latency spread), dit_ffn_1024 = the NextDiT FFN of the
+    diffusers <= 0.32 convention (what rounds 1-5 timed)."""
+    import copy
+    import gc
+
+    out = {}
+    for name, kw in (("prefix_kv", dict(prefix_kv=True)), ("s2_every2", dict(s2_every=2)), ("dit_ffn_1024", dict(dit_ffn=1024))):
+        b = copy.copy(a)
+        for k, v in kw.items():
+            setattr(b, k, v)
+        gc.collect()
+        torch.cuda.empty_cache()
+        w = N1Dual(b, dev, 0)
+        w.capture()
+        for i in range(warmup):
+            w.step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        marks = [t0]
+        for i in range(steps):
+            w.step(warmup + i)
+            marks.append(time.perf_counter())
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lat = np.diff(np.asarray(marks)) * 1e3
+        out[name] = {"value": round(w.B * steps / dt, 2), "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+                     "p50": round(float(np.percentile(lat, 50)), 2), "max": round(float(lat.max()), 2), "workload": w.name,
+                     "algorithmic_tflop_per_env_step": round(w.f_alg / 1e12, 4)}
+        del w
+    return out
+
+
 def _median_time(fn, runs: int, autocast: bool = False) -> float:
     """wall-clock of fn(): one untimed warm-up, then the median of `runs` runs (>= 3 runs after warm-up)."""
     ts = []
@@ -1088,6 +1127,11 @@ def main():
             line["config"]["schedule_check"] = {"max_abs_diff_vs_single_stream": round(overlap_check[0], 5), "traj_abs_max": round(overlap_check[1], 3)}
         # the CPU port of the reference path is timed on rank 0 of a single-GPU run only (contract); the key is always present
         line["cpu_baseline"] = wl.cpu_baseline() if (world == 1 and not a.no_cpu_baseline) else None
+        plain = (a.workload == "n1_dual" and a.cadence == "nominal" and not (a.prefix_kv or a.vit_cache or a.lookdown or a.no_graph or a.no_overlap) and
+                 a.s2_every == 1 and a.num_history == 3 and a.dit_ffn == 1536)
+        if world == 1 and plain and not a.no_variants:
+            del wl
+            line["variants"] = n1_variants(a, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

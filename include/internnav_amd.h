@@ -38,7 +38,7 @@ int ina_abi_version(void);
 const char* ina_last_error(void);
 /* Fails (non-zero) unless a gfx950 device is current; fills name[0..n) with the arch string. */
 int ina_device_check(char* name, int n);
-/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn, 20 gn_mish, 21 pad_rows, 22 ddim_step, 23 ew, 24 colsum, 25 norm_bwd, 26 transpose, 27 sparse_rows, 28 small_linear, 29 mse, 30 adamw, 31 gemm_nn, 32 attn_bwd, 33 dit_rowchain):
+/* sizeof() of the k-th argument struct below (0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 resize_u8, 15 qwen_patchify, 16 u8_lut, 17 resize_f32, 18 gn_mish, 19 pad_rows, 20 ddim_step, 21 ew, 22 colsum, 23 norm_bwd, 24 transpose, 25 sparse_rows, 26 small_linear, 27 mse, 28 adamw, 29 gemm_nn, 30 attn_bwd, 31 dit_rowchain):
  * lets a binding verify its struct mirrors against the compiled layout. */
 int ina_struct_size(int k);
 /* Per-launch timing for the benchmark's roofline line: while enabled every launch is bracketed by a hipEvent pair on its
@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 38 / 39 = gemm_bf16_w4_kernel<256, 0|1> (four-wave 256x256 tile), 40 = dit_ffn_kernel, 41 = gemm_rownorm_kernel, 42 = dit_rowchain_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 38 / 39 = gemm_bf16_w4_kernel<256, 0|1> (four-wave 256x256 tile), 40 = gemm_bf16_w4p_kernel<256> (the same tile on fragment-ordered weights), 42 = dit_rowchain_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
@@ -380,50 +380,6 @@ typedef struct ina_u8_lut_args {
 } ina_u8_lut_args;
 int ina_u8_lut(const ina_u8_lut_args* args, void* stream);
 
-/* ---- gemm_rownorm: row-block GEMM (N = 384) with the NextDiT gated-norm / residual / next-pre-norm epilogue:
- *          P = A . W^T ;  X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma ;  H = rmsnorm(X) * gamma2 * (1 + mod_scale2[r/mod_div])
- *      replaces attn2.to_out / feed_forward.linear_2 + norm2 / ffn_norm2 + gate + residual + ffn_norm1 / next norm1 of diffusers'
- *      LuminaNextDiTBlock.forward (diffusers==0.33.1) as wired by nextdit_traj.py:121-188; the projection stays fp32 on chip. */
-typedef struct ina_gemm_rownorm_args {
-    const void* A;          /* bf16 [M,K], row stride lda */
-    const void* W;          /* bf16 [N,K], row stride ldw */
-    const float* gamma;     /* f32 [N] RMSNorm weight on the projection */
-    const float* gate;      /* f32 [M/mod_div, mod_ld] (tanh applied) or NULL */
-    float* X;               /* f32 [M,N] residual stream, updated in place, row stride ldx */
-    void* H;                /* bf16 [M,N] pre-norm output or NULL, row stride ldh */
-    const float* gamma2;    /* f32 [N] or NULL */
-    const float* mod_scale2;/* f32 [M/mod_div, mod_ld] or NULL */
-    int32_t M, N, K;
-    int32_t lda, ldw, ldx, ldh;
-    int32_t mod_div, mod_ld;
-    float eps;
-} ina_gemm_rownorm_args;
-int ina_gemm_rownorm_bf16(const ina_gemm_rownorm_args* args, void* stream);
-
-/* ---- dit_ffn: the SwiGLU feed-forward of one NextDiT block (dim 384) in one launch, F never leaves the chip:
- *          F = silu(A . W1^T) * (A . W3^T) ;  P = F . W2^T ;  X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma ;
- *          H = rmsnorm(X) * gamma2 * (1 + mod_scale2[r/mod_div])
- *      replaces feed_forward.linear_1/3 + SiLU gate + linear_2 + ffn_norm2 + gate + residual + the next block's norm1 of diffusers'
- *      LuminaNextDiTBlock.forward / LuminaFeedForward (diffusers==0.33.1) as wired by nextdit_traj.py:121-188.
- *      W13 = linear_1 / linear_3 rows interleaved in 16-row blocks [gate16 | up16] (the GLU layout of ina_gemm_bf16). H may alias A. */
-typedef struct ina_dit_ffn_args {
-    const void* A;          /* bf16 [M,D] pre-normed input, row stride lda */
-    const void* W13;        /* bf16 [2F,D], row stride ldw13 */
-    const void* W2;         /* bf16 [D,F], row stride ldw2 */
-    const float* gamma;     /* f32 [D] RMSNorm weight on the projection (ffn_norm2) */
-    const float* gate;      /* f32 [M/mod_div, mod_ld] (tanh applied) or NULL */
-    float* X;               /* f32 [M,D] residual stream, updated in place, row stride ldx */
-    void* H;                /* bf16 [M,D] next pre-norm output or NULL, row stride ldh */
-    const float* gamma2;    /* f32 [D] or NULL */
-    const float* mod_scale2;/* f32 [M/mod_div, mod_ld] or NULL */
-    int32_t M, D, F;
-    int32_t lda, ldw13, ldw2, ldx, ldh;
-    int32_t mod_div, mod_ld;
-    float eps;
-    int32_t rotate;         /* 1: workgroup b starts at F chunk b % (F/128) (spreads the concurrent workgroups over the weight lines) */
-} ina_dit_ffn_args;
-int ina_dit_ffn(const ina_dit_ffn_args* args, void* stream);
-
 /* ---- dit_rowchain (round 5): everything of a NextDiT block between two attention stages that is local to a row, in one launch:
  *          P  = A . W1^T (bf16)                                     attn2.to_out (K1 = 384) / feed_forward.linear_2 (K1 = 1024)
  *          X += tanh(gate[r/mod_div]) * rmsnorm(P) * gamma1         norm2 / ffn_norm2 + gate + residual (fp32, in place)
@@ -432,7 +388,7 @@ int ina_dit_ffn(const ina_dit_ffn_args* args, void* stream);
  *      replaces GEMM + norm launch + GEMM of diffusers' LuminaNextDiTBlock.forward (diffusers==0.33.1) as wired by
  *      nextdit_traj.py:121-178: the projection and H stay in registers. W2 == NULL: no second GEMM (the last block); H != NULL
  *      additionally writes H (bf16) to memory. Built pairs: (K1 = 384, glu2 = 1) and (K1 = 1024, glu2 = 0); N = 384 fixed.
- *      M and mod_div must be multiples of the row panel (128 rows; 256 with waves = 8). */
+ *      M and mod_div must be multiples of the 128-row panel. */
 typedef struct ina_dit_rowchain_args {
     const void* A;          /* bf16 [M,K1], row stride lda */
     const void* W1;         /* bf16 [384,K1], row stride ldw1 */
@@ -449,7 +405,7 @@ typedef struct ina_dit_rowchain_args {
     int32_t glu2;
     int32_t mod_div, mod_ld;
     float eps;
-    int32_t waves;          /* 0 / 4: 128-row panels, two workgroups per CU; 8: 256-row panels */
+    int32_t _reserved;      /* 0 */
     float* seg_stats;       /* f32 [M][N2/384][mean, rstd] or NULL (plain second GEMM, N2 % 384 == 0): LayerNorm statistics (eps seg_eps) of every
                              * 384-wide segment of the C2 rows, from the fp32 accumulators - what ina_dit_attn_args.stats consumes */
     float seg_eps;

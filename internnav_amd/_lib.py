@@ -149,33 +149,13 @@ class DitAttnArgs(C.Structure):
     ]
 
 
-class GemmRownormArgs(C.Structure):
-    _fields_ = [
-        ("A", c_void_p), ("W", c_void_p), ("gamma", c_void_p), ("gate", c_void_p), ("X", c_void_p), ("H", c_void_p),
-        ("gamma2", c_void_p), ("mod_scale2", c_void_p),
-        ("M", c_int32), ("N", c_int32), ("K", c_int32),
-        ("lda", c_int32), ("ldw", c_int32), ("ldx", c_int32), ("ldh", c_int32),
-        ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float),
-    ]
-
-
-class DitFfnArgs(C.Structure):
-    _fields_ = [
-        ("A", c_void_p), ("W13", c_void_p), ("W2", c_void_p), ("gamma", c_void_p), ("gate", c_void_p), ("X", c_void_p), ("H", c_void_p),
-        ("gamma2", c_void_p), ("mod_scale2", c_void_p),
-        ("M", c_int32), ("D", c_int32), ("F", c_int32),
-        ("lda", c_int32), ("ldw13", c_int32), ("ldw2", c_int32), ("ldx", c_int32), ("ldh", c_int32),
-        ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("rotate", c_int32),
-    ]
-
-
 class DitRowchainArgs(C.Structure):
     _fields_ = [
         ("A", c_void_p), ("W1", c_void_p), ("gamma1", c_void_p), ("gate", c_void_p), ("X", c_void_p), ("gamma2", c_void_p),
         ("mod_scale2", c_void_p), ("H", c_void_p), ("W2", c_void_p), ("C2", c_void_p),
         ("M", c_int32), ("K1", c_int32), ("N2", c_int32),
         ("lda", c_int32), ("ldw1", c_int32), ("ldx", c_int32), ("ldh", c_int32), ("ldw2", c_int32), ("ldc2", c_int32),
-        ("glu2", c_int32), ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("waves", c_int32),
+        ("glu2", c_int32), ("mod_div", c_int32), ("mod_ld", c_int32), ("eps", c_float), ("_reserved", c_int32),
         ("seg_stats", c_void_p), ("seg_eps", c_float), ("_pad", c_int32),
     ]
 
@@ -308,12 +288,10 @@ SYMBOLS = {
     "ina_mrope_table": (C.c_int, [C.POINTER(MropeTableArgs), c_void_p]),
     "ina_argmax_rows": (C.c_int, [C.POINTER(ArgmaxArgs), c_void_p]),
     "ina_dit_attention": (C.c_int, [C.POINTER(DitAttnArgs), c_void_p]),
-    "ina_gemm_rownorm_bf16": (C.c_int, [C.POINTER(GemmRownormArgs), c_void_p]),
     "ina_resize_u8": (C.c_int, [C.POINTER(ResizeU8Args), c_void_p]),
     "ina_qwen_patchify_u8": (C.c_int, [C.POINTER(QwenPatchifyArgs), c_void_p]),
     "ina_u8_lut": (C.c_int, [C.POINTER(U8LutArgs), c_void_p]),
     "ina_resize_f32": (C.c_int, [C.POINTER(ResizeF32Args), c_void_p]),
-    "ina_dit_ffn": (C.c_int, [C.POINTER(DitFfnArgs), c_void_p]),
     "ina_dit_rowchain": (C.c_int, [C.POINTER(DitRowchainArgs), c_void_p]),
     "ina_gn_mish": (C.c_int, [C.POINTER(GnMishArgs), c_void_p]),
     "ina_pad_rows": (C.c_int, [C.POINTER(PadRowsArgs), c_void_p]),

@@ -178,8 +178,7 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
     return ina_launch_norm(*args, reinterpret_cast<hipStream_t>(stream));
 }
 
-/* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify,
- * 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 gemm_rownorm, 15 resize_u8, 16 qwen_patchify, 17 u8_lut, 18 resize_f32, 19 dit_ffn */
+/* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 resize_u8, 15 qwen_patchify, 16 u8_lut, 17 resize_f32, 18 gn_mish, 19 pad_rows, 20 ddim_step, 21 ew, 22 colsum, 23 norm_bwd, 24 transpose, 25 sparse_rows, 26 small_linear, 27 mse, 28 adamw, 29 gemm_nn, 30 attn_bwd, 31 dit_rowchain */
 int ina_struct_size(int k) {
     switch (k) {
         case 0: return (int)sizeof(ina_gemm_args);
@@ -196,26 +195,24 @@ int ina_struct_size(int k) {
         case 11: return (int)sizeof(ina_mrope_table_args);
         case 12: return (int)sizeof(ina_argmax_args);
         case 13: return (int)sizeof(ina_dit_attn_args);
-        case 14: return (int)sizeof(ina_gemm_rownorm_args);
-        case 15: return (int)sizeof(ina_resize_u8_args);
-        case 16: return (int)sizeof(ina_qwen_patchify_args);
-        case 17: return (int)sizeof(ina_u8_lut_args);
-        case 18: return (int)sizeof(ina_resize_f32_args);
-        case 19: return (int)sizeof(ina_dit_ffn_args);
-        case 20: return (int)sizeof(ina_gn_mish_args);
-        case 21: return (int)sizeof(ina_pad_rows_args);
-        case 22: return (int)sizeof(ina_ddim_step_args);
-        case 23: return (int)sizeof(ina_ew_args);
-        case 24: return (int)sizeof(ina_colsum_args);
-        case 25: return (int)sizeof(ina_norm_bwd_args);
-        case 26: return (int)sizeof(ina_transpose_args);
-        case 27: return (int)sizeof(ina_sparse_rows_args);
-        case 28: return (int)sizeof(ina_small_linear_args);
-        case 29: return (int)sizeof(ina_mse_args);
-        case 30: return (int)sizeof(ina_adamw_args);
-        case 31: return (int)sizeof(ina_gemm_nn_args);
-        case 32: return (int)sizeof(ina_attn_bwd_args);
-        case 33: return (int)sizeof(ina_dit_rowchain_args);
+        case 14: return (int)sizeof(ina_resize_u8_args);
+        case 15: return (int)sizeof(ina_qwen_patchify_args);
+        case 16: return (int)sizeof(ina_u8_lut_args);
+        case 17: return (int)sizeof(ina_resize_f32_args);
+        case 18: return (int)sizeof(ina_gn_mish_args);
+        case 19: return (int)sizeof(ina_pad_rows_args);
+        case 20: return (int)sizeof(ina_ddim_step_args);
+        case 21: return (int)sizeof(ina_ew_args);
+        case 22: return (int)sizeof(ina_colsum_args);
+        case 23: return (int)sizeof(ina_norm_bwd_args);
+        case 24: return (int)sizeof(ina_transpose_args);
+        case 25: return (int)sizeof(ina_sparse_rows_args);
+        case 26: return (int)sizeof(ina_small_linear_args);
+        case 27: return (int)sizeof(ina_mse_args);
+        case 28: return (int)sizeof(ina_adamw_args);
+        case 29: return (int)sizeof(ina_gemm_nn_args);
+        case 30: return (int)sizeof(ina_attn_bwd_args);
+        case 31: return (int)sizeof(ina_dit_rowchain_args);
         default: return -1;
     }
 }
@@ -235,13 +232,11 @@ INA_ENTRY(ina_gather_rows, ina_gather_args, ina_launch_gather)
 INA_ENTRY(ina_rope_bf16, ina_rope_args, ina_launch_rope)
 INA_ENTRY(ina_mrope_table, ina_mrope_table_args, ina_launch_mrope_table)
 INA_ENTRY(ina_dit_attention, ina_dit_attn_args, ina_launch_dit_attention)
-INA_ENTRY(ina_gemm_rownorm_bf16, ina_gemm_rownorm_args, ina_launch_gemm_rownorm)
 INA_ENTRY(ina_resize_u8, ina_resize_u8_args, ina_launch_resize_u8)
 INA_ENTRY(ina_qwen_patchify_u8, ina_qwen_patchify_args, ina_launch_qwen_patchify_u8)
 INA_ENTRY(ina_u8_lut, ina_u8_lut_args, ina_launch_u8_lut)
 INA_ENTRY(ina_resize_f32, ina_resize_f32_args, ina_launch_resize_f32)
 INA_ENTRY(ina_argmax_rows, ina_argmax_args, ina_launch_argmax)
-INA_ENTRY(ina_dit_ffn, ina_dit_ffn_args, ina_launch_dit_ffn)
 INA_ENTRY(ina_dit_rowchain, ina_dit_rowchain_args, ina_launch_dit_rowchain)
 INA_ENTRY(ina_gn_mish, ina_gn_mish_args, ina_launch_gn_mish)
 INA_ENTRY(ina_pad_rows, ina_pad_rows_args, ina_launch_pad_rows)

@@ -116,7 +116,7 @@ int ina_workspace(int kind, size_t bytes, hipStream_t stream, float** out);
 // launch stream around its kernel and tallies the algorithmic FLOPs / bytes of that launch. bench.py reads the totals per
 // kernel class for the live roofline line; disabled (the default) it costs one branch. Not usable under graph capture.
 enum : int { INA_PROF_GEMM = 0, INA_PROF_ATTN = 1, INA_PROF_NORM = 2, INA_PROF_ELEMENTWISE = 3, INA_PROF_GEMM_SKINNY = 4, INA_PROF_KINDS = 5 };
-// sub-tag of the NEXT profiled launch of this thread (the GEMM tile config id; 40 = dit_ffn, 41 = gemm_rownorm): lets bench.py tally one
+// sub-tag of the NEXT profiled launch of this thread (the GEMM tile config id; 42 = dit_rowchain): lets bench.py tally one
 // named kernel on its own (ina_prof_read_sub). Consumed (reset to 0) by the next InaProfScope.
 void ina_prof_set_sub(int sub);
 struct InaProfScope {

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dit_rowchain_kernel(ina_dit_rowcha
     constexpr int NS = RC_NS, BN = RC_BN, STAGE = RC_STAGE, D = RC_D, NT1 = RC_NT1, KC2 = RC_KC2;
     constexpr int INST = 16 / NW;                         // 1 KiB DMA wave-instructions per wave and stage
     constexpr int NST = GLU2 ? 4 : 8;                     // store instructions per wave and column tile of GEMM 2
-    static_assert(KC1 % 2 == 0 && (NW == 4 || NW == 8), "the A double buffer alternates per k chunk across column tiles");
+    static_assert(KC1 % 2 == 0 && NW == 4, "the A double buffer alternates per k chunk across column tiles; a workgroup is four 32-row waves");
     extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
     bf16* Ws = reinterpret_cast<bf16*>(smem_raw);         // [NS][128][64]
     float* tab = reinterpret_cast<float*>(Ws + NS * STAGE);   // [2][384]: gamma1 * tanh(gate[b]) | gamma2 * (1 + mod_scale2[b])
@@ -490,7 +490,7 @@ int launch_rowchain(const ina_dit_rowchain_args& p, hipStream_t stream) {
 int ina_launch_dit_rowchain(const ina_dit_rowchain_args& p_in, hipStream_t stream) {
     ina_dit_rowchain_args p = p_in;
     if (p.mod_div <= 0) p.mod_div = p.M;
-    const int nw = p.waves == 8 ? 8 : 4;
+    constexpr int nw = 4;
     INA_REQUIRE(p.A && p.W1 && p.X && p.gamma1, "dit_rowchain: A, W1, X and gamma1 are required");
     INA_REQUIRE(p.K1 == 384 || p.K1 == 1024 || p.K1 == 1536, "dit_rowchain: K1=%d (built for 384 = attn2.to_out and 1024 / 1536 = feed_forward.linear_2)", p.K1);
     INA_REQUIRE(p.M > 0 && p.M % (nw * 32) == 0 && p.mod_div % (nw * 32) == 0, "dit_rowchain: M=%d and mod_div=%d must be multiples of the %d-row panel", p.M,
@@ -507,12 +507,7 @@ int ina_launch_dit_rowchain(const ina_dit_rowchain_args& p_in, hipStream_t strea
         INA_REQUIRE(p.glu2 ? p.K1 == 384 : p.K1 != 384, "dit_rowchain: built pairs are (K1 = 384, SwiGLU second GEMM) and (K1 = 1024 | 1536, plain second GEMM)");
     }
     ina_prof_set_sub(42);
-    if (nw == 4) {
-        if (p.K1 == 384) return !p.W2 ? launch_rowchain<4, 6, false, false>(p, stream) : launch_rowchain<4, 6, true, true>(p, stream);
-        if (p.K1 == 1024) return !p.W2 ? launch_rowchain<4, 16, false, false>(p, stream) : launch_rowchain<4, 16, true, false>(p, stream);
-        return !p.W2 ? launch_rowchain<4, 24, false, false>(p, stream) : launch_rowchain<4, 24, true, false>(p, stream);
-    }
-    if (p.K1 == 384) return !p.W2 ? launch_rowchain<8, 6, false, false>(p, stream) : launch_rowchain<8, 6, true, true>(p, stream);
-    if (p.K1 == 1024) return !p.W2 ? launch_rowchain<8, 16, false, false>(p, stream) : launch_rowchain<8, 16, true, false>(p, stream);
-    return !p.W2 ? launch_rowchain<8, 24, false, false>(p, stream) : launch_rowchain<8, 24, true, false>(p, stream);
+    if (p.K1 == 384) return !p.W2 ? launch_rowchain<4, 6, false, false>(p, stream) : launch_rowchain<4, 6, true, true>(p, stream);
+    if (p.K1 == 1024) return !p.W2 ? launch_rowchain<4, 16, false, false>(p, stream) : launch_rowchain<4, 16, true, false>(p, stream);
+    return !p.W2 ? launch_rowchain<4, 24, false, false>(p, stream) : launch_rowchain<4, 24, true, false>(p, stream);
 }

@@ -52,12 +52,10 @@ __device__ __forceinline__ u32x4 rp_merge_rows(unsigned lo0, unsigned lo1, unsig
     return u32x4{s0[0], s1[0], s0[1], s1[1]};
 }
 
-// VAR (experiments, built only with -DINA_RP_EXPERIMENTS by tools/native/build_rp_experiments.sh; the product instantiates VAR = 0):
-// ablations that deliberately compute garbage to price one ingredient - 1: no DMA inside the loop, 2: no stores, 4: fragments read once per
-// stage 0 only (no LDS reads in the loop), 8: no barriers - and schedule variants with unchanged results - 16: s_setprio(1) around the MFMA
-// groups, 32: reads and MFMAs interleaved 1 : 1.
+// (the ablation builds that priced one ingredient each - no DMA / no stores / no LDS reads / no barriers - and the s_setprio / 1 : 1 interleave
+//  schedule variants of round 4 are in profiles/r04*_native_rowpanel*.log, not in the source any more)
 // EPI: + bias[n] and an activation in the (non-GLU) epilogue - the biased projections of the nn.Transformer layers (NavDP decoder q|k|v, FFN).
-template <int NW, int NS, bool GLU, int VAR = 0, bool EPI = false>
+template <int NW, int NS, bool GLU, bool EPI = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_rowpanel_kernel(GemmArgs p) {   // two waves per SIMD: one 8-wave or two 4-wave workgroups per CU
     constexpr int K = 384, KC = K / 64, BN = 128, STAGE = BN * 64;      // STAGE: elements of one ring slot (16 KiB)
     constexpr int INST = 16 / NW;                                       // 1 KiB DMA wave-instructions per wave and stage
@@ -132,42 +130,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_rowpanel_kernel(GemmArgs
             // stage t has landed for this wave's share: the NS - 2 newer stages (and, right behind an epilogue, its NST stores - same
             // in-order counter, issued after the DMA of stage t + NS - 2) may stay outstanding
             // (the epilogue of tile nt - j was issued behind the DMA of stage t iff kc <= NS + 4 - 6 j: j = 1 for every ring depth, j = 2 for NS = 8)
-            if constexpr (VAR & 1) rp_wait_vm<0>();
-            else if (live && nt > 1 && kc <= NS - 8) rp_wait_vm<(NS - 2) * INST + 2 * NST>();
+            if (live && nt > 1 && kc <= NS - 8) rp_wait_vm<(NS - 2) * INST + 2 * NST>();
             else if (live && nt > 0 && kc <= NS - 2) rp_wait_vm<(NS - 2) * INST + NST>();
             else rp_wait_vm<(NS - 2) * INST>();
-            if constexpr (!(VAR & 8)) __builtin_amdgcn_s_barrier();   // stage t visible to every wave; every wave is done reading stage t - 1
-            if constexpr (!(VAR & 1)) issue(t + NS - 1);              // ... whose slot is refilled
-            else if (t == 0) issue(NS - 1);
+            __builtin_amdgcn_s_barrier();   // stage t visible to every wave; every wave is done reading stage t - 1
+            issue(t + NS - 1);              // ... whose slot is refilled
             const bf16* ws = Ws + (t % NS) * STAGE;
             // fragments of k step kk + 1 are requested before the MFMAs of step kk are issued (pinned: the compiler otherwise sinks every
             // read right in front of its MFMA and waits lgkmcnt(0) per pair)
             bf16x8 wf[2][4];
-            if constexpr (VAR & 32) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(ws + j * 32 * 64 + foff[0]);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (kk + 1 < 4) wf[(kk + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ws + j * 32 * 64 + foff[kk + 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][j], a[kc * 4 + kk], acc[j], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            } else if constexpr (VAR & 4) {
-                if (t == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wf[0][j] = wf[1][j] = *reinterpret_cast<const bf16x8*>(ws + j * 32 * 64 + foff[0]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wf[0][j] = wf[1][j] = a[j];
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][j], a[kc * 4 + kk], acc[j], 0, 0, 0);
-            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) wf[0][j] = *reinterpret_cast<const bf16x8*>(ws + j * 32 * 64 + foff[0]);
 #pragma unroll
@@ -177,17 +148,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_rowpanel_kernel(GemmArgs
                     for (int j = 0; j < 4; ++j) wf[(kk + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(ws + j * 32 * 64 + foff[kk + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (VAR & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][j], a[kc * 4 + kk], acc[j], 0, 0, 0);
-                if constexpr (VAR & 16) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot have returned before it reaches the next barrier
         }
         // ---- epilogue of column tile nt: lane = output row m0 + lrow; acc[j][i * 4 + e] = column nt * 128 + j * 32 + i * 8 + khalf * 4 + e
-        if (live && (!(VAR & 2) || acc[0][0] == 1.2345e30f)) {
+        if (live) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (GLU) {
@@ -234,13 +202,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_rowpanel_kernel(GemmArgs
     rp_wait_vm<0>();      // the dummy tail stages land in LDS: nothing of this workgroup is in flight when it retires
 }
 
-template <int NW, int NS, int VAR = 0>
+template <int NW, int NS>
 int launch_rowpanel(const GemmArgs& p, hipStream_t stream) {
     const size_t LDS_BYTES = size_t(NS) * 128 * 64 * sizeof(bf16) + (p.bias ? size_t(p.N) * 4 : 0);
     static bool attr_done[3] = {false, false, false};
     const bool epi = !p.glu && (p.bias || p.act != INA_ACT_NONE);
     const int which = p.glu ? 1 : (epi ? 2 : 0);
-    auto kern = p.glu ? gemm_bf16_rowpanel_kernel<NW, NS, true, VAR> : (epi ? gemm_bf16_rowpanel_kernel<NW, NS, false, VAR, true> : gemm_bf16_rowpanel_kernel<NW, NS, false, VAR>);
+    auto kern = p.glu ? gemm_bf16_rowpanel_kernel<NW, NS, true> : (epi ? gemm_bf16_rowpanel_kernel<NW, NS, false, true> : gemm_bf16_rowpanel_kernel<NW, NS, false>);
     if (!attr_done[which]) {
         INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(size_t(NS) * 128 * 64 * sizeof(bf16) + 4096 * 4)));
         attr_done[which] = true;
@@ -276,27 +244,6 @@ int ina_launch_gemm_rowpanel(const GemmArgs& p, hipStream_t stream, int cfg) {
         case 35: return launch_rowpanel<4, 4>(p, stream);
         case 36: return launch_rowpanel<8, 3>(p, stream);
         case 37: return launch_rowpanel<4, 3>(p, stream);
-#ifdef INA_RP_EXPERIMENTS
-        case 41: return launch_rowpanel<4, 4, 1>(p, stream);    // no DMA in the loop
-        case 42: return launch_rowpanel<4, 4, 2>(p, stream);    // no stores
-        case 43: return launch_rowpanel<4, 4, 4>(p, stream);    // no LDS reads in the loop
-        case 44: return launch_rowpanel<4, 4, 8>(p, stream);    // no barriers
-        case 45: return launch_rowpanel<4, 4, 7>(p, stream);    // MFMAs + barriers only
-        case 46: return launch_rowpanel<4, 4, 15>(p, stream);   // MFMAs only
-        case 47: return launch_rowpanel<4, 4, 16>(p, stream);   // s_setprio(1) around the MFMA groups
-        case 48: return launch_rowpanel<4, 4, 32>(p, stream);   // reads and MFMAs interleaved 1 : 1
-        case 49: return launch_rowpanel<8, 4, 16>(p, stream);
-        case 50: return launch_rowpanel<8, 4, 32>(p, stream);
-        case 51: return launch_rowpanel<8, 4, 1>(p, stream);
-        case 52: return launch_rowpanel<8, 4, 8>(p, stream);
-        case 53: return launch_rowpanel<8, 4, 15>(p, stream);
-        case 54: return launch_rowpanel<4, 4, 3>(p, stream);    // no DMA, no stores
-        case 55: return launch_rowpanel<4, 4, 6>(p, stream);    // no stores, no LDS reads
-        case 56: return launch_rowpanel<4, 4, 5>(p, stream);    // no DMA, no LDS reads (stores present)
-        case 57: return launch_rowpanel<8, 6>(p, stream);       // deeper rings (96 / 128 KiB)
-        case 58: return launch_rowpanel<8, 8>(p, stream);
-        case 59: return launch_rowpanel<4, 5>(p, stream);       // 80 KiB x 2 workgroups
-#endif
         default: ina_set_error("gemm(row panel): unknown config %d", cfg); return -2;
     }
 }

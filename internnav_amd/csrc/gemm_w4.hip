@@ -428,7 +428,7 @@ int launch_w4p(const GemmArgs& p, hipStream_t stream) {
     GemmArgs q = p;
     if (q.group_m == 0) q.group_m = ((p.N + BN - 1) / BN >= 24 && (p.M + BM - 1) / BM >= 8) ? 8 : 1;
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
-    ina_prof_set_sub(43);                                  // (sub id 40 of the per-kernel tally is the fused DiT FFN kernel)
+    ina_prof_set_sub(40);
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
     hipLaunchKernelGGL(kern, dim3(tiles, 1, 1), dim3(C::NT), C::LDS_BYTES, stream, q);   // (the epilogue scratch needs the full 128 KiB; the A ring uses half)
     INA_HIP_CHECK(hipGetLastError());

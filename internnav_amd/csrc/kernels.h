@@ -22,12 +22,10 @@ using RopeArgs = ina_rope_args;
 using MropeTableArgs = ina_mrope_table_args;
 using ArgmaxArgs = ina_argmax_args;
 using DitAttnArgs = ina_dit_attn_args;
-using GemmRownormArgs = ina_gemm_rownorm_args;
 using ResizeU8Args = ina_resize_u8_args;
 using QwenPatchifyArgs = ina_qwen_patchify_args;
 using U8LutArgs = ina_u8_lut_args;
 using ResizeF32Args = ina_resize_f32_args;
-using DitFfnArgs = ina_dit_ffn_args;
 using DitRowchainArgs = ina_dit_rowchain_args;
 using GnMishArgs = ina_gn_mish_args;
 using PadRowsArgs = ina_pad_rows_args;
@@ -68,13 +66,11 @@ int ina_launch_gather(const GatherArgs& p, hipStream_t stream);
 int ina_launch_rope(const RopeArgs& p, hipStream_t stream);
 int ina_launch_mrope_table(const MropeTableArgs& p, hipStream_t stream);
 int ina_launch_argmax(const ArgmaxArgs& p, hipStream_t stream);
-int ina_launch_gemm_rownorm(const GemmRownormArgs& p, hipStream_t stream);  // N = 384 row-block GEMM + gated rmsnorm + residual + next pre-norm
 int ina_launch_resize_u8(const ResizeU8Args& p, hipStream_t stream);            // one axis of PIL's 8-bit bicubic resample
 int ina_launch_qwen_patchify_u8(const QwenPatchifyArgs& p, hipStream_t stream);  // HF Qwen2-VL rescale + normalize + patchify from bytes
 int ina_launch_u8_lut(const U8LutArgs& p, hipStream_t stream);
 int ina_launch_resize_f32(const ResizeF32Args& p, hipStream_t stream);          // one axis of PIL's float ("F" mode) bicubic resample
 int ina_launch_dit_attention(const DitAttnArgs& p, hipStream_t stream);  // q/k-LayerNorm + self-attention + gated cross-attention of a NextDiT block
-int ina_launch_dit_ffn(const DitFfnArgs& p, hipStream_t stream);  // fused SwiGLU FFN + gated rmsnorm + residual + next pre-norm of a NextDiT block
 int ina_launch_dit_rowchain(const DitRowchainArgs& p, hipStream_t stream);  // GEMM + gated rmsnorm + residual + next pre-norm + next GEMM of a NextDiT block, one launch
 int ina_launch_gn_mish(const GnMishArgs& p, hipStream_t stream);      // GroupNorm + Mish (+ FiLM, + residual) of a ConditionalUnet1D block
 int ina_launch_pad_rows(const PadRowsArgs& p, hipStream_t stream);

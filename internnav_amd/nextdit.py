@@ -42,8 +42,7 @@ def _interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 class NextDiTSystem1:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, fuse_rownorm: bool = False,
-                 fuse_ffn: bool = False, use_async: bool = True, row_chain: bool = True, chain_waves: int = 4):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: dict, device="cuda:0", max_envs: int = 64, use_async: bool = True, row_chain: bool = True):
         """use_async: the 'async' System-1 types condition the DiT on [32 memory tokens of the two look-down frames | projected VLM latents]
         (internvla_n1.py:364-381); without it ('nextdit': :382-383) the condition is the n_query projected latents alone - no DINOv2,
         MemoryEncoder or QFormer weights are read."""
@@ -51,29 +50,19 @@ class NextDiTSystem1:
         bf, f32 = torch.bfloat16, torch.float32
         sd = state_dict
         self.cfg, self.device, self.b_max = cfg, dev, max_envs
-        # attn2.to_out / linear_2 as row-block GEMMs with the gated-norm + residual + next-pre-norm epilogue (needs dim 384). Off by
-        # default: 5 % faster than the GEMM + chained-norm pair in isolation, 1 % slower end to end next to the concurrent decode phase.
-        # round 5: everything of a block between two attention stages that is local to a row as TWO launches (csrc/dit_rowchain.hip):
+        # everything of a block between two attention stages that is local to a row as TWO launches (csrc/dit_rowchain.hip):
         # [attn2.to_out + norm2 / gate / residual + ffn_norm1 + linear_1/3 SwiGLU] and [linear_2 + ffn_norm2 / gate / residual + the next block's
         # norm1 + its fused q1|k1|v1|q2 projection]; the bf16 projection and the pre-normed GEMM operand stay in registers. Used from 16 k rows
         # (16 envs) on - below that the one-workgroup-per-128-rows grid leaves the chip empty, as for the row-panel GEMMs it is built from.
         # The chain is built for dim 384 and the two FFN widths the reference's block can have (1536 under its pinned diffusers 0.33.1, 1024
         # under <= 0.32: synthetic.lumina_ffn_width); its 128-row panels must not straddle two environments (S * T % 128 == 0). Any other
         # geometry takes the GEMM + chained-norm launches below - same results, more launches.
-        self.row_chain = (bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] in (1024, 1536) and not fuse_rownorm and not fuse_ffn
-                          and (cfg["sample_num"] * cfg["predict_size"]) % (chain_waves * 32) == 0)
-        self.chain_waves = chain_waves
+        self.row_chain = (bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] in (1024, 1536)
+                          and (cfg["sample_num"] * cfg["predict_size"]) % 128 == 0)
         self.chain_min_rows = 16384
         # the chain's second launch also hands the attention stage the LayerNorm statistics of the projection rows it writes (blocks 1 ...):
         # dit_attention then reads every row once and runs without its statistics pass / barrier
         self.chain_stats = True
-        self.fuse_rownorm = bool(fuse_rownorm) and cfg["dit_dim"] == 384
-        # feed_forward.linear_1/3 -> SiLU gate -> linear_2 -> ffn_norm2 + gate + residual -> next norm1 as ONE launch (dit_ffn.hip): the
-        # [rows, 1024] intermediate never reaches HBM (3 launches and 670 MB of traffic per block at 64 envs otherwise). Parity-tested;
-        # off by default: measured 366 us vs 308 us for the three launches at 65 536 rows (profiles/r02b_bench_ffn.log) - with 64-row
-        # tiles every workgroup re-streams the 2.4 MB of FFN weights through a 3-stage LDS-DMA ring, and 48 KiB in flight per CU
-        # bounds that stream at ~6.5 TB/s chip-wide (the unfused 128 x 128 tiles move the same operand bytes with 4 workgroups per CU)
-        self.fuse_ffn = bool(fuse_ffn) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] % 128 == 0
         D, L, S, T = cfg["dit_dim"], cfg["latent_dim"], cfg["sample_num"], cfg["predict_size"]
         self.D, self.L, self.S, self.T, self.nq = D, L, S, T, cfg["n_query"]
         self.Fr = cfg["memory_frames"]
@@ -291,41 +280,29 @@ class NextDiTSystem1:
             last = l + 1 >= self.nl
             # attn2.to_out -> x += tanh(gate_msa) * norm2(.) -> ffn_norm1(x) * (1 + scale_mlp) -> linear_1/3 + SiLU gate
             ops.dit_rowchain(att, Lr["wo"], Lr["n2"], x, gate=gate_msa, gamma2=Lr["fn1"], mod_scale2=scale_mlp, w2=Lr["w13"], c2=ff, glu2=True,
-                             mod_div=S * T, eps=1e-5, waves=self.chain_waves)
+                             mod_div=S * T, eps=1e-5)
             # linear_2 -> x += tanh(gate_mlp) * ffn_norm2(.) -> the next block's norm1(x) * (1 + scale_msa) -> its q1|k1|v1|q2 projection
             if last:
-                ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, mod_div=S * T, eps=1e-5, waves=self.chain_waves)
+                ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, mod_div=S * T, eps=1e-5)
             else:
                 nxt = mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
                 ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt,
-                                 w2=self.layers[l + 1]["wq"], c2=qkvq, mod_div=S * T, eps=1e-5, waves=self.chain_waves, seg_stats=stats, seg_eps=1e-5)
+                                 w2=self.layers[l + 1]["wq"], c2=qkvq, mod_div=S * T, eps=1e-5, seg_stats=stats, seg_eps=1e-5)
             return
-        if self.fuse_rownorm:
-            # attn2.to_out as a row-block GEMM whose epilogue does x += tanh(gate) * norm2(.) and h = ffn_norm1(x) * (1 + scale_mlp)
-            ops.gemm_rownorm(att, Lr["wo"], Lr["n2"], x, gate=gate_msa, h=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp, mod_div=S * T, eps=1e-5)
-        else:
-            ops.linear(att, Lr["wo"], out=proj)
-            # x += tanh(gate) * norm2(attn) and, chained in the same launch on the fresh row, h = ffn_norm1(x) * (1 + scale_mlp)
-            ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x,
-                     out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
+        ops.linear(att, Lr["wo"], out=proj)
+        # x += tanh(gate) * norm2(attn) and, chained in the same launch on the fresh row, h = ffn_norm1(x) * (1 + scale_mlp)
+        ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x,
+                 out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
         # linear_1/3 + SiLU gate, linear_2, then x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
         last = l + 1 >= self.nl
         nxt = None if last else mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
-        if self.fuse_ffn:
-            ops.dit_ffn(h, Lr["w13"], Lr["w2"], Lr["fn2"], x, gate=gate_mlp, h=None if last else h,
-                        gamma2=None if last else self.layers[l + 1]["n1"], mod_scale2=nxt, mod_div=S * T, eps=1e-5)
-            return
         ops.linear(h, Lr["w13"], act="silu", glu=True, out=ff)
-        if self.fuse_rownorm:
-            ops.gemm_rownorm(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, h=None if last else h,
-                             gamma2=None if last else self.layers[l + 1]["n1"], mod_scale2=nxt, mod_div=S * T, eps=1e-5)
+        ops.linear(ff, Lr["w2"], out=proj)
+        if last:
+            ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x)
         else:
-            ops.linear(ff, Lr["w2"], out=proj)
-            if last:
-                ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x)
-            else:
-                ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x,
-                         out2=h, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt)
+            ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x,
+                     out2=h, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt)
 
     def generate_traj(self, traj_latents: torch.Tensor, images_dp: torch.Tensor, x_init: torch.Tensor, guidance_scale: float = 1.0,
                       images_encoded: bool = False) -> torch.Tensor:

@@ -489,42 +489,15 @@ def dit_attention(x: torch.Tensor, out: torch.Tensor, norms, kv2: torch.Tensor, 
     return out
 
 
-def gemm_rownorm(a_in: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
-                 h: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None,
-                 mod_div: int = 1, eps: float = 1e-5) -> torch.Tensor:
-    """x += tanh(gate[r // mod_div]) * rmsnorm(a_in @ w.T) * gamma;  h = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div]).
-
-    a_in bf16 [M, K], w bf16 [384, K], x f32 [M, 384] (in place), h bf16 [M, 384] or None. One launch: the projection stays on chip."""
-    assert a_in.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a_in.dim() == 2 and a_in.stride(1) == 1 and w.stride(1) == 1
-    M, K = a_in.shape
-    N = w.shape[0]
-    assert w.shape[1] == K and x.dtype == torch.float32 and x.shape == (M, N) and x.stride(1) == 1
-    a = _lib.GemmRownormArgs()
-    a.A, a.W, a.gamma, a.X = a_in.data_ptr(), w.data_ptr(), _f32(gamma).data_ptr(), x.data_ptr()
-    a.M, a.N, a.K, a.lda, a.ldw, a.ldx = M, N, K, a_in.stride(0), w.stride(0), x.stride(0)
-    if gate is not None:
-        assert gate.dtype == torch.float32 and gate.stride(-1) == 1
-        a.gate, a.mod_ld = gate.data_ptr(), gate.stride(0)
-    if h is not None:
-        assert h.dtype == torch.bfloat16 and h.shape == (M, N) and h.stride(1) == 1
-        a.H, a.ldh, a.gamma2 = h.data_ptr(), h.stride(0), _ptr(_f32(gamma2))
-        if mod_scale2 is not None:
-            assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and a.mod_ld in (0, mod_scale2.stride(0))
-            a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
-    a.mod_div, a.eps = mod_div, eps
-    _lib.check(_lib.lib().ina_gemm_rownorm_bf16(C.byref(a), _stream()), "gemm_rownorm_bf16")
-    return x
-
-
 def dit_rowchain(a_in: torch.Tensor, w1: torch.Tensor, gamma1: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
                  gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None,
                  w2: Optional[torch.Tensor] = None, c2: Optional[torch.Tensor] = None, glu2: bool = False, mod_div: int = 0, eps: float = 1e-5,
-                 waves: int = 4, seg_stats: Optional[torch.Tensor] = None, seg_eps: float = 1e-5) -> torch.Tensor:
+                 seg_stats: Optional[torch.Tensor] = None, seg_eps: float = 1e-5) -> torch.Tensor:
     """the row-local chain of a NextDiT block in one launch (csrc/dit_rowchain.hip):
         x += tanh(gate[r // mod_div]) * rmsnorm(bf16(a_in @ w1.T)) * gamma1
         H  = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div])
         c2 = H @ w2.T   (glu2: silu(H @ wg.T) * (H @ wu.T) with w2's rows interleaved [gate16 | up16])
-    a_in bf16 [M, K1] (K1 = 384 | 1024), w1 bf16 [384, K1], x f32 [M, 384] (in place); w2 bf16 [N2, 384] -> c2 bf16 [M, N2 (/ 2)], or w2 None
+    a_in bf16 [M, K1] (K1 = 384 | 1024 | 1536; M a multiple of 128), w1 bf16 [384, K1], x f32 [M, 384] (in place); w2 bf16 [N2, 384] -> c2 bf16 [M, N2 (/ 2)], or w2 None
     (then h bf16 [M, 384] may be given to receive H). The projection and H never leave the chip.
     seg_stats f32 [M, N2 // 384, 2] (plain second GEMM): receives (mean, rstd) of every 384-wide segment of the c2 rows = the LayerNorm
     statistics dit_attention(stats=) consumes."""
@@ -553,38 +526,8 @@ def dit_rowchain(a_in: torch.Tensor, w1: torch.Tensor, gamma1: torch.Tensor, x: 
         assert w2 is not None and not glu2 and N2 % 384 == 0
         assert seg_stats.dtype == torch.float32 and seg_stats.shape == (M, N2 // 384, 2) and seg_stats.is_contiguous()
         a.seg_stats, a.seg_eps = seg_stats.data_ptr(), seg_eps
-    a.mod_div, a.eps, a.waves = mod_div, eps, waves
+    a.mod_div, a.eps = mod_div, eps
     _lib.check(_lib.lib().ina_dit_rowchain(C.byref(a), _stream()), "dit_rowchain")
-    return x
-
-
-def dit_ffn(h_in: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, gamma: torch.Tensor, x: torch.Tensor, gate: Optional[torch.Tensor] = None,
-            h: Optional[torch.Tensor] = None, gamma2: Optional[torch.Tensor] = None, mod_scale2: Optional[torch.Tensor] = None,
-            mod_div: int = 1, eps: float = 1e-5, rotate: int = 0) -> torch.Tensor:
-    """SwiGLU feed-forward of a NextDiT block in one launch (the F = silu(h W1^T) * (h W3^T) intermediate never leaves the chip):
-    x += tanh(gate[r // mod_div]) * rmsnorm((silu(h_in @ w1.T) * (h_in @ w3.T)) @ w2.T) * gamma;  h = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div]).
-
-    h_in bf16 [M, 384]; w13 bf16 [2F, 384] = linear_1 / linear_3 interleaved in 16-row blocks; w2 bf16 [384, F]; x f32 [M, 384] (in place);
-    h bf16 [M, 384] or None (may be h_in itself)."""
-    assert h_in.dtype == torch.bfloat16 and w13.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
-    assert h_in.dim() == 2 and h_in.stride(1) == 1 and w13.stride(1) == 1 and w2.stride(1) == 1
-    M, D = h_in.shape
-    F = w2.shape[1]
-    assert w13.shape == (2 * F, D) and w2.shape[0] == D and x.dtype == torch.float32 and x.shape == (M, D) and x.stride(1) == 1
-    a = _lib.DitFfnArgs()
-    a.A, a.W13, a.W2, a.gamma, a.X = h_in.data_ptr(), w13.data_ptr(), w2.data_ptr(), _f32(gamma).data_ptr(), x.data_ptr()
-    a.M, a.D, a.F, a.lda, a.ldw13, a.ldw2, a.ldx = M, D, F, h_in.stride(0), w13.stride(0), w2.stride(0), x.stride(0)
-    if gate is not None:
-        assert gate.dtype == torch.float32 and gate.stride(-1) == 1
-        a.gate, a.mod_ld = gate.data_ptr(), gate.stride(0)
-    if h is not None:
-        assert h.dtype == torch.bfloat16 and h.shape == (M, D) and h.stride(1) == 1
-        a.H, a.ldh, a.gamma2 = h.data_ptr(), h.stride(0), _ptr(_f32(gamma2))
-        if mod_scale2 is not None:
-            assert mod_scale2.dtype == torch.float32 and mod_scale2.stride(-1) == 1 and a.mod_ld in (0, mod_scale2.stride(0))
-            a.mod_scale2, a.mod_ld = mod_scale2.data_ptr(), mod_scale2.stride(0)
-    a.mod_div, a.eps, a.rotate = mod_div, eps, int(rotate)
-    _lib.check(_lib.lib().ina_dit_ffn(C.byref(a), _stream()), "dit_ffn")
     return x
 
 

@@ -44,7 +44,7 @@ def test_struct_sizes_match_header(built_lib):
 
     mirrors = [_lib.GemmArgs, _lib.AttnArgs, _lib.NormArgs, _lib.PatchifyArgs, _lib.Embed3Args, _lib.Head3Args,
                _lib.SeqpoolArgs, _lib.SelectArgs, _lib.PoolActArgs, _lib.GatherArgs,
-               _lib.RopeArgs, _lib.MropeTableArgs, _lib.ArgmaxArgs, _lib.DitAttnArgs, _lib.GemmRownormArgs, _lib.ResizeU8Args, _lib.QwenPatchifyArgs, _lib.U8LutArgs, _lib.ResizeF32Args, _lib.DitFfnArgs, _lib.GnMishArgs, _lib.PadRowsArgs, _lib.DdimStepArgs,
+               _lib.RopeArgs, _lib.MropeTableArgs, _lib.ArgmaxArgs, _lib.DitAttnArgs, _lib.ResizeU8Args, _lib.QwenPatchifyArgs, _lib.U8LutArgs, _lib.ResizeF32Args, _lib.GnMishArgs, _lib.PadRowsArgs, _lib.DdimStepArgs,
                _lib.EwArgs, _lib.ColsumArgs, _lib.NormBwdArgs, _lib.TransposeArgs, _lib.SparseRowsArgs, _lib.SmallLinearArgs, _lib.MseArgs,
                _lib.AdamwArgs, _lib.GemmNnArgs, _lib.AttnBwdArgs, _lib.DitRowchainArgs]
     for k, m in enumerate(mirrors):

@@ -716,69 +716,6 @@ def test_norm_chained_prenorm(ops, rms, C):
     assert torch.equal(x_c, x_b)
 
 
-@pytest.mark.parametrize("M,K,with_h", [(300, 384, True), (4096 + 40, 1024, True), (128, 64, False), (1000, 384, False)])
-def test_gemm_rownorm_fused_block_epilogue(ops, M, K, with_h):
-    """row-block GEMM + gated rmsnorm + residual + chained pre-norm vs the fp32 formula and vs the two launches it replaces."""
-    N, div = 384, 100
-    g = torch.Generator().manual_seed(M + K)
-    a_in, w = _rand((M, K), g), _rand((N, K), g, scale=K ** -0.5)
-    x0 = torch.randn(M, N, generator=g).to(_dev())
-    g1, g2 = [(1.0 + 0.1 * torch.randn(N, generator=g)).to(_dev()) for _ in range(2)]
-    nb = (M + div - 1) // div
-    mod = (0.5 * torch.randn(nb, 2 * N, generator=g)).to(_dev())
-    gate, ms2 = mod[:, :N], mod[:, N:]
-    x = x0.clone()
-    h = torch.empty(M, N, dtype=torch.bfloat16, device=_dev()) if with_h else None
-    ops.gemm_rownorm(a_in, w, g1, x, gate=gate, h=h, gamma2=g2, mod_scale2=ms2, mod_div=div)
-    rms = lambda t: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5)
-    rowb = torch.arange(M, device=_dev()) // div
-    proj = a_in.float() @ w.float().t()
-    x_ref = x0 + torch.tanh(gate[rowb]) * rms(proj) * g1
-    _close(x, x_ref, rtol=2e-3, atol=5e-3)
-    if with_h:
-        _close(h, rms(x_ref) * g2 * (1.0 + ms2[rowb]), rtol=1.0 / 128, atol=1e-2)
-    # the unfused launch pair (bf16 projection in between)
-    pj = ops.linear(a_in, w)
-    xu, hu = x0.clone(), torch.empty(M, N, dtype=torch.bfloat16, device=_dev())
-    ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
-    _close(x, xu, rtol=1.0 / 128, atol=2e-2)
-
-
-@pytest.mark.parametrize("M,with_h,alias", [(64, True, False), (200, True, True), (1024 + 37, False, False), (4096, True, True)])
-def test_dit_ffn_fused_swiglu_block(ops, M, with_h, alias):
-    """fused SwiGLU FFN (GLU GEMM -> F chunk in LDS -> linear_2 -> gated rmsnorm + residual + next pre-norm) vs the fp32 formula and vs
-    the three launches it replaces; M not a multiple of the 64-row tile; H aliasing the input (the NextDiT engine's usage)."""
-    D, F, div = 384, 1024, 96
-    g = torch.Generator().manual_seed(M + 7)
-    h_in = _rand((M, D), g)
-    w1, w3 = _rand((F, D), g, scale=D ** -0.5), _rand((F, D), g, scale=D ** -0.5)
-    w2 = _rand((D, F), g, scale=F ** -0.5)
-    w13 = torch.stack([w1.view(F // 16, 16, D), w3.view(F // 16, 16, D)], dim=1).reshape(2 * F, D).contiguous()
-    x0 = torch.randn(M, D, generator=g).to(_dev())
-    g1, g2 = [(1.0 + 0.1 * torch.randn(D, generator=g)).to(_dev()) for _ in range(2)]
-    nb = (M + div - 1) // div
-    mod = (0.5 * torch.randn(nb, 2 * D, generator=g)).to(_dev())
-    gate, ms2 = mod[:, :D], mod[:, D:]
-    x = x0.clone()
-    h_src = h_in.clone()
-    h = (h_src if alias else torch.empty(M, D, dtype=torch.bfloat16, device=_dev())) if with_h else None
-    ops.dit_ffn(h_src, w13, w2, g1, x, gate=gate, h=h, gamma2=g2, mod_scale2=ms2, mod_div=div)
-    rms = lambda t: t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + 1e-5)
-    rowb = torch.arange(M, device=_dev()) // div
-    hf = h_in.float()
-    ff = (torch.nn.functional.silu(hf @ w1.float().t()) * (hf @ w3.float().t())).to(torch.bfloat16).float()   # F is bf16 between the GEMMs, as unfused
-    x_ref = x0 + torch.tanh(gate[rowb]) * rms(ff @ w2.float().t()) * g1
-    _close(x, x_ref, rtol=2e-3, atol=5e-3)
-    if with_h:
-        _close(h, rms(x_ref) * g2 * (1.0 + ms2[rowb]), rtol=1.0 / 128, atol=1e-2)
-    # the three launches it replaces
-    fu = ops.linear(h_in, w13, act="silu", glu=True)
-    pj = ops.linear(fu, w2)
-    xu, hu = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device=_dev())
-    ops.norm(pj, g1, None, eps=1e-5, rms=True, gate=gate, base=xu, mod_div=div, out32=xu, out2=hu, gamma2=g2, mod_scale2=ms2)
-    _close(x, xu, rtol=1.0 / 128, atol=2e-2)
-
-
 def test_workspace_growth_never_frees_a_buffer_a_graph_has_seen(ops):
     """library hardening: a hipGraph captured under a workspace slot keeps the scratch pointer it was captured with.
     When a later eager launch under the same slot needs more scratch, the old buffer must stay alive (retired, not freed): the graph
@@ -900,18 +837,17 @@ def test_gemm_rowpanel_bias_activation_epilogue(ops, cfg, M, N, act):
     assert d.max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item()) and (d > 0).float().mean().item() < 0.05
 
 
-@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("M,K1,N2,glu", [(256, 384, 2048, True), (2048, 1024, 1536, False), (1024 + 256, 384, 256, True), (512, 1024, 0, False),
                                          (768, 384, 0, False),
                                          # FFN width 1536 (the reference's block under its pinned diffusers 0.33.1): SwiGLU N2 = 2 x 1536, linear_2 K1 = 1536
                                          (512, 384, 3072, True), (1024, 1536, 1536, False), (256, 1536, 0, False)])
-def test_dit_rowchain(ops, waves, M, K1, N2, glu):
+def test_dit_rowchain(ops, M, K1, N2, glu):
     """csrc/dit_rowchain.hip: GEMM 1 (N = 384) + gated rmsnorm + residual + next pre-norm + GEMM 2 of a NextDiT block in one launch, against
     (a) the fp32 formula of the chain with the unfused chain's rounding points (bf16 projection, bf16 pre-normed operand), (b) the three
     launches it replaces. Several environments per launch (mod_div = 256: a workgroup's rows share one modulation row), more than one
     workgroup per environment, row-strided views, both weight pairs; N2 = 0: no second GEMM, H written to memory instead."""
     D, div = 384, 256
-    g = torch.Generator().manual_seed(M + K1 + N2 + waves)
+    g = torch.Generator().manual_seed(M + K1 + N2 + 4)
     aw = _rand((M, K1 + 64), g)
     a_in = aw[:, :K1]                                                    # row-strided A
     w1 = _rand((D, K1), g, scale=K1 ** -0.5)
@@ -927,19 +863,19 @@ def test_dit_rowchain(ops, waves, M, K1, N2, glu):
     x = x0.clone()
     if N2 == 0:
         h = torch.full((M, D), 7.0, dtype=torch.bfloat16, device=_dev())
-        ops.dit_rowchain(a_in, w1, g1, x, gate=gate, gamma2=g2, mod_scale2=ms2, h=h, mod_div=div, waves=waves)
+        ops.dit_rowchain(a_in, w1, g1, x, gate=gate, gamma2=g2, mod_scale2=ms2, h=h, mod_div=div)
         torch.cuda.synchronize()
         _close(x, x_ref, rtol=2e-3, atol=5e-3)
         _close(h, h_ref, rtol=1.0 / 128, atol=1e-2)
         x2 = x0.clone()                                                  # the last block's form: no H, no second GEMM
-        ops.dit_rowchain(a_in, w1, g1, x2, gate=gate, mod_div=div, waves=waves)
+        ops.dit_rowchain(a_in, w1, g1, x2, gate=gate, mod_div=div)
         assert torch.equal(x2, x)
         return
     w2 = _rand((N2, D), g, scale=D ** -0.5)
     n_out = N2 // 2 if glu else N2
     cw = torch.zeros(M, n_out + 8, dtype=torch.bfloat16, device=_dev())
     c2 = cw[:, :n_out]
-    ops.dit_rowchain(a_in, w1, g1, x, gate=gate, gamma2=g2, mod_scale2=ms2, w2=w2, c2=c2, glu2=glu, mod_div=div, waves=waves)
+    ops.dit_rowchain(a_in, w1, g1, x, gate=gate, gamma2=g2, mod_scale2=ms2, w2=w2, c2=c2, glu2=glu, mod_div=div)
     torch.cuda.synchronize()
     _close(x, x_ref, rtol=2e-3, atol=5e-3)
     assert float(cw[:, n_out:].abs().max()) == 0.0, "columns beyond the output were written"
@@ -959,7 +895,7 @@ def test_dit_rowchain(ops, waves, M, K1, N2, glu):
         # LayerNorm statistics of the 384-wide segments of the produced rows, for the attention stage that consumes them
         x3, c3 = x0.clone(), torch.zeros_like(cw)
         st = torch.full((M, N2 // 384, 2), float("nan"), device=_dev())
-        ops.dit_rowchain(a_in, w1, g1, x3, gate=gate, gamma2=g2, mod_scale2=ms2, w2=w2, c2=c3[:, :n_out], mod_div=div, waves=waves, seg_stats=st, seg_eps=1e-5)
+        ops.dit_rowchain(a_in, w1, g1, x3, gate=gate, gamma2=g2, mod_scale2=ms2, w2=w2, c2=c3[:, :n_out], mod_div=div, seg_stats=st, seg_eps=1e-5)
         torch.cuda.synchronize()
         assert torch.equal(x3, x) and torch.equal(c3, cw), "the statistics epilogue changed the outputs"
         seg = c2.float().view(M, N2 // 384, 384)

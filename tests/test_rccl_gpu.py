@@ -1,4 +1,4 @@
-"""GPU, >= 2 devices only (skipped on the 1-GPU test box): the per-step action exchange over the `nccl` backend (= RCCL over xGMI on
+"""GPU. The multi-rank tests need >= 2 devices (skipped on the 1-GPU test box); the one-rank test runs everywhere: the per-step action exchange over the `nccl` backend (= RCCL over xGMI on
 ROCm), one process per GPU as bench.py / the evaluator launch it. The gathered tensor must be bit-equal to what the gloo CPU test of
 the same helper produces (tests/test_host_logic.py::test_data_parallel_helpers_gloo_world2): integer action ids, rank-major."""
 import os
@@ -119,3 +119,38 @@ def test_sft_flat_bucket_zero2_equals_all_reduce_over_rccl():
         assert head == res[0][1]                       # identical weights on every rank
         assert diff <= 1e-6 and dlq == 0.0             # sharded update == replicated update
         assert abs(n_ar - n_z2) <= 1e-4 * n_ar and n_ar == res[0][3]
+
+
+def _worker_one(port, q):
+    """a ONE-rank process group on the `nccl` backend: the helpers short-circuit at world 1, so the collectives are called directly here"""
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    acts = (torch.arange(64 * 4, dtype=torch.int32, device=dev).view(64, 4) % 4)
+    out = torch.full_like(acts, -1)
+    dist.all_gather_into_tensor(out, acts)                       # the per-step exchange of bench.py / dist.all_gather_actions
+    t = torch.tensor([3.0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # the max-over-ranks timing of bench.py
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put((str(dist.get_backend()), dist.get_world_size(), out.cpu().tolist(), float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_rccl_communicator_with_one_rank_on_the_test_gpu():
+    """the single test GPU can still LOAD RCCL: a one-rank `nccl` process group (communicator creation), the per-step
+    all_gather_into_tensor of the action table, the timing all-reduce, a barrier, teardown - so a broken librccl / IPC environment shows up
+    here and not first at the driver's 8-GPU run. (No scaling claim: one rank.)"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one, args=(31000 + (os.getpid() % 2000), q))
+    p.start()
+    backend, world, g, t = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0 and backend == "nccl" and world == 1 and t == 3.0
+    assert torch.equal(torch.tensor(g, dtype=torch.int32), torch.arange(64 * 4, dtype=torch.int32).view(64, 4) % 4)

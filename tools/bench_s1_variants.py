@@ -17,9 +17,7 @@ for B in ([int(x) for x in sys.argv[1:]] or [64, 57]):
   inp = synthetic.n1_nextdit_inputs(B, seed=0)
   lat, img, x0 = inp["traj_latents"].to(dev, torch.bfloat16), inp["images"].to(dev), inp["x_init"].to(dev)
   ref = None
-  for name, kw in (("unfused", dict(row_chain=False)), ("row_chain w4", dict(row_chain=True, chain_waves=4)),
-                   ("row_chain w4 own-stats", dict(row_chain=True, chain_waves=4, chain_stats=False)), ("row_chain w8", dict(row_chain=True, chain_waves=8)),
-                   ("fuse_rownorm", dict(fuse_rownorm=True)), ("fuse_ffn", dict(fuse_ffn=True))):
+  for name, kw in (("unfused", dict(row_chain=False)), ("row_chain", dict(row_chain=True))):
     chain_stats = kw.pop("chain_stats", True)
     eng = NextDiTSystem1(sd, cfg, dev, max_envs=B, **kw)
     eng.chain_stats = chain_stats

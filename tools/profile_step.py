@@ -11,9 +11,9 @@ import bench  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
 kw = {}
 for i, x in enumerate(sys.argv):
-    if x == "--chain-waves":
-        kw["chain_waves"] = int(sys.argv[i + 1])
-    elif x in ("--thin-decode", "--no-row-chain", "--no-chain-stats", "--decode-fused"):
+    if x == "--dit-ffn":
+        kw["dit_ffn"] = int(sys.argv[i + 1])
+    elif x in ("--no-row-chain", "--no-fuse-decode-rope", "--no-frag-weights", "--no-split-prefill"):
         kw[x[2:].replace("-", "_")] = True
 wl = bench.N1Dual(bench.default_args(**kw), torch.device("cuda:0"), 0)
 wl.capture()

@@ -10,10 +10,10 @@ import bench  # noqa: E402
 
 kw = {}
 argv = sys.argv[1:]
-for i, x in enumerate(argv):        # e.g. `python tools/step_breakdown.py --chain-waves 8 --thin-decode --no-row-chain`
-    if x == "--chain-waves":
-        kw["chain_waves"] = int(argv[i + 1])
-    elif x in ("--thin-decode", "--no-row-chain", "--no-chain-stats", "--decode-fused"):
+for i, x in enumerate(argv):        # e.g. `python tools/step_breakdown.py --s1-tail-envs 0 --no-row-chain --dit-ffn 1024`
+    if x in ("--dit-ffn",):
+        kw[x[2:].replace("-", "_")] = int(argv[i + 1])
+    elif x in ("--no-row-chain", "--no-fuse-decode-rope", "--no-frag-weights", "--no-split-prefill"):
         kw[x[2:].replace("-", "_")] = True
 a = bench.default_args(**kw)
 print("# variant:", kw or "default")
@@ -40,12 +40,14 @@ for (nA, m_), g in wl.gAimg.items():
 for m, g in wl.gB.items():
     print(f"S1 graph (small engine{', from the projected latents on' if wl.merge_images else ''}), {m} envs: {t(g):.1f} ms")
 m = max(wl.mb)
-nA = 64 - m
+X = 0
+nA = 64 - m - X
+mB = m + X
 
 
 def side_call():
     if wl.merge_images:
-        wl.gAimg[(nA, m)]()
+        wl.gAimg[(nA, mB)]()
     wl.gA[nA]()
 
 
@@ -65,11 +67,11 @@ def both3():
     with torch.cuda.stream(wl.side):
         side_call()
     wl.gD[m]()
-    wl.gB[m]()
+    wl.gB[mB]()
     torch.cuda.current_stream().wait_stream(wl.side)
 
 
-print(f"(decode+latents, S1 small) || S1 ({nA} envs): {t(both3):.1f} ms")
+print(f"(decode+latents, S1 of {mB} envs) || S1 ({nA} envs): {t(both3):.1f} ms")
 # timeline of the concurrent phase: when does each chain end?
 ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "dec", "s1b", "s1a")}
 torch.cuda.synchronize()
@@ -81,7 +83,7 @@ with torch.cuda.stream(wl.side):
     ev["s1a"].record(wl.side)
 wl.gD[m]()
 ev["dec"].record(main)
-wl.gB[m]()
+wl.gB[mB]()
 ev["s1b"].record(main)
 torch.cuda.synchronize()
 print("concurrent phase timeline: decode+latents ends at %.1f ms, S1(small) at %.1f ms (main stream); S1(%d envs, side stream) at %.1f ms"
