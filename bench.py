@@ -373,7 +373,7 @@ class N1Dual:
         if getattr(a, "no_split_prefill", False):
             self.model.qwen.split_prefill = False
         if getattr(a, "no_frag_weights", False):
-            self.model.qwen.frag_weights = False
+            self.model.qwen.drop_frag_weights()
         if getattr(a, "no_fuse_decode_rope", False):
             self.model.qwen.fuse_decode_rope = False
         g = self.g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)

@@ -862,6 +862,7 @@ int launch_d(const AttnArgs& p, hipStream_t stream) {
     InaProfScope prof(INA_PROF_ATTN, 4.0 * p.B * p.H * (double)p.Lq * keys * p.D,
                       2.0 * p.D * ((double)p.B * p.H * p.Lq * 2.0 + 2.0 * (double)(p.B / p.kv_bdiv) * p.Hkv * p.Lk), stream);
     // long dense shapes: 32x32 MFMA kernel (attention_wide.hip); ina_attn_args.kernel pins one of the two kernels (tests compare them)
+    INA_REQUIRE(p.kernel != 3, "attention: kernel = 3 (the four-wave one-launch decode kernel) outside the decode contract (few query rows, dense K / V, Lk >= 256)");
     if (p.kernel == 2) INA_REQUIRE(ina_attention_wide_contract(p), "attention: kernel = 2 (32-rows-per-wave) outside its contract (d 64 / 80 / 128, Lq, Lk >= 128, no gate / accumulate / dropout)");
     if (p.kernel == 2 || (p.kernel == 0 && ina_attention_wide_eligible(p)))
         return ina_launch_attention_wide(p, stream);

@@ -115,7 +115,8 @@ def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
 class QwenVLEngine:
     """weights: mapping key -> tensor (a state dict, or a lazy provider that materialises tensors on the device)."""
 
-    def __init__(self, weights, cfg: dict, device="cuda:0", max_seqs: int = 16, max_seq_len: int = 1024, max_patches: int = 16 * 3136):
+    def __init__(self, weights, cfg: dict, device="cuda:0", max_seqs: int = 16, max_seq_len: int = 1024, max_patches: int = 16 * 3136,
+                 frag_weights: Optional[bool] = None):
         dev = torch.device(device)
         bf, f32 = torch.bfloat16, torch.float32
         self.cfg, self.device = cfg, dev
@@ -191,12 +192,9 @@ class QwenVLEngine:
         # the three wide decoder weights a second time in MFMA fragment order (ops.gemm_preshuffle, + 12 GB at the 7B geometry): the prefill GEMMs
         # that run the four-wave 256 x 256 tile then fetch their B fragments straight from global memory into registers (tile config 40,
         # gemm_w4.hip: half the LDS-DMA pieces and fragment reads per stage; bit-equal); the single-token passes keep streaming the row-major copy
-        self.frag_weights = torch.device(dev).type == "cuda"
+        self.frag_weights = torch.device(dev).type == "cuda" if frag_weights is None else bool(frag_weights)
         if self.frag_weights:
-            for L in self.layers:
-                for k in ("qkv_w", "gu_w", "down_w"):
-                    n_, k_ = L[k].shape
-                    L[k + "f"] = ops.gemm_preshuffle(L[k]) if (n_ % 16 == 0 and k_ % 32 == 0) else None
+            self.refresh_frag_weights()
         self.norm_w = f("model.norm.weight")
         self.lm_head = w("lm_head.weight")
         self.latent_q = W["model.latent_queries"].to(device=dev, dtype=bf).reshape(-1, H).contiguous()
@@ -282,6 +280,25 @@ class QwenVLEngine:
         k-th image token in sequence order."""
         vp = self.plan_vision(grids)
         return self.run_vision(vp, pixel_values), vp["inv"]
+
+    def refresh_frag_weights(self):
+        """(re)build the fragment-ordered copies of the wide decoder weights from the row-major ones - at load, and after anything that
+        replaces or updates a layer weight in place (checkpoint reload, LoRA merge): the copies are not views"""
+        self.frag_weights = True
+        for L in self.layers:
+            for k in ("qkv_w", "gu_w", "down_w"):
+                n_, k_ = L[k].shape
+                if n_ % 16 == 0 and k_ % 32 == 0:
+                    L[k + "f"] = ops.gemm_preshuffle(L[k], out=L.get(k + "f"))
+                else:
+                    L[k + "f"] = None
+
+    def drop_frag_weights(self):
+        """release the fragment-ordered copies (12 GB at the 7B geometry): the prefill GEMMs fall back to tile config 39 / 18, same bits"""
+        self.frag_weights = False
+        for L in self.layers:
+            for k in ("qkv_wf", "gu_wf", "down_wf"):
+                L.pop(k, None)
 
     # ------------------------------------------------------------------------------------------------ text model
     def _phase(self, B: int, S: int, pos3: np.ndarray, cache_pos0, k_len: Optional[np.ndarray] = None, b0: int = 0) -> dict:

@@ -213,7 +213,8 @@ class InternVLAN1SftTrainer:
         for bit, name in ((1, "image_token_id"), (2, "vision_start_id"), (4, "traj_token_id")):
             layout |= (idn == cfg[name]).astype(np.uint8) * bit
         g = grid.cpu().numpy() if isinstance(grid, torch.Tensor) else np.asarray(grid)
-        key = (id(e), idn.shape, layout.tobytes(), g.tobytes(), tuple(int(x) for x in t_s_pos), tuple(pv.shape))
+        # (the workspace slot baked into the captured launches is part of the key: the main-stream and the prefetch path capture their own graphs)
+        key = (id(e), self._cap_slot, idn.shape, layout.tobytes(), g.tobytes(), tuple(int(x) for x in t_s_pos), tuple(pv.shape))
         ent = self._prefix_graphs.get(key)
         if ent is None:
             self._prefix_seen[key] = self._prefix_seen.get(key, 0) + 1
@@ -231,9 +232,14 @@ class InternVLAN1SftTrainer:
             self._prefix_graphs[key] = ent
         else:
             self._prefix_graphs[key] = self._prefix_graphs.pop(key)      # most recently used last
+        if ent.get("done") is not None:      # a replay of this graph on ANOTHER stream may still read the static inputs: order the overwrite behind it
+            torch.cuda.current_stream().wait_event(ent["done"])
         ent["P"]["ids"].copy_(prefix.reshape(-1).to(torch.int32))
         ent["pv"].copy_(pv)
         ent["graph"]()
+        if prefix.is_cuda or pv.is_cuda:
+            ent["done"] = torch.cuda.Event()
+            ent["done"].record(torch.cuda.current_stream())
         st = dict(ent["state"])
         st["next_pos"] = st["next_pos"].copy()
         if "lens" in st:

@@ -481,3 +481,22 @@ def test_prefix_kv_plan_host_logic_on_cpu():
     assert torch.equal(eng.export_prefix_kv(0, P0), kv)
     eng.import_prefix_kv_batch(torch.stack([kv, kv]))
     assert torch.equal(eng.export_prefix_kv(1, P0), kv)
+
+
+def test_nextdit_row_chain_is_selected_by_geometry_not_assumed():
+    """the row-chain launches are built for dim 384, FFN 1024 / 1536 and 128-row panels that do not straddle two environments
+    (sample_num * predict_size % 128 == 0). Any other geometry must fall back to the GEMM + chained-norm launches instead of raising at >= 16 envs."""
+    from internnav_amd import synthetic as S
+    from internnav_amd.nextdit import NextDiTSystem1
+
+    def engine(**kw):
+        cfg = dict(S.N1_NEXTDIT_CFG, **kw)
+        sd = {k: t for k, t in S.n1_nextdit_state_dict(seed=1, cfg=cfg).items() if not k.startswith(("rgb_model.", "memory_encoder.", "rgb_resampler."))}
+        return NextDiTSystem1(sd, cfg, "cpu", max_envs=1, use_async=False)
+
+    assert engine().row_chain and engine(dit_ffn=1024).row_chain
+    assert engine(predict_size=24).row_chain                      # 32 x 24 = 768 rows per env = 6 panels
+    assert not engine(sample_num=20, predict_size=24).row_chain   # 480 rows per env: a panel would straddle two environments
+    assert not engine(dit_ffn=768).row_chain
+    e = engine(sample_num=20, predict_size=24)
+    assert e.ff.shape == (20 * 24, 1536) and e.T == 24
