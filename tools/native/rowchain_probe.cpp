@@ -1,9 +1,9 @@
 // Torch-free probe of the row-local part of a NextDiT block over the C-ABI (round 5): per block-step the launches between two attention stages,
 //   unfused: GEMM(attn2.to_out) -> norm (gated rmsnorm + residual + next pre-norm) -> GEMM(linear_1/3, SwiGLU) -> GEMM(linear_2) -> norm -> GEMM(next q|k|v|q2)
-//   chained: ina_dit_rowchain x 2 (csrc/dit_rowchain.hip), 128-row (waves 4) and 256-row (waves 8) panels
+//   chained: ina_dit_rowchain x 2 (csrc/dit_rowchain.hip), 128-row panels
 // timed back to back on one stream (12 block-steps per repetition, distinct weights per block so the W stream is not an L2 replay), plus the max
 // difference of the residual stream and of the last q|k|v|q2 projection between the two forms.
-// Build: tools/native/build.sh; run from the repo root: tools/native/rowchain_probe [lib]
+// Build: tools/native/build.sh; run from the repo root: tools/native/rowchain_probe [lib] [ffn width]
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -89,7 +89,10 @@ int main(int argc, char** argv) {
     err_t err = (err_t)dlsym(h, "ina_last_error");
     if (!gemm || !norm || !chain || !err) { fprintf(stderr, "missing symbols\n"); return 1; }
     printf("# %s\n", lib);
-    const int D = 384, F = 1024, NL = 12, ST = 1024, MODLD = NL * 4 * D + D;
+    const int F = argc > 2 ? atoi(argv[2]) : 1536;          // FFN width (1536: diffusers 0.33.1 as pinned; 1024: <= 0.32)
+    const int abl = argc > 3 ? atoi(argv[3]) : 0;           // experimental builds only: ablation bits handed to the kernel in the reserved field
+    const int D = 384, NL = 12, ST = 1024, MODLD = NL * 4 * D + D;
+    printf("# FFN %d, ablation %d\n", F, abl);
     const int ENVS_MAX = 64;
     const size_t rows_max = (size_t)ENVS_MAX * ST;
     void *att = bf16_buf(rows_max * D, 1, 1.0f), *ff, *proj, *hbuf, *qkvq, *qkvq_ref;
@@ -161,7 +164,8 @@ int main(int argc, char** argv) {
                 memset(&c, 0, sizeof c);
                 c.A = att; c.W1 = wo[l]; c.gamma1 = n2[l]; c.gate = m + D; c.X = X; c.gamma2 = fn1[l]; c.mod_scale2 = m + 2 * D; c.W2 = w13[l]; c.C2 = ff;
                 c.M = M; c.K1 = D; c.N2 = 2 * F; c.lda = D; c.ldw1 = D; c.ldx = D; c.ldw2 = D; c.ldc2 = F; c.glu2 = 1; c.mod_div = ST; c.mod_ld = MODLD; c.eps = 1e-5f;
-                c.waves = waves;
+                c._reserved = abl;
+                (void)waves;
                 if (chain(&c, nullptr)) return 1;
                 const int ln = (l + 1) % NL;
                 c.A = ff; c.W1 = w2[l]; c.gamma1 = fn2[l]; c.gate = m + 3 * D; c.gamma2 = n1[ln]; c.mod_scale2 = mod + (size_t)ln * 4 * D; c.W2 = wq[ln]; c.C2 = qkvq;
@@ -176,8 +180,8 @@ int main(int argc, char** argv) {
         HIP_OK(hipMemcpy(qkvq_ref, qkvq, (size_t)M * 4 * D * 2, hipMemcpyDeviceToDevice));
         HIP_OK(hipDeviceSynchronize());
         const int reps = 5;
-        for (int mode = 0; mode < 3; ++mode) {
-            const int waves = mode == 1 ? 4 : 8;
+        for (int mode = 0; mode < 2; ++mode) {
+            const int waves = 4;
             HIP_OK(hipMemcpy(x, x0, (size_t)M * D * 4, hipMemcpyDeviceToDevice));
             if (mode == 0 ? unfused(x) : chained(x, waves)) { fprintf(stderr, "mode %d: %s\n", mode, err()); return 3; }
             float d[2] = {0.f, 0.f};
@@ -196,7 +200,7 @@ int main(int argc, char** argv) {
             const double us = ms * 1e3 / (reps * NL);
             const double flop = 2.0 * M * D * (D + 2.0 * F + F + 4.0 * D);
             printf("%2d envs (%6d rows)  %-28s %8.1f us per block-step  %6.1f TF/s   max|dx| vs unfused %.3e (after 12 blocks)  max|dqkvq| %.3e\n", envs, M,
-                   mode == 0 ? "unfused (6 launches)" : mode == 1 ? "row chain, 128-row panels" : "row chain, 256-row panels", us, flop / us * 1e-6, d[0], d[1]);
+                   mode == 0 ? "unfused (6 launches)" : "row chain, 128-row panels", us, flop / us * 1e-6, d[0], d[1]);
         }
     }
     return 0;
