@@ -2,7 +2,7 @@
 #   bash tools/final_validation.sh <tag> [quick]      quick: skip the variant benches and the PMC passes
 export TMPDIR=/tmp
 R=$PWD
-TAG=${1:-r05}
+TAG=${1:-r06}
 QUICK=${2:-}
 mkdir -p $R/gpurun_out
 rm -f $R/gpurun_out/qwen_full_drift.txt $R/gpurun_out/qwen_outliers_drift.txt $R/gpurun_out/sft_full_drift.txt $R/gpurun_out/sft_navdp_drift.txt $R/gpurun_out/s1_b64_distribution.txt
@@ -11,23 +11,23 @@ for f in qwen_full_drift qwen_outliers_drift sft_full_drift sft_navdp_drift s1_b
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/gpurun_out/${TAG}_smoke.log 2>&1
 timeout 900 python bench.py > $R/gpurun_out/${TAG}_bench_n1_dual_b64.json 2> $R/gpurun_out/${TAG}_bench.err
 if [ -z "$QUICK" ]; then
-timeout 600 python bench.py --no-cpu-baseline --cadence reference > $R/gpurun_out/${TAG}_bench_n1_dual_b64_reference.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-variants --cadence reference > $R/gpurun_out/${TAG}_bench_n1_dual_b64_reference.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload s2_only > $R/gpurun_out/${TAG}_bench_s2_only_b7.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --num-history 8 --lookdown --steps 10 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_h8_lookdown.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --prefix-kv > $R/gpurun_out/${TAG}_bench_n1_dual_b64_prefixkv.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-variants --num-history 8 --lookdown --steps 10 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_h8_lookdown.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --prefix-kv --steps 20 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_prefixkv.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload navdp_s1 > $R/gpurun_out/${TAG}_bench_navdp_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload unet1d_s1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unet1d_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_sft.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline --no-prefetch > $R/gpurun_out/${TAG}_bench_sft_noprefetch.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --s2-every 2 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_s2every2.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --no-frag-weights > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_frag_weights.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --no-row-chain > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_row_chain.json 2>> $R/gpurun_out/${TAG}_bench.err
-timeout 600 python bench.py --no-cpu-baseline --decode-fused > $R/gpurun_out/${TAG}_bench_n1_dual_b64_decode_fused.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-variants --dit-ffn 1024 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_ffn1024.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-variants --no-frag-weights > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_frag_weights.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-variants --no-row-chain > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_row_chain.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --no-cpu-baseline --no-variants --no-fuse-decode-rope > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_fuse_decode_rope.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --workload host_stub --gpus 8 --steps 20 > $R/gpurun_out/${TAG}_bench_host_stub_8ranks.json 2>> $R/gpurun_out/${TAG}_bench.err
 fi
 timeout 300 python tools/step_breakdown.py > $R/gpurun_out/${TAG}_step_breakdown.log 2>&1
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/kt.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-variants > $R/gpurun_out/kt.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/kt/*.db | head -1) 45 > $R/gpurun_out/${TAG}_n1_dual_b64_kernel_stats.txt 2>&1
 rm -rf $R/gpurun_out/kt
 for w in s1 s2; do
@@ -55,11 +55,12 @@ if [ -x tools/native/chain_sweep ]; then
   timeout 90 tools/native/chain_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_w4_chain.txt spec > $R/gpurun_out/${TAG}_native_w4_chain.log 2>&1
   timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so all part > $R/gpurun_out/${TAG}_native_chain_partitions.log 2>&1
   timeout 60 tools/native/chain_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_phase_mix.txt spec > $R/gpurun_out/${TAG}_native_phase_mix.log 2>&1
-  timeout 20 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
+  timeout 30 tools/native/skinny_sweep internnav_amd/libinternnav_amd.so 6 > $R/gpurun_out/${TAG}_native_skinny.log 2>&1
   timeout 20 tools/native/attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_attn.log 2>&1
   timeout 120 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r05_w4p.txt > $R/gpurun_out/${TAG}_native_w4p.log 2>&1
   timeout 60 tools/native/dit_attn_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_dit_attn.log 2>&1
-  timeout 60 tools/native/rowchain_probe internnav_amd/libinternnav_amd.so > $R/gpurun_out/${TAG}_native_rowchain.log 2>&1
+  timeout 60 tools/native/rowchain_probe internnav_amd/libinternnav_amd.so 1536 > $R/gpurun_out/${TAG}_native_rowchain.log 2>&1
+  timeout 60 tools/native/rowchain_probe internnav_amd/libinternnav_amd.so 1024 > $R/gpurun_out/${TAG}_native_rowchain_ffn1024.log 2>&1
   timeout 60 tools/native/issue_cost_probe > $R/gpurun_out/${TAG}_native_issue_cost.log 2>&1
 fi
 tail -3 $R/gpurun_out/${TAG}_pytest_gpu.log
