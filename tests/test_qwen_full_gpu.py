@@ -95,8 +95,11 @@ def test_full_depth_drift_logits_tokens_latents(full):
     assert ld.mean().item() <= float(gold["bf16_logits"]["mean"])
     assert ld.mean().item() <= 5e-3 * std      # absolute reading of the tolerance at 60 layers of depth (measured value printed above)
 
-    # greedy tokens: identical wherever the fp32 margin exceeds twice the worst logit error; a sequence stops being comparable after
-    # its first (legitimate, sub-margin) divergence
+    # greedy tokens (the reference parses the decoded ids with a regex, internvla_n1_policy.py:169-186: they must be the same tokens). There is ONE
+    # decode path in the engine (no kernel switch can change them: tests/test_qwen_gpu.py::test_single_token_pass_variants_agree); against the fp32
+    # oracle a token may differ ONLY at a step whose fp32 top-2 margin is below 0.04 logits - twice the largest logit error ANY bf16 arithmetic shows
+    # here (the engine's max is 2.0e-2, the reference's own bf16 path 6.7e-2) - and a sequence stops being comparable after such a step.
+    NEAR_TIE = 0.04
     toks = eng.decode(state, gold["n_decode"]).cpu().long()
     ref_t, margins = gold["tokens"], gold["margins"]
     n_cmp, alive = 0, [True] * B
@@ -107,13 +110,17 @@ def test_full_depth_drift_logits_tokens_latents(full):
             if toks[b, j] == ref_t[b, j]:
                 n_cmp += 1
             else:
-                assert margins[b, j] <= 2 * max(ld.max().item(), td.max().item()), f"env {b} token {j}: {toks[b, j]} != {ref_t[b, j]} although the fp32 margin is {margins[b, j]:.3f}"
+                assert margins[b, j] < NEAR_TIE, f"env {b} token {j}: {toks[b, j]} != {ref_t[b, j]} although the fp32 margin is {margins[b, j]:.3f}"
                 alive[b] = False
-    lines = [f"greedy tokens: {n_cmp} of {B * gold['n_decode']} compared equal; envs still identical after {gold['n_decode']} tokens: {sum(alive)} of {B}",
+    clear = [b for b in range(B) if bool((margins[b] >= NEAR_TIE).all())]
+    lines = [f"greedy tokens: {n_cmp} of {B * gold['n_decode']} compared equal; envs still identical after {gold['n_decode']} tokens: {sum(alive)} of {B}; "
+             f"envs without a near-tie (all margins >= {NEAR_TIE}): {clear} - all identical: {all(alive[b] for b in clear)}",
              f"engine {toks.tolist()}", f"fp32   {ref_t.tolist()}"]
-    # the fixture's margins: envs 3, 5, 6 never come closer than 0.04 logits to a tie over the 8 steps, the other four have one
-    # sub-0.02 step each (random-weight logits over 152064 entries) - those may legitimately flip, the three must not
-    assert sum(alive) >= 3 and n_cmp >= 3 * gold["n_decode"]
+    # the fixture: envs 3, 5, 6 never come closer than 0.04 logits to a tie over the 8 steps - they must be identical; the other four carry one or two
+    # sub-0.02 steps each (random-weight logits over 152064 entries). Of the 56 tokens at most those behind a near-tie flip may be lost.
+    assert len(clear) >= 3 and all(alive[b] for b in clear)
+    near = int((margins < NEAR_TIE).sum())
+    assert sum(alive) >= B - near and n_cmp >= len(clear) * gold["n_decode"]
     # the 4 latent queries on the KV cache generate() left (reference: full re-run, internvla_n1.py:320-347)
     lat = eng.latents(state, toks[:, -1:].to(DEV, torch.int32).contiguous()).float().cpu()
     keep = torch.tensor(alive)
