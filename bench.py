@@ -396,8 +396,7 @@ class N1Dual:
         # raw camera frames (the metric's input: N x 640x480 RGB per env) resident in HBM; every step runs them through the
         # bit-exact device pre-processor (PIL bicubic 640x480 -> 384x384 -> 392x392, rescale / normalise / patchify for the System-2
         # micro-batch; 640x480 -> 224x224, / 255 for the System-1 look-down pair = frames 0 and N-1), one batched launch per stage
-        self.raw = not getattr(a, "no_raw_frames", False)
-        assert self.raw or not self.lookdown, "--lookdown needs the raw-frame path (the look-down frame is pre-processed at camera size)"
+        self.raw = True          # (the round-1 boundary - resident pixel_values / 224x224 frames - is gone: the timed step starts at raw camera frames)
         if self.raw:
             from internnav_amd.preprocess import FramePreprocessor
 
@@ -420,7 +419,8 @@ class N1Dual:
                                 + ("(= the reference's LuminaFeedForward(dim, inner_dim=4*dim) under its pinned diffusers 0.33.1; unverified against a released checkpoint)"
                                    if scfg["dit_ffn"] == 1536 else "(= the diffusers <= 0.32 convention of LuminaFeedForward; rounds 1-5 timed this width)")) if self.with_s1 else "none",
                      "s1": ("2 look-down frames @224x224, 32 samples x 10 flow-matching steps" + ("" if getattr(a, "no_row_chain", False) else
-                            "; row-local chain of every DiT block in two launches (dit_rowchain, 128-row panels)")) if self.with_s1 else "none",
+                            ("; row-local chain of every DiT block in two launches (dit_rowchain, 128-row panels)" if scfg["dit_ffn"] <= 1024 else
+                             "; attn2.to_out + norms + SwiGLU of every DiT block in one launch (dit_rowchain, 128-row panels), linear_2 and the next projection as GEMM + norm launches"))) if self.with_s1 else "none",
                      "s2_microbatches_per_period": self.mb, "s2_every": self.s2_every, "s1_side_stream_envs_per_step": sorted(set(len(x) for x in side))}
         self.desc["s2_prefill"] = ("two half micro-batches on two streams (fork / join inside the captured launch sequence), GEMM tiles selected in the shared-tail mode (force_cfg = -1)"
                                    if self.model.qwen.split_prefill else "one launch sequence")
@@ -501,11 +501,8 @@ class N1Dual:
             self.traj = torch.zeros(B, scfg["sample_num"], scfg["predict_size"], 3, device=dev)
             self.hostA = torch.empty(nA, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
             self.hostB = torch.empty(mmax, scfg["sample_num"], scfg["predict_size"], 3).pin_memory()
-            self.gA, self.gB, self.gP, self.gD, self.gD1, self.gAimg = {}, {}, {}, {}, {}, {}
-            self.ev, self.ev_img, self.ev_go = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-            self.s1_delay = max(0, min(int(getattr(a, "s1_delay_passes", 0)), self.N_DECODE - 1))
-            if self.s1_delay:
-                self.desc["s1_start"] = f"side-stream System-1 call starts behind the first {self.s1_delay} single-token decode passes (its look-down encoder pass right behind the prefill)"
+            self.gA, self.gB, self.gP, self.gD, self.gAimg = {}, {}, {}, {}, {}
+            self.ev, self.ev_img = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- ingest: raw frames -> engine inputs (inside the timed step)
     def _ingest_s2(self, lo, m, dst):
@@ -587,12 +584,8 @@ class N1Dual:
                     s = self.s2[m]
                     self.gP[m] = runtime.GraphedCall(lambda s=s: q.run_prefill(s["P"], s["pv"]), {})
 
-                    kd = self.s1_delay
-                    if kd:        # the decode chain in two graphs: tokens [0, kd] (kd single-token passes), then the rest + the latent queries
-                        self.gD1[m] = runtime.GraphedCall(lambda s=s: q.run_decode(s["P"], s["toks"], 0, kd), {})
-
                     def dec(s=s):
-                        q.run_decode(s["P"], s["toks"], kd, None)
+                        q.run_decode(s["P"], s["toks"], 0, None)
                         q.run_latents(s["P"], s["lat"])
                     self.gD[m] = runtime.GraphedCall(dec, {})
 
@@ -657,16 +650,11 @@ class N1Dual:
         self._ingest_s2(lo, m, s["pv"])
         self.gP[m]()
         self.ev.record(main)
-        if self.s1_delay:
-            self.gD1[m]()
-            self.ev_go.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.ev)
             if self.merge_images:
                 self.gAimg[(nA, m)]()
                 self.ev_img.record(self.side)
-            if self.s1_delay:
-                self.side.wait_event(self.ev_go)
             trajA = self.gA[nA]()
         self.gD[m]()
         self.latent_table[lo:lo + m].copy_(s["lat"])
@@ -1125,13 +1113,16 @@ def main():
         }
         if overlap_check is not None:
             line["config"]["schedule_check"] = {"max_abs_diff_vs_single_stream": round(overlap_check[0], 5), "traj_abs_max": round(overlap_check[1], 3)}
-        # the CPU port of the reference path is timed on rank 0 of a single-GPU run only (contract); the key is always present
-        line["cpu_baseline"] = wl.cpu_baseline() if (world == 1 and not a.no_cpu_baseline) else None
         plain = (a.workload == "n1_dual" and a.cadence == "nominal" and not (a.prefix_kv or a.vit_cache or a.lookdown or a.no_graph or a.no_overlap) and
                  a.s2_every == 1 and a.num_history == 3 and a.dit_ffn == 1536)
+        cpu_leg = wl.cpu_baseline if (world == 1 and not a.no_cpu_baseline) else None
         if world == 1 and plain and not a.no_variants:
-            del wl
+            # (before the CPU leg: that one leaves 64 busy host threads behind it, and the variants' steps carry host work)
             line["variants"] = n1_variants(a, dev)
+        # the CPU port of the reference path is timed on rank 0 of a single-GPU run only (contract); the key is always present
+        nthr = torch.get_num_threads()
+        line["cpu_baseline"] = cpu_leg() if cpu_leg is not None else None
+        torch.set_num_threads(nthr)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

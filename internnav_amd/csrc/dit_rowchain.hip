@@ -1,7 +1,9 @@
 // Row-chain kernel of a NextDiT block (gfx950): everything between two attention stages that is LOCAL TO A ROW, in one launch.
 //
-//     P  = A[M,K1] . W1[384,K1]^T                                  attn2.to_out (K1 = 384) / feed_forward.linear_2 (K1 = the FFN width: 1536 under the
-//                                                                  reference's pinned diffusers 0.33.1, 1024 under <= 0.32), rounded to bf16
+//     P  = A[M,K1] . W1[384,K1]^T                                  attn2.to_out (K1 = 384) / feed_forward.linear_2 at FFN width 1024 (K1 = 1024), rounded to bf16
+//                                                                  (FFN 1536 - the reference's block under its pinned diffusers 0.33.1 - runs the FIRST launch form only,
+//                                                                  with N2 = 3072: a K1 = 1536 build of the second form was measured slower inside the policy step,
+//                                                                  profiles/r06i_rowchain_halves_in_step.txt, and is not built)
 //     X += tanh(gate[b]) * rmsnorm(P) * gamma1                     norm2 / ffn_norm2 + tanh gate + residual (fp32 stream, in place)
 //     H  = rmsnorm(X) * gamma2 * (1 + mod_scale2[b])               ffn_norm1 / the next block's norm1 + adaLN scale (bf16 GEMM operand)
 //     C2 = H . W2[N2,384]^T   or   silu(H . Wg^T) * (H . Wu^T)      feed_forward.linear_1/3 + SiLU gate (GLU)  /  the next block's q1|k1|v1|q2
@@ -492,7 +494,7 @@ int ina_launch_dit_rowchain(const ina_dit_rowchain_args& p_in, hipStream_t strea
     if (p.mod_div <= 0) p.mod_div = p.M;
     constexpr int nw = 4;
     INA_REQUIRE(p.A && p.W1 && p.X && p.gamma1, "dit_rowchain: A, W1, X and gamma1 are required");
-    INA_REQUIRE(p.K1 == 384 || p.K1 == 1024 || p.K1 == 1536, "dit_rowchain: K1=%d (built for 384 = attn2.to_out and 1024 / 1536 = feed_forward.linear_2)", p.K1);
+    INA_REQUIRE(p.K1 == 384 || p.K1 == 1024, "dit_rowchain: K1=%d (built for 384 = attn2.to_out and 1024 = feed_forward.linear_2)", p.K1);
     INA_REQUIRE(p.M > 0 && p.M % (nw * 32) == 0 && p.mod_div % (nw * 32) == 0, "dit_rowchain: M=%d and mod_div=%d must be multiples of the %d-row panel", p.M,
                 p.mod_div, nw * 32);
     INA_REQUIRE(p.lda % 8 == 0 && p.ldw1 % 8 == 0 && p.ldx % 4 == 0 && (!p.H || p.ldh % 8 == 0), "dit_rowchain: row strides must keep 16-byte alignment");
@@ -504,10 +506,9 @@ int ina_launch_dit_rowchain(const ina_dit_rowchain_args& p_in, hipStream_t strea
         INA_REQUIRE(p.C2 && p.N2 > 0 && p.N2 % 128 == 0 && p.ldw2 % 8 == 0 && p.ldc2 % 8 == 0 && ((uintptr_t)p.W2 % 16) == 0 && ((uintptr_t)p.C2 % 16) == 0,
                     "dit_rowchain: second GEMM needs C2, N2 %% 128 == 0 and 16-byte aligned rows (N2=%d)", p.N2);
         INA_REQUIRE(!p.seg_stats || (!p.glu2 && p.N2 % 384 == 0 && ((uintptr_t)p.seg_stats % 8) == 0), "dit_rowchain: seg_stats needs a plain second GEMM with N2 %% 384 == 0 (N2=%d)", p.N2);
-        INA_REQUIRE(p.glu2 ? p.K1 == 384 : p.K1 != 384, "dit_rowchain: built pairs are (K1 = 384, SwiGLU second GEMM) and (K1 = 1024 | 1536, plain second GEMM)");
+        INA_REQUIRE(p.glu2 ? p.K1 == 384 : p.K1 != 384, "dit_rowchain: built pairs are (K1 = 384, SwiGLU second GEMM) and (K1 = 1024, plain second GEMM)");
     }
     ina_prof_set_sub(42);
     if (p.K1 == 384) return !p.W2 ? launch_rowchain<4, 6, false, false>(p, stream) : launch_rowchain<4, 6, true, true>(p, stream);
-    if (p.K1 == 1024) return !p.W2 ? launch_rowchain<4, 16, false, false>(p, stream) : launch_rowchain<4, 16, true, false>(p, stream);
-    return !p.W2 ? launch_rowchain<4, 24, false, false>(p, stream) : launch_rowchain<4, 24, true, false>(p, stream);
+    return !p.W2 ? launch_rowchain<4, 16, false, false>(p, stream) : launch_rowchain<4, 16, true, false>(p, stream);
 }

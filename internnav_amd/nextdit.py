@@ -60,6 +60,10 @@ class NextDiTSystem1:
         self.row_chain = (bool(row_chain) and cfg["dit_dim"] == 384 and cfg["dit_ffn"] in (1024, 1536)
                           and (cfg["sample_num"] * cfg["predict_size"]) % 128 == 0)
         self.chain_min_rows = 16384
+        # The two chain launches are selected separately (the unselected half runs its GEMM / norm launches). The second one pays inside the policy
+        # step at FFN 1024 (+ 0.9 %) and costs at FFN 1536 (- 1.0 %: its first GEMM re-reads the 32 x 1536 SwiGLU panel once per column tile, and its
+        # long workgroups hold the CUs the concurrent decode chain wants) - profiles/r06i_rowchain_halves_in_step.txt
+        self.chain_a, self.chain_b = True, cfg["dit_ffn"] <= 1024
         # the chain's second launch also hands the attention stage the LayerNorm statistics of the projection rows it writes (blocks 1 ...):
         # dit_attention then reads every row once and runs without its statistics pass / barrier
         self.chain_stats = True
@@ -266,37 +270,38 @@ class NextDiTSystem1:
         m = mod[:B, l * 4 * D:(l + 1) * 4 * D]
         scale_msa, gate_msa, scale_mlp, gate_mlp = m[:, :D], m[:, D:2 * D], m[:, 2 * D:3 * D], m[:, 3 * D:]
         chain = self.row_chain and rows >= self.chain_min_rows
-        if l == 0 or not chain:   # later blocks of the row chain get their projection from the previous block's second launch
-            if l == 0:            # (unchained: later blocks get their pre-norm from the previous block's ffn_norm2 launch)
+        chain_a, chain_b = chain and self.chain_a, chain and self.chain_b
+        if l == 0 or not chain_b:   # later blocks of the chain get their projection from the previous block's second chain launch
+            if l == 0:              # (unchained: later blocks get their pre-norm from the previous block's ffn_norm2 launch)
                 ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
             ops.linear(h, Lr["wq"], out=qkvq)
         # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
         # env's condition rows (shared by its S samples): one launch, the projection row is read once
         kv5 = cs["kv2"][l][: B * Lz].view(B, Lz, 2, nh, hd)
-        stats = self.qstats[:rows] if (chain and self.chain_stats) else None
+        stats = self.qstats[:rows] if (chain_b and self.chain_stats) else None
         ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5,
                           stats=stats if l > 0 else None)
-        if chain:
-            last = l + 1 >= self.nl
+        last = l + 1 >= self.nl
+        nxt = None if last else mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
+        if chain_a:
             # attn2.to_out -> x += tanh(gate_msa) * norm2(.) -> ffn_norm1(x) * (1 + scale_mlp) -> linear_1/3 + SiLU gate
             ops.dit_rowchain(att, Lr["wo"], Lr["n2"], x, gate=gate_msa, gamma2=Lr["fn1"], mod_scale2=scale_mlp, w2=Lr["w13"], c2=ff, glu2=True,
                              mod_div=S * T, eps=1e-5)
+        else:
+            ops.linear(att, Lr["wo"], out=proj)
+            # x += tanh(gate) * norm2(attn) and, chained in the same launch on the fresh row, h = ffn_norm1(x) * (1 + scale_mlp)
+            ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x,
+                     out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
+            ops.linear(h, Lr["w13"], act="silu", glu=True, out=ff)
+        if chain_b:
             # linear_2 -> x += tanh(gate_mlp) * ffn_norm2(.) -> the next block's norm1(x) * (1 + scale_msa) -> its q1|k1|v1|q2 projection
             if last:
                 ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, mod_div=S * T, eps=1e-5)
             else:
-                nxt = mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
                 ops.dit_rowchain(ff, Lr["w2"], Lr["fn2"], x, gate=gate_mlp, gamma2=self.layers[l + 1]["n1"], mod_scale2=nxt,
                                  w2=self.layers[l + 1]["wq"], c2=qkvq, mod_div=S * T, eps=1e-5, seg_stats=stats, seg_eps=1e-5)
             return
-        ops.linear(att, Lr["wo"], out=proj)
-        # x += tanh(gate) * norm2(attn) and, chained in the same launch on the fresh row, h = ffn_norm1(x) * (1 + scale_mlp)
-        ops.norm(proj, Lr["n2"], None, eps=1e-5, rms=True, gate=gate_msa, base=x, mod_div=S * T, out32=x,
-                 out2=h, gamma2=Lr["fn1"], mod_scale2=scale_mlp)
-        # linear_1/3 + SiLU gate, linear_2, then x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
-        last = l + 1 >= self.nl
-        nxt = None if last else mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
-        ops.linear(h, Lr["w13"], act="silu", glu=True, out=ff)
+        # linear_2, then x += tanh(gate) * ffn_norm2(ffn) and the next block's norm1(x) * (1 + scale_msa)
         ops.linear(ff, Lr["w2"], out=proj)
         if last:
             ops.norm(proj, Lr["fn2"], None, eps=1e-5, rms=True, gate=gate_mlp, base=x, mod_div=S * T, out32=x)

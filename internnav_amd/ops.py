@@ -497,7 +497,7 @@ def dit_rowchain(a_in: torch.Tensor, w1: torch.Tensor, gamma1: torch.Tensor, x: 
         x += tanh(gate[r // mod_div]) * rmsnorm(bf16(a_in @ w1.T)) * gamma1
         H  = rmsnorm(x) * gamma2 * (1 + mod_scale2[r // mod_div])
         c2 = H @ w2.T   (glu2: silu(H @ wg.T) * (H @ wu.T) with w2's rows interleaved [gate16 | up16])
-    a_in bf16 [M, K1] (K1 = 384 | 1024 | 1536; M a multiple of 128), w1 bf16 [384, K1], x f32 [M, 384] (in place); w2 bf16 [N2, 384] -> c2 bf16 [M, N2 (/ 2)], or w2 None
+    a_in bf16 [M, K1] (K1 = 384 | 1024; M a multiple of 128), w1 bf16 [384, K1], x f32 [M, 384] (in place); w2 bf16 [N2, 384] -> c2 bf16 [M, N2 (/ 2)], or w2 None
     (then h bf16 [M, 384] may be given to receive H). The projection and H never leave the chip.
     seg_stats f32 [M, N2 // 384, 2] (plain second GEMM): receives (mean, rstd) of every 384-wide segment of the c2 rows = the LayerNorm
     statistics dit_attention(stats=) consumes."""

@@ -9,6 +9,7 @@ driver with no Python in the loop. Inputs live in static device buffers that are
 from __future__ import annotations
 
 import ctypes as C
+import gc
 from typing import Callable, Dict
 
 import torch
@@ -49,8 +50,18 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = fn(**static_inputs)
+        # The cyclic garbage collector must not run inside the capture: engines and older GraphedCall objects sit in reference cycles (closures
+        # over `self`), and collecting one of them there destroys its hipGraph / events while the stream is capturing - HIP refuses that, the
+        # destructor throws and the process aborts ("Fatal Python error: Aborted ... Garbage-collecting", seen once in 430 GPU tests, r06v).
+        # torch.cuda.graph() collects BEFORE the capture begins; the capture itself runs with the collector off.
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.outputs = fn(**static_inputs)
+        finally:
+            if was_enabled:
+                gc.enable()
         _lib.check(_lib.lib().ina_set_workspace_slot(0), "set_workspace_slot")
 
     def __call__(self, **new_inputs):

@@ -115,7 +115,7 @@ def test_nextdit_b64_distribution(built_lib, gold, section, cfg):
     sd = W.n1_nextdit_state_dict(seed=g["seed"], cfg=cfg)
     inp = W.n1_nextdit_inputs(B, seed=g["seed"])
     eng = NextDiTSystem1(sd, cfg, DEV, max_envs=B)
-    assert eng.row_chain
+    assert eng.row_chain and eng.chain_a and eng.chain_b == (cfg["dit_ffn"] <= 1024)      # (which chain launches run: profiles/r06i_rowchain_halves_in_step.txt)
     out = eng.generate_traj(inp["traj_latents"].to(DEV, torch.bfloat16), inp["images"].to(DEV, torch.bfloat16), inp["x_init"].to(DEV))
     mine = _per_env(out.view(B, *g["latents"].shape[1:]), g["latents"])
     r = _report("NextDiT B=64 trajectory latents", mine, g["yard"])

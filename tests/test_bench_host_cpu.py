@@ -9,7 +9,7 @@ import bench
 
 def test_default_args_match_the_parser(monkeypatch):
     monkeypatch.setattr("sys.argv", ["bench.py"])
-    a, d = bench.parse(), bench.default_args(no_cpu_baseline=False)
+    a, d = bench.parse(), bench.default_args(no_cpu_baseline=False, no_variants=False)     # (tools build workloads without the two post-run legs)
     for k, v in vars(a).items():
         assert getattr(d, k) == v, k
     monkeypatch.setattr("sys.argv", ["bench.py", "--workload", "s2_only"])
