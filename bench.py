@@ -871,39 +871,29 @@ def n1_cpu_baseline(qc, grids, pv_rows, ids, n_decode, cadence, with_s1, unit, d
                            + f"; combined as {how}"}, **out)
 
 
-def n1_variants(a, dev, steps: int = 10, warmup: int = 3) -> dict:
+def n1_variants(a, steps: int = 10, warmup: int = 3) -> dict:
     """the headline workload under its two EXACT schedule variants and at the other FFN width, `steps` timed steps each on this same box, for
     the driver's record (the headline `value` is not touched): prefix_kv = K/V of template + instruction + frame 0 from a per-env cache
     (--prefix-kv: causal attention, bit-exact), s2_every2 = System-2 micro-batches of 12-14 envs on every other step (--s2-every 2: same calls per
     env, the single-token passes stream the decoder weights half as often; worse step-latency spread), dit_ffn_1024 = the NextDiT FFN of the
-    diffusers <= 0.32 convention (what rounds 1-5 timed)."""
-    import copy
-    import gc
+    diffusers <= 0.32 convention (what rounds 1-5 timed). Each variant is this same file run in a fresh process (its line is what
+    `python bench.py <flag> --steps 10` prints): timed inside the headline's process the variants with eager host-side work per step came out
+    8-10 % low (profiles/r06j_variants_inline_vs_process.txt)."""
+    import subprocess
 
     out = {}
-    for name, kw in (("prefix_kv", dict(prefix_kv=True)), ("s2_every2", dict(s2_every=2)), ("dit_ffn_1024", dict(dit_ffn=1024))):
-        b = copy.copy(a)
-        for k, v in kw.items():
-            setattr(b, k, v)
-        gc.collect()
-        torch.cuda.empty_cache()
-        w = N1Dual(b, dev, 0)
-        w.capture()
-        for i in range(warmup):
-            w.step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        marks = [t0]
-        for i in range(steps):
-            w.step(warmup + i)
-            marks.append(time.perf_counter())
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        lat = np.diff(np.asarray(marks)) * 1e3
-        out[name] = {"value": round(w.B * steps / dt, 2), "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
-                     "p50": round(float(np.percentile(lat, 50)), 2), "max": round(float(lat.max()), 2), "workload": w.name,
-                     "algorithmic_tflop_per_env_step": round(w.f_alg / 1e12, 4)}
-        del w
+    for name, flags in (("prefix_kv", ["--prefix-kv"]), ("s2_every2", ["--s2-every", "2"]), ("dit_ffn_1024", ["--dit-ffn", "1024"])):
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--envs", str(a.envs),
+               "--no-cpu-baseline", "--no-variants"] + flags
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            out[name] = {"value": d["value"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "p50": d["step_latency_ms"]["p50"], "max": d["step_latency_ms"]["max"],
+                         "workload": d["config"]["workload"], "algorithmic_tflop_per_env_step": d["roofline"]["whole_step"]["algorithmic_tflop_per_env_step"],
+                         "cmd": "python bench.py " + " ".join(cmd[2:])}
+        except Exception as e:      # a variant must never cost the headline line
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
@@ -1118,7 +1108,7 @@ def main():
         cpu_leg = wl.cpu_baseline if (world == 1 and not a.no_cpu_baseline) else None
         if world == 1 and plain and not a.no_variants:
             # (before the CPU leg: that one leaves 64 busy host threads behind it, and the variants' steps carry host work)
-            line["variants"] = n1_variants(a, dev)
+            line["variants"] = n1_variants(a)
         # the CPU port of the reference path is timed on rank 0 of a single-GPU run only (contract); the key is always present
         nthr = torch.get_num_threads()
         line["cpu_baseline"] = cpu_leg() if cpu_leg is not None else None
