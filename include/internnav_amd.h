@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11-17 other LDS-DMA tiles, 1-8 gemm_bf16_nt_kernel tiles, 34-37 = gemm_bf16_rowpanel_kernel<8|4 waves, 4|3 stages>, 38 / 39 = gemm_bf16_w4_kernel<256, 0|1> (four-wave 256x256 tile), 40 = gemm_bf16_w4p_kernel<256> (the same tile on fragment-ordered weights), 42 = dit_rowchain_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11 / 14 / 26 / 27 other LDS-DMA tiles, 1-5 gemm_bf16_nt_kernel tiles, 34 / 35 = gemm_bf16_rowpanel_kernel<8|4 waves>, 39 = gemm_bf16_w4_kernel<256> (four-wave 256x256 tile), 40 = gemm_bf16_w4p_kernel<256> (the same tile on fragment-ordered weights), 42 = dit_rowchain_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
@@ -95,9 +95,9 @@ int ina_gemm_bf16(const ina_gemm_args* args, void* stream);
  * ((n / 16) * (K / 32) + k / 32) * 512 + ((k % 32) / 8 * 16 + n % 16) * 8 + k % 8. Done once per weight at load time. */
 int ina_gemm_preshuffle(const void* W, void* Wp, int32_t N, int32_t K, int64_t ldw, void* stream);
 /* Which kernel ina_gemm_bf16 would run for these arguments - validation and tile selection only, nothing is launched and no GPU is needed
- * (the selection is host arithmetic on M / N / K, the epilogue and force_cfg): *kernel = 1-8 register-staged tiles, 11-29 / 33 LDS-DMA tiles
+ * (the selection is host arithmetic on M / N / K, the epilogue and force_cfg): *kernel = 1-5 register-staged tiles, 11-27 / 33 LDS-DMA tiles
  * (18 = 256x256 ping-pong, 21 = 192x256 ping-pong, 22 / 26 / 27 single-buffer tiles of the d = 384 heads, 33 = 256x256 with 16 waves),
- * 34-37 row-panel kernels (K = 384), 38 / 39 / 40 the 256x256 tile on four waves of 128x128 (39 is selected for wide no-residual K = 2048 .. 4096 GEMMs, 40 instead of it when Wp is given),
+ * 34 / 35 row-panel kernels (K = 384), 39 / 40 the 256x256 tile on four waves of 128x128 (39 is selected for wide no-residual K = 2048 .. 4096 GEMMs, 40 instead of it when Wp is given),
  * 30 = weight streaming with the fused input RMSNorm, 32 = weight streaming (M <= 64). Returns non-zero (and sets ina_last_error)
  * exactly when ina_gemm_bf16 would reject the arguments. */
 int ina_gemm_select(const ina_gemm_args* args, int* kernel);

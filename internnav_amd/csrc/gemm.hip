@@ -167,8 +167,8 @@ int launch_cfg(const GemmArgs& p, hipStream_t stream) {
 }  // namespace
 
 // Validation + kernel selection of one GEMM call, without launching anything (host arithmetic only: also reachable as ina_gemm_select so
-// that the selection can be inspected / tested without a GPU). `kernel`: 1-8 register-staged tiles (gemm_bf16_nt_kernel), 11-29 / 33
-// LDS-DMA tiles (gemm_glds.hip), 38 / 39 the four-wave 256 x 256 tile (gemm_w4.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 32 = weight streaming (gemm_skinny.hip).
+// that the selection can be inspected / tested without a GPU). `kernel`: 1-5 register-staged tiles (gemm_bf16_nt_kernel), 11-27 / 33
+// LDS-DMA tiles (gemm_glds.hip), 39 / 40 the four-wave 256 x 256 tile (gemm_w4.hip), 30 = weight-streaming kernel with the fused input RMSNorm, 32 = weight streaming (gemm_skinny.hip).
 int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     p = p_in;
     if (p.rowscale_div <= 0) p.rowscale_div = 1;
@@ -264,17 +264,17 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
         }
     }
     {
-        static const int known[] = {1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 29, 33, 34, 35, 36, 37, 38, 39, 40};
+        static const int known[] = {1, 2, 3, 4, 5, 11, 14, 18, 21, 22, 26, 27, 33, 34, 35, 39, 40};     // every one of them is a choice of the cost model above for some shape
         bool ok = false;
         for (int k : known) ok = ok || k == cfg;
         INA_REQUIRE(ok, "gemm: unknown tile config %d", cfg);
     }
     if (cfg == 40) INA_REQUIRE(p.Wp && p.N % 16 == 0 && p.batch == 1, "gemm: tile config 40 needs the fragment-ordered copy of W (Wp), N %% 16 == 0, no batch (N=%d)", p.N);
-    if (cfg == 38 || cfg == 39 || cfg == 40)
-        INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 38 / 39 / 40 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
+    if (cfg == 39 || cfg == 40)
+        INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 39 / 40 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
                     "(M=%d N=%d K=%d ldc=%d)", p.M, p.N, p.K, p.ldc);
-    if (cfg >= 34 && cfg <= 37)
-        INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34-37 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
+    if (cfg == 34 || cfg == 35)
+        INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34 / 35 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
                     "no scales / residual, bias + activation or SiLU-GLU (M=%d N=%d K=%d)", p.M, p.N, p.K);
     kernel = cfg;
     return 0;
@@ -293,11 +293,8 @@ int ina_launch_gemm(const GemmArgs& p_in, hipStream_t stream) {
         case 3: return launch_cfg<64, 128, 64, 1, 4>(p, stream);   // wave tile 64x32 (skinny M)
         case 4: return launch_cfg<64, 64, 64, 2, 2>(p, stream);    // wave tile 32x32
         case 5: return launch_cfg<128, 64, 64, 2, 2>(p, stream);   // wave tile 64x32 (narrow N)
-        case 6: return launch_cfg<256, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 128x64 (large problems)
-        case 7: return launch_cfg<256, 128, 64, 4, 2>(p, stream);  // 8 waves, wave tile 64x64
-        case 8: return launch_cfg<128, 256, 64, 2, 4>(p, stream);  // 8 waves, wave tile 64x64
-        case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 29: case 33: case 38: case 39: case 40: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
-        case 34: case 35: case 36: case 37: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
+        case 11: case 14: case 18: case 21: case 22: case 26: case 27: case 33: case 39: case 40: return ina_launch_gemm_glds(p, stream, cfg);  // LDS-DMA staged kernels (K % 64 == 0)
+        case 34: case 35: return ina_launch_gemm_rowpanel(p, stream, cfg);   // K = 384 row-panel kernels (gemm_rowpanel.hip)
         default: ina_set_error("gemm: unknown tile config %d", cfg); return -2;
     }
 }

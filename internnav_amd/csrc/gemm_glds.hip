@@ -286,141 +286,6 @@ __global__ __launch_bounds__(2 * WN * 64) void gemm_bf16_pp_kernel(GemmArgs p) {
     }
 }
 
-// Deep-ring ping-pong variant: 32-wide K stages (64-byte swizzled LDS rows, as gemm_rownorm.hip) in an NS-stage ring, so NS - 1 stages
-// ((NS - 1) x 32 KiB = 96 KiB at 256 x 256, NS = 4) are in flight under the MFMAs instead of the one 64 KiB stage of the kernel above:
-// the DMA of K stage t + NS - 1 is issued in the R slot of stage t and only has to have landed NS - 2 stages later. Same slot scheme
-// (two wave rows half a step apart, one s_barrier per slot), one R and one M slot per 32-wide stage:
-//     wave row 0:  slot 2t: R(t)  slot 2t+1: M(t)          wave row 1 (one extra barrier up front): slot 2t+1: R(t)  slot 2t+2: M(t)
-// Buffer (t + NS - 1) % NS = (t - 1) % NS was last read in R(t - 1) (row 1: slot 2t - 1, retired with lgkmcnt(0) before that slot's
-// barrier), so both rows may refill it from slot 2t on. Stage t + 1 must be complete for EVERY wave before row 0 reads it in slot
-// 2t + 2: each wave retires its share (counted vmcnt: the NS - 2 newer stages may stay outstanding) before the barrier that ends slot
-// 2t + 1 - the end of M(t) for row 0, the end of R(t) for row 1.
-template <int BM, int BN, int WN, int NS, bool STAGED>
-__global__ __launch_bounds__(2 * WN * 64) void gemm_bf16_pp32_kernel(GemmArgs p) {
-    constexpr int WM = 2, BK = 32, NW = WM * WN;
-    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    constexpr int A_INST = BM / 16 / NW, B_INST = BN / 16 / NW, INST = A_INST + B_INST;   // 1 KiB DMA wave-instructions (16 rows x 64 B) per wave and stage
-    constexpr size_t LDS_BYTES = size_t(NS) * (BM + BN) * BK * sizeof(bf16);
-    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0 && NS >= 3 && NS <= 4, "tile / ring shape");
-    extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
-    bf16* As = reinterpret_cast<bf16*>(smem_raw);          // [NS][BM][32]
-    bf16* Bs = As + NS * BM * BK;                          // [NS][BN][32]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    int tm, tn;
-    if (p.group_m > 1) {
-        const int gsz = p.group_m * tiles_n, grp = id / gsz, first = grp * p.group_m;
-        const int gm = min(tiles_m - first, p.group_m), in = id - grp * gsz;
-        tm = first + in % gm;
-        tn = in / gm;
-    } else {
-        tm = id / tiles_n;
-        tn = id % tiles_n;
-    }
-    const int m0 = tm * BM, n0 = tn * BN;
-    const bf16* __restrict__ A = reinterpret_cast<const bf16*>(p.A) + (size_t)blockIdx.y * p.strideA;
-    const bf16* __restrict__ W = reinterpret_cast<const bf16*>(p.W) + (size_t)blockIdx.y * p.strideW;
-
-    // 64-byte LDS rows: physical 16-byte chunk cp of row r holds logical chunk cp ^ sw4(r), sw4(r) = (-(r >> 2)) & 3 (conflict-free
-    // ds_read_b128 under the 4 x 16-lane service groups); the DMA lands lane-linearly, so the swizzle is applied on the SOURCE address
-    const bf16* asrc[A_INST];
-    const bf16* bsrc[B_INST];
-    const int drow = lane >> 2, dcp = lane & 3;
-    const int lc = (dcp ^ ((0 - (drow >> 2)) & 3)) << 3;
-#pragma unroll
-    for (int s = 0; s < A_INST; ++s) asrc[s] = A + (size_t)min(m0 + (wave * A_INST + s) * 16 + drow, p.M - 1) * p.lda + lc;
-#pragma unroll
-    for (int s = 0; s < B_INST; ++s) bsrc[s] = W + (size_t)min(n0 + (wave * B_INST + s) * 16 + drow, p.N - 1) * p.ldw + lc;
-    auto stage = [&](int buf, int k0) {
-        bf16* as = As + buf * BM * BK + wave * A_INST * 512;
-        bf16* bs = Bs + buf * BN * BK + wave * B_INST * 512;
-#pragma unroll
-        for (int s = 0; s < A_INST; ++s) glds16(asrc[s] + k0, as + s * 512);
-#pragma unroll
-        for (int s = 0; s < B_INST; ++s) glds16(bsrc[s] + k0, bs + s * 512);
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
-    const int frow = lane & 15, g = lane >> 4;
-    const int chunk = (g ^ ((0 - (frow >> 2)) & 3)) << 3;
-    bf16x8 fa[FM], fb[FN];
-    auto read_frags = [&](int buf) {
-        const bf16* as = As + buf * BM * BK + (wm * TM + frow) * BK + chunk;
-        const bf16* bs = Bs + buf * BN * BK + (wn * TN + frow) * BK + chunk;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(bs + j * 16 * BK);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(as + i * 16 * BK);
-    };
-    auto mfmas = [&]() {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-    auto slot_end = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // retire this wave's share of stage t + 1: the stages t + 2 .. min(t + NS - 1, nk - 1) issued after it may stay in flight
-    auto retire_next = [&](int t) {
-        const int newer = min(NS - 2, nk - 2 - t);
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * INST) : "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) stage(s, s * BK);
-    // stage 0 complete for everybody before the first R slot
-    {
-        const int newer = min(NS - 2, nk - 1);
-        if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * INST) : "memory");
-        else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                 // slot -1
-    if (wm == 1) __builtin_amdgcn_s_barrier();    // wave row 1 runs one slot behind
-    int buf = 0;
-    for (int t = 0; t < nk; ++t) {
-        // R(t): refill the buffer read in R(t - 1) with stage t + NS - 1, fetch this stage's fragments
-        {
-            const int nt = t + NS - 1;
-            int nb = buf + NS - 1;
-            if (nb >= NS) nb -= NS;
-            if (nt < nk) stage(nb, nt * BK);
-        }
-        read_frags(buf);
-        if (wm == 1) retire_next(t);              // row 1: this barrier ends slot 2t + 1
-        slot_end();
-        mfmas();                                  // M(t)
-        if (wm == 0) retire_next(t);              // row 0: this barrier ends slot 2t + 1
-        slot_end();
-        if (++buf == NS) buf = 0;
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();    // matching count for the extra barrier of row 1
-    if constexpr (STAGED) {
-        __syncthreads();
-        constexpr bool ALL = LDS_BYTES >= size_t(NW) * FM * 4096;
-        float* scratch = reinterpret_cast<float*>(smem_raw) + wave * (ALL ? FM * 1024 : 1024);
-        gemm_store_tile_staged<FM, FN, TM, TN, ALL>(p, acc, m0, n0, wm, wn, lane, scratch);
-    } else {
-        gemm_store_tile<FM, FN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
-    }
-}
-
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_glds(const GemmArgs& p, hipStream_t stream) {
     using C = GldsCfg<BM, BN, WM, WN, NS>;
@@ -473,32 +338,6 @@ int launch_pp(const GemmArgs& p, hipStream_t stream) {
     return 0;
 }
 
-template <int BM, int BN, int WN, int NS>
-int launch_pp32(const GemmArgs& p, hipStream_t stream) {
-    constexpr int TN = BN / WN, BK = 32;
-    constexpr size_t LDS_BYTES = size_t(NS) * (BM + BN) * BK * sizeof(bf16);
-    const size_t oes = p.out_dtype == INA_DT_BF16 ? 2 : 4, res = p.res_dtype == INA_DT_BF16 ? 2 : 4;
-    const bool staged = TN == 64 && ((uintptr_t)p.C % 16) == 0 && (p.ldc * oes) % 16 == 0 && (p.strideC * oes) % 16 == 0 &&
-                        (!p.R || (((uintptr_t)p.R % 16) == 0 && (p.ldr * res) % 16 == 0 && (p.strideR * res) % 16 == 0)) &&
-                        ((p.glu ? p.N / 2 : p.N) % 4 == 0);
-    static bool attr_done[2] = {false, false};
-    auto kern = staged ? gemm_bf16_pp32_kernel<BM, BN, WN, NS, true> : gemm_bf16_pp32_kernel<BM, BN, WN, NS, false>;
-    if (!attr_done[staged]) {
-        INA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        attr_done[staged] = true;
-    }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    GemmArgs q = p;
-    if (q.group_m == 0) q.group_m = ((p.N + BN - 1) / BN >= 24 && (p.M + BM - 1) / BM >= 8) ? 8 : 1;
-    const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
-    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K * p.batch,
-                      (double)p.batch * (2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N)), stream);
-    hipLaunchKernelGGL(kern, dim3(tiles, p.batch, 1), dim3(2 * WN * 64), LDS_BYTES, stream, q);
-    INA_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-
 }  // namespace
 
 // cfg 11: 128x128 / 4 waves / 2 stages, cfg 12: 256x128 / 8 waves / 2 stages, cfg 13: 128x256 / 8 waves / 2 stages,
@@ -510,25 +349,15 @@ int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg) {
     ina_prof_set_sub(cfg);
     switch (cfg) {
         case 11: return launch_glds<128, 128, 2, 2, 2>(p, stream);
-        case 12: return launch_glds<256, 128, 4, 2, 2>(p, stream);
-        case 13: return launch_glds<128, 256, 2, 4, 2>(p, stream);
         case 14: return launch_glds<256, 128, 4, 2, 3>(p, stream);
-        case 15: return launch_glds<128, 128, 2, 2, 3>(p, stream);
-        case 16: return launch_glds<128, 256, 2, 4, 3>(p, stream);
-        case 17: return launch_glds<256, 256, 2, 4, 2>(p, stream);   // wave tile 128x64
         case 22: return launch_glds<128, 128, 2, 2, 1>(p, stream);   // 128x128 single buffer, 4 workgroups per CU (2 waves of 128x64 wave tiles
                                                                       // instead of 4 of 64x64: 566 vs 726 TF/s at 65536x1536x384)
         case 26: return launch_glds<128, 256, 2, 4, 1>(p, stream);   // 128x256 single buffer (48 KiB LDS, 3 workgroups per CU), 85 FLOP per operand byte
         case 27: return launch_glds<256, 128, 4, 2, 1>(p, stream);   // 256x128 single buffer
         case 18: return launch_pp<256, 256, 4>(p, stream);           // 256x256, wave tile 128x64, ping-pong wave rows
-        case 19: return launch_pp<128, 256, 4>(p, stream);           // 128x256, wave tile 64x64, ping-pong wave rows
         case 21: return launch_pp<192, 256, 4>(p, stream);           // 192x256, wave tile 96x64: finer row quantisation for M = 5520 / 6440
-        case 23: return launch_pp32<256, 256, 4, 4>(p, stream);      // 256x256 ping-pong, 32-wide K stages, 4-stage ring (96 KiB in flight)
-        case 24: return launch_pp32<256, 256, 4, 3>(p, stream);      // same with a 3-stage ring (96 KiB LDS)
-        case 25: return launch_pp32<128, 256, 4, 4>(p, stream);      // 128x256, wave tile 64x64, 4-stage ring (96 KiB LDS)
         case 33: return launch_glds<256, 256, 4, 4, 2>(p, stream);   // 256x256 lock-step with 16 waves (wave tile 64x64, 4 waves per SIMD): the fp32-residual GEMMs with a short K loop
-        case 38: case 39: case 40: return ina_launch_gemm_w4(p, stream, cfg);                      // 256x256, FOUR waves of 128x128 (wave tile 128 x 128): gemm_w4.hip
-        case 29: return launch_pp32<128, 256, 4, 3>(p, stream);      // same with a 3-stage ring: 72 KiB LDS, 2 workgroups per CU (short-K experiment, round 3)
+        case 39: case 40: return ina_launch_gemm_w4(p, stream, cfg);                      // 256x256, FOUR waves of 128x128 (wave tile 128 x 128): gemm_w4.hip
         default: ina_set_error("gemm(glds): unknown tile config %d", cfg); return -2;
     }
 }

@@ -242,8 +242,6 @@ int ina_launch_gemm_rowpanel(const GemmArgs& p, hipStream_t stream, int cfg) {
     switch (cfg) {
         case 34: return launch_rowpanel<8, 4>(p, stream);
         case 35: return launch_rowpanel<4, 4>(p, stream);
-        case 36: return launch_rowpanel<8, 3>(p, stream);
-        case 37: return launch_rowpanel<4, 3>(p, stream);
         default: ina_set_error("gemm(row panel): unknown config %d", cfg); return -2;
     }
 }

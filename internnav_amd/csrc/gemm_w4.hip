@@ -61,8 +61,8 @@ __device__ __forceinline__ void for_seq(F&& f) {
     for_seq_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// VAR 0 (cfg 38): the wave's DMA instructions of a stage are issued in one clump right after the barrier (compiler builtin). VAR 1 (cfg 39): they
-// are threaded between the MFMAs of the stage's second slice (after MFMAs 1, 4, 7, ...) as asm pieces with a scalar base + 32-bit lane offset
+// (VAR 1 = cfg 39 is the only build: round 4's VAR 0 - the wave's DMA instructions of a stage in one clump right after the barrier - lost to it.) The DMA
+// instructions of a stage are threaded between the MFMAs of the stage's second slice (after MFMAs 1, 4, 7, ...) as asm pieces with a scalar base + 32-bit lane offset
 // (no vector address add per piece: 1477 vs 1440 TF/s at 8192^3, decoder chain 70.4 vs 70.9 ms, profiles/r04n_native_w4_saddr*.log); the last two
 // stages (which request nothing) run in a second copy of the loop body.
 template <int BM, int VAR>
@@ -115,13 +115,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
     uint32_t a_dma = lds0 + wave * C::A_INST * 1024u, b_dma = lds0 + B_BASE + wave * C::B_INST * 1024u;   // this wave's rows of the buffer to fill
     auto dma_one = [&](auto Dc, uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
         constexpr int D = decltype(Dc)::value;
-        if constexpr (VAR == 1) {
-            if constexpr (D < C::A_INST) glds16_saddr(A + k0, aoff[D], __builtin_amdgcn_readfirstlane(la + D * 1024u));
-            else glds16_saddr(W + k0, boff[D - C::A_INST], __builtin_amdgcn_readfirstlane(lb + (D - C::A_INST) * 1024u));
-        } else {
-            if constexpr (D < C::A_INST) glds16(asrc[D] + k0, la + D * 1024u);
-            else glds16(bsrc[D - C::A_INST] + k0, lb + (D - C::A_INST) * 1024u);
-        }
+        if constexpr (D < C::A_INST) glds16_saddr(A + k0, aoff[D], __builtin_amdgcn_readfirstlane(la + D * 1024u));
+        else glds16_saddr(W + k0, boff[D - C::A_INST], __builtin_amdgcn_readfirstlane(lb + (D - C::A_INST) * 1024u));
     };
     auto dma_stage = [&](uint32_t la, uint32_t lb, int k0) __attribute__((always_inline)) {
         for_seq<NDMA>([&](auto Dc) __attribute__((always_inline)) { dma_one(Dc, la, lb, k0); });
@@ -186,9 +181,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
         slice(IC<0>{}, IC<0>{}, a_rd[1], b_rd[1], 0u, 0u, 0);        // slice 0 multiplies, slice 1 of this stage lands in set 1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own share of stage t + 1 landed; the current buffer is not read any more
         __builtin_amdgcn_s_barrier();
-        if constexpr (VAR == 0) {
-            if (t + 2 < nk) dma_stage(a_dma, b_dma, (t + 2) * 64);   // refill it with stage t + 2
-        }
         // slice 1 multiplies, slice 0 of stage t + 1 (other buffer; stale LDS after the last stage) lands in set 0
         slice(IC<1>{}, DMAc, a_rd[0] + da, b_rd[0] + db, a_dma, b_dma, (t + 2) * 64);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -197,9 +189,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(GemmArgs p) {
         da = -da; db = -db;
     };
     int t = 0;
-    if constexpr (VAR >= 1) {
-        for (; t + 2 < nk; ++t) stage_body(IC<1>{}, t);
-    }
+    for (; t + 2 < nk; ++t) stage_body(IC<1>{}, t);
     for (; t < nk; ++t) stage_body(IC<0>{}, t);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the last MFMAs retire before the compiler-scheduled epilogue reads the accumulators
     // LDS-transposed epilogue only (the launcher rejects outputs it cannot take): the direct register epilogue indexes the accumulator
@@ -394,7 +384,7 @@ int launch_w4(const GemmArgs& p, hipStream_t stream) {
     constexpr int BN = 256;
     using C = GldsCfg<BM, BN, 2, 2, 2>;
     static_assert(C::LDS_BYTES >= size_t(4) * C::FM * 4096, "the per-wave epilogue scratch must fit in the two stage buffers");
-    INA_REQUIRE(ina_gemm_w4_contract(p), "gemm(w4): tile configs 38 / 39 need K %% 64 == 0 and 16-byte aligned output (and residual) rows (K=%d ldc=%d)", p.K, p.ldc);
+    INA_REQUIRE(ina_gemm_w4_contract(p), "gemm(w4): tile config 39 needs K %% 64 == 0 and 16-byte aligned output (and residual) rows (K=%d ldc=%d)", p.K, p.ldc);
     static bool attr_done = false;
     auto kern = gemm_bf16_w4_kernel<BM, VAR>;
     if (!attr_done) {
@@ -457,7 +447,6 @@ bool ina_gemm_w4_contract(const GemmArgs& p) {
 
 int ina_launch_gemm_w4(const GemmArgs& p, hipStream_t stream, int cfg) {
     switch (cfg) {
-        case 38: return launch_w4<256, 0>(p, stream);   // DMA clump after the barrier
         case 39: return launch_w4<256, 1>(p, stream);   // DMA pieces threaded between the MFMAs of the second slice (asm, scalar base + lane offset)
         case 40: return launch_w4p(p, stream);          // B fragments from the fragment-ordered copy of W straight into registers, LDS for A only
         default: ina_set_error("gemm(w4): unknown tile config %d", cfg); return -2;

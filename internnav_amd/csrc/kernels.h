@@ -46,11 +46,11 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel);   // validati
 int ina_launch_gemm_skinny_prenorm(const GemmArgs& p, hipStream_t stream);   // M <= 16 with the input RMSNorm fused in front (gemm_skinny.hip)
 int ina_launch_gemm_glds(const GemmArgs& p, hipStream_t stream, int cfg);  // direct-to-LDS staged large-K path
 int ina_launch_gemm_skinny_fused(const GemmArgs& p, hipStream_t stream);  // M <= 64 weight-streaming, workgroup owns its columns for all K, fused epilogue
-int ina_launch_gemm_rowpanel(const GemmArgs& p, hipStream_t stream, int cfg);  // gemm_rowpanel.hip: K = 384, register-resident row panels (cfg 34-37)
+int ina_launch_gemm_rowpanel(const GemmArgs& p, hipStream_t stream, int cfg);  // gemm_rowpanel.hip: K = 384, register-resident row panels (cfg 34 / 35)
 bool ina_gemm_rowpanel_contract(const GemmArgs& p);
 bool ina_gemm_w4_contract(const GemmArgs& p);
 int ina_launch_gemm_preshuffle(const void* W, void* Wp, int N, int K, long ldw, hipStream_t stream);   // gemm_w4.hip: W -> MFMA fragment order (cfg 40)
-int ina_launch_gemm_w4(const GemmArgs& p, hipStream_t stream, int cfg);        // gemm_w4.hip: 256 x 256 tile on four waves of 128 x 128 (cfg 38 / 39)
+int ina_launch_gemm_w4(const GemmArgs& p, hipStream_t stream, int cfg);        // gemm_w4.hip: 256 x 256 tile on four waves of 128 x 128 (cfg 39 / 40)
 int ina_launch_attention(const AttnArgs& p, hipStream_t stream);
 bool ina_attention_wide_eligible(const AttnArgs& p);                   // attention_wide.hip: long dense shapes (32 query rows per wave) - the automatic rule
 bool ina_attention_wide_contract(const AttnArgs& p);                   // what that kernel can run at all

@@ -108,11 +108,11 @@ def test_weight_streaming_paths(select):
 def test_forced_configs_and_rejections(select):
     assert select(6440, QKV, H, force_cfg=21) == 21 and select(6440, QKV, H, force_cfg=33) == 33 and select(6440, QKV, H, force_cfg=18) == 18
     # four-wave tile: forced anywhere inside its contract (16-byte aligned output rows), selected for wide no-residual K = 2048 .. 4096 GEMMs only
-    assert select(300, 264, 64, force_cfg=38) == 38 and select(6440, H, H, force_cfg=39, **RES) == 39
+    assert select(300, 264, 64, force_cfg=39) == 39 and select(6440, H, H, force_cfg=39, **RES) == 39
     assert select(2047, QKV, H) != 39 and select(6440, 4096, 2048) == 39 and select(6440, 4096, 4160) == 18 and select(6440, 3584, H) != 39
     bad = select(300, 260, 64, force_cfg=39)               # bf16 rows of 520 bytes
-    assert isinstance(bad, tuple) and "38 / 39" in bad[1]
+    assert isinstance(bad, tuple) and "39 / 40" in bad[1]
     for bad in (select(100, 100, 63), select(7, QKV, H, force_cfg=30), select(100, 48, 64, glu=1), select(0, 4, 8),
-                select(100, 102, 64), select(17, QKV, H, norm_gamma=0x3000, a_dtype=1), select(100, 512, 64, force_cfg=32), select(7, QKV, H, force_cfg=31), select(7, QKV, H, force_cfg=60),
+                select(100, 102, 64), select(17, QKV, H, norm_gamma=0x3000, a_dtype=1), select(100, 512, 64, force_cfg=32), select(7, QKV, H, force_cfg=31), select(7, QKV, H, force_cfg=60), select(6440, QKV, H, force_cfg=38), select(6440, QKV, H, force_cfg=23), select(65536, 1536, 384, force_cfg=36),
                 select(7, QKV, H, force_cfg=18, norm_gamma=0x3000, a_dtype=1)):
         assert isinstance(bad, tuple) and bad[0] == "error" and bad[1].startswith("gemm")

@@ -367,7 +367,7 @@ def test_bad_arguments_fail_loudly(ops):
         ops.attention(q, q, q)
 
 
-@pytest.mark.parametrize("cfg", [11, 12, 13, 14, 15, 16, 17, 18, 19, 21, 22, 23, 24, 25, 26, 27, 33, 38, 39])
+@pytest.mark.parametrize("cfg", [11, 14, 18, 21, 22, 26, 27, 33, 39])
 @pytest.mark.parametrize("M,N,K", [(300, 260, 320), (1000, 1280, 3456), (257, 4608, 3584), (130, 132, 64)])
 def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     """LDS-DMA staged kernels: ragged M/N edges (clamped rows), swizzled LDS, every epilogue term."""
@@ -380,7 +380,7 @@ def test_gemm_glds_tile_configs(ops, cfg, M, N, K):
     _close(out, ref, rtol=2e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (17, 5), (17, 0), (18, 8), (19, 3), (39, 8), (38, 3)])
+@pytest.mark.parametrize("cfg,group_m", [(11, 3), (11, 8), (14, 8), (26, 5), (27, 0), (18, 8), (21, 3), (39, 8), (33, 3)])
 def test_gemm_glds_grouped_tile_order(ops, cfg, group_m):
     """Grouped tile order (group_m row-tiles per group, ragged last group, auto rule at 0) is a pure re-ordering: same result as
     row-major, bit for bit, and equal to the fp32 reference."""
@@ -410,7 +410,7 @@ def test_gemm_shared_tail_selection_is_bit_equal(ops, M, N, K, glu):
     assert torch.equal(plain, ops.linear(x, w, force_cfg=-1, **kw))
 
 
-@pytest.mark.parametrize("cfg", [38, 39, 40])
+@pytest.mark.parametrize("cfg", [39, 40])
 @pytest.mark.parametrize("M,N,K,mode", [(2760, 4608, 3584, "bias"), (2100, 4096, 3584, "glu"), (777, 1024, 448, "glu"), (1000, 1000, 192, "res"),
                                         (300, 264, 64, "bias"), (515, 520, 128, "plain"), (2761, 3592, 320, "bf16res"),
                                         (300, 272, 64, "bias"), (515, 528, 128, "plain"), (1000, 1008, 192, "res"), (2761, 3600, 320, "bf16res")])
@@ -779,7 +779,7 @@ def test_rope_with_fused_kv_append_equals_rope_then_gather(ops):
     assert torch.equal(b[:, nh * D:], qkv[:, nh * D:])                      # k / v columns untouched in the fused form
 
 
-@pytest.mark.parametrize("cfg", [34, 35, 36, 37])
+@pytest.mark.parametrize("cfg", [34, 35])
 @pytest.mark.parametrize("M,N,glu", [(32, 128, False), (7168, 1536, False), (8224, 2048, True), (4128, 256, True), (65536, 1536, False)])
 def test_gemm_rowpanel_k384(ops, cfg, M, N, glu):
     """row-panel kernels of the d = 384 heads (csrc/gemm_rowpanel.hip: activations as register-resident MFMA fragments, W streamed through an
