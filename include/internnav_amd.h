@@ -87,6 +87,12 @@ typedef struct ina_gemm_args {
     const float* norm_gamma; /* f32 [K] or NULL (no fused norm; A is bf16) */
     float norm_eps;
     int32_t a_dtype;        /* dtype of A when norm_gamma is set: INA_BF16 | INA_F32 */
+    /* LayerNorm statistics of the produced rows (row-panel kernels only: K = 384, plain epilogue, N a multiple of 384, M >= 16384 rows): seg_stats
+     * f32 [M, N / 384, 2] receives (mean, 1 / sqrt(var + seg_eps)) of every 384-wide segment of C's fp32 row - what ina_dit_attention(stats=)
+     * consumes (the fused q1|k1|v1|q2 projection of a NextDiT block). Refused, not ignored, where another kernel would run. */
+    float* seg_stats;
+    float seg_eps;
+    int32_t _pad_seg;
     const void* Wp;         /* NULL, or the same W in MFMA fragment order (ina_gemm_preshuffle; N % 16 == 0, K % 32 == 0): tile config 40 takes its
                              * B fragments from it straight into registers (selected where cfg 39 would run; bit-equal results) */
 } ina_gemm_args;

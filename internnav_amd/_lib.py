@@ -25,6 +25,7 @@ class GemmArgs(C.Structure):
         ("strideA", c_int64), ("strideW", c_int64), ("strideC", c_int64), ("strideR", c_int64),
         ("force_cfg", c_int32), ("group_m", c_int32),
         ("norm_gamma", c_void_p), ("norm_eps", c_float), ("a_dtype", c_int32),
+        ("seg_stats", c_void_p), ("seg_eps", c_float), ("_pad_seg", c_int32),
         ("Wp", c_void_p),
     ]
 

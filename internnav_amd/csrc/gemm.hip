@@ -182,6 +182,7 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     INA_REQUIRE(!p.glu || (p.N % 32 == 0), "gemm: GLU mode needs N %% 32 == 0");
     // tile selection: big tiles when the grid still fills the 256 CUs, smaller ones otherwise
     // skinny M: HBM-bound weight streaming with split-K (gemm_skinny.hip) instead of an under-filled tile grid
+    INA_REQUIRE(!p.seg_stats || (p.M > 64 && !p.norm_gamma), "gemm: seg_stats exist in the row-panel kernels only (M >= 16384 rows; M=%d)", p.M);
     if (p.norm_gamma) {
         INA_REQUIRE(p.M <= 16 && p.batch <= 1 && p.K % 8 == 0 && p.K <= 4096 && p.N >= 256,
                     "gemm: the fused input RMSNorm is built for the decode passes (M <= 16 rows, K <= 4096, one batch): M=%d K=%d N=%d batch=%d", p.M, p.K, p.N, p.batch);
@@ -273,6 +274,8 @@ int ina_plan_gemm(const GemmArgs& p_in, GemmArgs& p, int& kernel) {
     if (cfg == 39 || cfg == 40)
         INA_REQUIRE(ina_gemm_w4_contract(p), "gemm: tile configs 39 / 40 (four-wave 256 x 256 tile) need K %% 64 == 0 and 16-byte aligned output / residual rows "
                     "(M=%d N=%d K=%d ldc=%d)", p.M, p.N, p.K, p.ldc);
+    INA_REQUIRE(!p.seg_stats || cfg == 34 || cfg == 35, "gemm: seg_stats (LayerNorm statistics of the produced rows) exist in the row-panel kernels only "
+                "(K = 384, plain epilogue, M >= 16384): this call would run tile config %d (M=%d N=%d K=%d)", cfg, p.M, p.N, p.K);
     if (cfg == 34 || cfg == 35)
         INA_REQUIRE(ina_gemm_rowpanel_contract(p), "gemm: tile configs 34 / 35 (row-panel kernels) need K = 384, N %% 128 == 0, M %% 32 == 0, bf16 output, "
                     "no scales / residual, bias + activation or SiLU-GLU (M=%d N=%d K=%d)", p.M, p.N, p.K);

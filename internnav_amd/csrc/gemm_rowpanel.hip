@@ -118,6 +118,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_rowpanel_kernel(GemmArgs
     bf16* __restrict__ Cb = reinterpret_cast<bf16*>(p.C);
     const size_t crow = (size_t)(m0 + lrow) * p.ldc;
 
+    // LayerNorm statistics of every 384-wide segment of the rows this launch produces (plain epilogue only; ina_gemm_args.seg_stats): what the
+    // attention stage of a NextDiT block needs for q1 / k1 / q2 (dit_attn_stats_kernel reads each projection row once instead of twice). Running
+    // sum / sum of squares of this lane's 64 of a tile's 128 columns over the fp32 accumulators, closed every third tile - the row chain's form
+    // (dit_rowchain.hip), so both producers hand the attention stage the same numbers.
+    float seg_s = 0.f, seg_q = 0.f;
+    int seg_t = 0;
+    float* __restrict__ seg_out = (!GLU && !EPI && p.seg_stats && live) ? p.seg_stats + (size_t)(m0 + lrow) * (size_t)(p.N / K) * 2 : nullptr;
+
     int t = 0;
     for (int nt = 0; nt < ntiles; ++nt) {
         f32x16 acc[4];
@@ -155,6 +163,31 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_rowpanel_kernel(GemmArgs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot have returned before it reaches the next barrier
         }
         // ---- epilogue of column tile nt: lane = output row m0 + lrow; acc[j][i * 4 + e] = column nt * 128 + j * 32 + i * 8 + khalf * 4 + e
+        if constexpr (!GLU && !EPI) {
+            if (seg_out) {
+                float ts[4] = {0.f, 0.f, 0.f, 0.f}, tq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        ts[j] += acc[j][r];
+                        tq[j] = fmaf(acc[j][r], acc[j][r], tq[j]);
+                    }
+                seg_s += (ts[0] + ts[1]) + (ts[2] + ts[3]);
+                seg_q += (tq[0] + tq[1]) + (tq[2] + tq[3]);
+                asm volatile("" : "+v"(seg_s), "+v"(seg_q));
+                if (++seg_t == 3) {
+                    seg_s += __shfl_xor(seg_s, 32);
+                    seg_q += __shfl_xor(seg_q, 32);
+                    const float mean = seg_s * (1.0f / K);
+                    const float var = fmaxf(seg_q * (1.0f / K) - mean * mean, 0.f);
+                    // both column halves of a row hold the same pair and store it to the same place (no exec-mask branch)
+                    *reinterpret_cast<f32x2*>(seg_out + (nt / 3) * 2) = f32x2{mean, rsqrtf(var + p.seg_eps)};
+                    seg_s = seg_q = 0.f;
+                    seg_t = 0;
+                }
+            }
+        }
         if (live) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -230,6 +263,7 @@ bool ina_gemm_rowpanel_contract(const GemmArgs& p) {
     if (p.glu && (p.act != INA_ACT_SILU || p.bias)) return false;
     if (p.bias && (((uintptr_t)p.bias % 16) || p.N > 4096)) return false;
     if (p.act < INA_ACT_NONE || p.act > INA_ACT_TANH) return false;
+    if (p.seg_stats && (p.glu || p.bias || p.act != INA_ACT_NONE || p.N % 384 != 0 || ((uintptr_t)p.seg_stats % 8))) return false;
     if (p.lda % 8 || p.ldw % 8 || p.ldc % 8 || ((uintptr_t)p.C % 16) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.W % 16)) return false;
     return true;
 }

@@ -271,16 +271,17 @@ class NextDiTSystem1:
         scale_msa, gate_msa, scale_mlp, gate_mlp = m[:, :D], m[:, D:2 * D], m[:, 2 * D:3 * D], m[:, 3 * D:]
         chain = self.row_chain and rows >= self.chain_min_rows
         chain_a, chain_b = chain and self.chain_a, chain and self.chain_b
+        # whoever produces the fused q1|k1|v1|q2 projection of >= 16 k rows - the second chain launch or the row-panel GEMM - also hands the
+        # attention stage the LayerNorm statistics of its rows (dit_attention then reads every row once, without a statistics pass / barrier)
+        stats = self.qstats[:rows] if (chain and self.chain_stats and D == 384) else None
         if l == 0 or not chain_b:   # later blocks of the chain get their projection from the previous block's second chain launch
             if l == 0:              # (unchained: later blocks get their pre-norm from the previous block's ffn_norm2 launch)
                 ops.norm(x, Lr["n1"], None, eps=1e-5, rms=True, mod_scale=scale_msa, mod_div=S * T, out=h)
-            ops.linear(h, Lr["wq"], out=qkvq)
+            ops.linear(h, Lr["wq"], out=qkvq, seg_stats=(stats, 1e-5) if stats is not None else None)
         # LayerNorm across heads on q1 / k1 / q2 + self-attention inside each sample's T tokens + gated cross-attention against the
         # env's condition rows (shared by its S samples): one launch, the projection row is read once
         kv5 = cs["kv2"][l][: B * Lz].view(B, Lz, 2, nh, hd)
-        stats = self.qstats[:rows] if (chain_b and self.chain_stats) else None
-        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5,
-                          stats=stats if l > 0 else None)
+        ops.dit_attention(qkvq, att, (Lr["q1n"], Lr["k1n"], Lr["q2n"]), kv5, cs["v2t"][l], Lr["gate"], T=T, seq_per_env=S, heads=nh, eps=1e-5, stats=stats)
         last = l + 1 >= self.nl
         nxt = None if last else mod[:B, (l + 1) * 4 * D:(l + 1) * 4 * D + D]
         if chain_a:

@@ -61,9 +61,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_dtype=torch.bfloat16, glu: bool = False,
            rowscale: Optional[torch.Tensor] = None, rowscale_div: int = 1, force_cfg: int = 0,
-           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+           batched: bool = False, group_m: int = 0, prenorm=None, w_frag: Optional[torch.Tensor] = None, seg_stats=None) -> torch.Tensor:
     """out = epilogue(x @ w.T). x: bf16 [..., K] (or a 2-D row-strided view), w: bf16 [N, K].
 
+    seg_stats=(stats f32 [M, N // 384, 2], eps): the row-panel GEMM (K = 384, >= 16384 rows, plain epilogue) also writes (mean, rstd) of every 384-wide
+    segment of its fp32 output rows - the LayerNorm statistics dit_attention(stats=) consumes. Refused where another kernel would run.
     w_frag: the same weight in MFMA fragment order (gemm_preshuffle(w)): the wide no-residual GEMMs that would run tile config 39 then take
     their B fragments from it straight into registers (config 40, bit-equal); ignored by every other tile.
 
@@ -113,6 +115,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     a.rowscale_div = rowscale_div
     a.force_cfg = force_cfg if force_cfg else _AUTO_CFG
     a.group_m = group_m
+    if seg_stats is not None:
+        st, se = seg_stats
+        assert not batched and st.dtype == torch.float32 and st.is_contiguous() and st.numel() >= M * (N // 384) * 2 and N % 384 == 0
+        a.seg_stats, a.seg_eps = st.data_ptr(), float(se)
     if w_frag is not None:
         assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and w_frag.numel() == N * K and N % 16 == 0 and K % 32 == 0
         a.Wp = w_frag.data_ptr()

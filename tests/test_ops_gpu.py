@@ -415,7 +415,7 @@ def test_gemm_shared_tail_selection_is_bit_equal(ops, M, N, K, glu):
                                         (300, 264, 64, "bias"), (515, 520, 128, "plain"), (2761, 3592, 320, "bf16res"),
                                         (300, 272, 64, "bias"), (515, 528, 128, "plain"), (1000, 1008, 192, "res"), (2761, 3600, 320, "bf16res")])
 def test_gemm_four_wave_tile_is_bit_equal(ops, cfg, M, N, K, mode):
-    """gemm_w4.hip (tile configs 38 / 39: 256 x 256 on four waves of 128 x 128, asm-threaded K loop; 40: the same tile with its B fragments
+    """gemm_w4.hip (tile config 39: 256 x 256 on four waves of 128 x 128, asm-threaded K loop; 40: the same tile with its B fragments
     fetched from the fragment-ordered copy of W straight into registers) accumulates K in the order of the 8-wave tiles: bit-equal to the
     ping-pong kernel (cfg 18) under every epilogue, with ragged edges and 1 / 2 / 3 / 5 / 7 / 56 K stages (the loop requests two stages
     ahead: the last two stages take the path that requests nothing; cfg 40 peels its first stage as well)."""
@@ -493,7 +493,7 @@ def test_gemm_frag_weights_repeatable_at_prefill_size(ops, M, N, K, glu):
 
 def test_gemm_four_wave_tile_rejects_unaligned_rows(ops):
     x, w = torch.zeros(300, 64, dtype=torch.bfloat16, device=_dev()), torch.zeros(260, 64, dtype=torch.bfloat16, device=_dev())
-    with pytest.raises(RuntimeError, match="38 / 39"):
+    with pytest.raises(RuntimeError, match="39 / 40"):
         ops.linear(x, w, force_cfg=39)          # bf16 rows of 520 bytes
     with pytest.raises(RuntimeError, match="fragment-ordered copy"):
         ops.linear(x[:, :64], torch.zeros(256, 64, dtype=torch.bfloat16, device=_dev()), force_cfg=40)   # no w_frag
@@ -809,6 +809,19 @@ def test_gemm_rowpanel_k384(ops, cfg, M, N, glu):
     # same bf16 result as the tiled kernel up to the rounding of a different K summation order (16- vs 32-wide MFMA steps)
     d = (out.float() - tiled.float()).abs()
     assert d.max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item()) and (d > 0).float().mean().item() < 0.2
+    if not glu and N % 384 == 0:
+        # LayerNorm statistics of the 384-wide segments of the produced rows (ina_gemm_args.seg_stats: what dit_attention(stats=) consumes) - the
+        # output itself must not change, the statistics are those of the fp32 rows
+        st = torch.full((M, N // 384, 2), float("nan"), device=_dev())
+        out2 = torch.zeros_like(outw)
+        ops.linear(x, w, out=out2[:, :n_out], force_cfg=cfg, seg_stats=(st, 1e-5))
+        torch.cuda.synchronize()
+        assert torch.equal(out2, outw)
+        seg = ref.view(M, N // 384, 384)
+        _close(st[..., 0], seg.mean(-1), rtol=1e-3, atol=2e-3)
+        _close(st[..., 1], torch.rsqrt(seg.var(-1, unbiased=False) + 1e-5), rtol=2e-3, atol=1e-3)
+        with pytest.raises(Exception, match="seg_stats"):
+            ops.linear(x, w, force_cfg=22, seg_stats=(st, 1e-5))              # any other tile: refused, not ignored
 
 
 def test_gemm_rowpanel_rejects_what_it_does_not_compute(ops):
