@@ -47,8 +47,10 @@ timeout 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACT
 rm -rf $R/gpurun_out/ps
 done
 fi
-# torch-free native probes over the C-ABI (seconds each; tools/native/build.sh builds them next to their sources before the snapshot is sent)
+# torch-free native probes over the C-ABI (seconds each). Rebuilt here against the header of THIS tree: a probe compiled before a struct of
+# include/internnav_amd.h changed hands the library a mis-laid argument block (a GPU memory fault in round 6)
 cd $R
+bash tools/native/build.sh > $R/gpurun_out/${TAG}_native_build.log 2>&1
 if [ -x tools/native/chain_sweep ]; then
   timeout 90 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_rowpanel.txt > $R/gpurun_out/${TAG}_native_rowpanel.log 2>&1
   timeout 90 tools/native/gemm_sweep internnav_amd/libinternnav_amd.so tools/native/specs_r04_w4.txt > $R/gpurun_out/${TAG}_native_w4.log 2>&1
