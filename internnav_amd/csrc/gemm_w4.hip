@@ -416,7 +416,13 @@ int launch_w4p(const GemmArgs& p, hipStream_t stream) {
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     GemmArgs q = p;
-    if (q.group_m == 0) q.group_m = ((p.N + BN - 1) / BN >= 24 && (p.M + BM - 1) / BM >= 8) ? 8 : 1;
+    // few column tiles and a long K (the decoder's down projection: 11-15 x 14 tiles, K = 18944, 9.7 MB operand panels): row-major order hands an XCD's
+    // contiguous run of ~26 tiles 2 rows x 14 columns = 16 panels; groups of 4 row-tiles make it 4 x 6.5 = 11 panels: 445 -> 435 us at 3680 rows, 437 -> 425
+    // at 2760, prefill graph - 0.3 ms (profiles/r06z_native_tile_order2.log, r06z_prefill_down_tile_order.txt). Bit-equal (the order of tiles, not of K).
+    if (q.group_m == 0) {
+        const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM - 1) / BM;
+        q.group_m = (tn >= 24 && tm >= 8) ? 8 : (tm >= 8 && p.K >= 8192) ? 4 : 1;
+    }
     const double osz = p.out_dtype == INA_DT_BF16 ? 2.0 : 4.0;
     ina_prof_set_sub(40);
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + osz * p.M * (p.glu ? p.N / 2 : p.N), stream);
