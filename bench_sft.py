@@ -45,10 +45,12 @@ def parse():
                     help="frozen prefix (ViT + prefill) of every micro-batch inside its own step, on the main stream (round-3 / early round-4 schedule) "
                          "instead of one step ahead on the prefetch stream (InternVLAN1SftTrainer.prefetch)")
     ap.add_argument("--prefetch-first", action="store_true", help="A/B: issue the next prefix before this step's own launches (first version of the pipeline)")
-    ap.add_argument("--graph-prefix", action="store_true",
-                    help="the frozen prefix (ViT + ragged prefill, ~1 100 launches) as ONE hipGraph replay per prompt geometry instead of eager launches. Measured "
-                         "neutral (15.96 vs 16.27 samples/s on one box, profiles/r05g_bench_sft*.json): the pipelined step is bound by the GPU-side overlap of the "
-                         "MFMA-bound prefix with the System-1 graph, not by the host's launch rate - off by default")
+    ap.add_argument("--no-graph-prefix", action="store_true",
+                    help="A/B: the frozen prefix (ViT + ragged prefill, ~1 100 launches) as eager launches instead of ONE hipGraph replay per prompt geometry. "
+                         "Eager, the step depends on the box's host (14.3-17.7 samples/s over boxes and runs); graphed AND with the step's own launches on a "
+                         "high-priority stream it is 17.6-17.9 on every box (profiles/r06z_sft_*_ab.txt)")
+    ap.add_argument("--no-priority", action="store_true", help="A/B: the step's own launches on the caller's stream instead of a high-priority one")
+    ap.add_argument("--no-split-prefill", action="store_true", help="A/B: the frozen prefix as one launch sequence instead of two half micro-batches on two streams")
     ap.add_argument("--no-graph-s1", action="store_true", help="System-1 loss + backward as eager launches (round-3 path) instead of one hipGraph replay")
     return ap.parse_args()
 
@@ -65,13 +67,16 @@ def build(a, dev, rank):
     S = n_text + F * (per // 4 + 2) + n_tail
     weights = synthetic.LazyDeviceWeights(synthetic.qwen_spec(qcfg), dev, seed=0)
     eng = QwenVLEngine(weights, qcfg, dev, max_seqs=B, max_seq_len=(S + qcfg["n_query"] + 63) // 64 * 64, max_patches=B * F * per)
+    if getattr(a, "no_split_prefill", False):
+        eng.split_prefill = False
     sd_s = {k: v.float() for k, v in synthetic.materialize(synthetic.n1_nextdit_spec(), 0).items()}
     from internnav_amd.dist import under_launcher
 
     world = int(os.environ["WORLD_SIZE"]) if under_launcher() else 1
-    tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1, graph_prefix=bool(getattr(a, "graph_prefix", False)))
+    tr = InternVLAN1SftTrainer(eng, sd_s, dev, total_steps=1000, zero2=a.zero2, graph_s1=not a.no_graph_s1, graph_prefix=not getattr(a, "no_graph_prefix", False))
     tr.step_idx = 10          # past the warm-up: non-zero learning rate
     tr.prefetch_first = bool(getattr(a, "prefetch_first", False))
+    tr.priority_step = not getattr(a, "no_priority", False)
     g = torch.Generator(device=dev).manual_seed(1000 * rank + 7)
     lim = qcfg["image_token_id"] - 16
     ids = torch.randint(0, lim, (B, S + qcfg["n_query"]), device=dev, generator=g)
@@ -244,7 +249,8 @@ def main():
                        "trainable_parameters": int(sum(int(np.prod(s)) for _, s in tr.P.index.values())), "optimizer": "fused AdamW + clip 1.0, cosine_with_min_lr", "dropout": 0.1,
                        "launch": ("frozen prefix one step ahead on a prefetch stream (engine twin); " if pipe else "frozen prefix inside the step; ") +
                                  ("System-1 loss + backward as one hipGraph replay" if not a.no_graph_s1 else "eager") +
-                                 ("; frozen prefix as one hipGraph replay per prompt geometry" if getattr(a, "graph_prefix", False) else ""), "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
+                                 ("; frozen prefix as one hipGraph replay per prompt geometry" if not getattr(a, "no_graph_prefix", False) else "") +
+                                 ("; the step's own launches on a high-priority stream" if pipe and not getattr(a, "no_priority", False) else ""), "device": arch, "final_loss": round(float(losses[-1].item()), 5)},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "launches": dom["launches"],
                          "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2), "traffic": None,

@@ -100,6 +100,12 @@ class InternVLAN1SftTrainer:
         self._pf = None               # (batch object, engine slot, prefill state, completion event) of the prefix in flight
         self._pf_stream = None
         self.prefetch_first = False   # A/B switch: issue the next prefix BEFORE this step's own launches (the first version of the pipeline)
+        # pipelined steps issue their own launches (latent-query rows, System-1 graph, update: ~2 000 short kernels, 61 ms alone) on a HIGH-priority
+        # stream: beside the prefetched prefix (256 x 256 GEMM tiles that hold a CU for ~0.4 ms each, 76 ms alone) every short kernel otherwise queues
+        # behind the prefix's pending tiles for the CUs that free up. With the prefix as one graph replay: 124.8 -> 113.2 ms per step
+        # (profiles/r06z_sft_priority_ab.txt); capturing the System-1 graph ON a high-priority stream instead is much worse (141.8 / 186.7 ms)
+        self.priority_step = True
+        self._hp_stream = None
         self.total_steps, self.lr, self.min_lr = total_steps, lr, min_lr
         self.warmup_steps = math.ceil(total_steps * warmup_ratio)
         self.wd, self.max_norm, self.betas, self.eps = weight_decay, max_grad_norm, betas, eps
@@ -458,9 +464,19 @@ class InternVLAN1SftTrainer:
         host while the other's launches are being issued."""
         if next_batch is None:
             loss = self.forward_backward(batch, noise, t_index)
-        else:
+            self.reduce_gradients()
+            self.optimizer_step()
+            return loss
+        caller = torch.cuda.current_stream()
+        own = caller
+        if self.priority_step and self.device.type == "cuda":
+            if self._hp_stream is None:
+                self._hp_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            own = self._hp_stream
+            own.wait_stream(caller)
+        with torch.cuda.stream(own):
             start = torch.cuda.Event()
-            start.record(torch.cuda.current_stream())
+            start.record(own)
             state = self._acquire_prefix(batch)
             if self.prefetch_first:
                 self.prefetch(next_batch)
@@ -468,6 +484,10 @@ class InternVLAN1SftTrainer:
             if not self.prefetch_first:
                 self.prefetch(next_batch, after=start)
             self._lq_backward(dh)
-        self.reduce_gradients()
-        self.optimizer_step()
+            self.reduce_gradients()
+            self.optimizer_step()
+        if own is not caller:
+            caller.wait_stream(own)          # the caller's stream sees the step as if it had run there
+            if isinstance(loss, torch.Tensor) and loss.is_cuda:
+                loss.record_stream(caller)
         return loss

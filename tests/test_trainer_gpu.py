@@ -236,6 +236,7 @@ def test_prefetched_prefix_gives_the_same_steps(built_lib):
                 assert len(tr._engines) == 2 and tr._engines[1].layers[0]["qkv_w"] is eng.layers[0]["qkv_w"]      # weights shared, not copied
                 assert tr._engines[1].layers[0]["kv"].data_ptr() != eng.layers[0]["kv"].data_ptr()
                 assert tr.engine is tr._engines[1] and tr._pf is None                                             # 4 steps: 0, 1, 0, 1
+                assert tr._hp_stream is not None and tr._hp_stream.priority == -1    # pipelined steps issue their own launches on a high-priority stream
             runs.append((losses, tr.P.p32.clone()))
         (l_seq, p_seq), (l_pipe, p_pipe) = runs
         print(f"lr {lr}: losses in-step prefix", l_seq, "prefetched", l_pipe, "weights rel diff", ((p_seq - p_pipe).norm() / p_seq.norm()).item())
