@@ -517,7 +517,8 @@ int ina_ew(const ina_ew_args* args, void* stream);
 typedef struct ina_colsum_args {
     const void* X; const void* X2;  /* X2 optional */
     float* out;
-    float* partial;         /* f32 scratch [groups * ceil(group_rows / 256) * C], needed when a group has more than 256 rows */
+    float* partial;         /* f32 scratch [groups * chunks * C] with chunks = ceil(group_rows / chunk), chunk = 32 rows up to 2048 rows per group, 64 up to 4096,
+                             * 128 up to 8192, 256 beyond; needed when a group has more than 32 rows */
     int64_t partial_elems;
     int32_t rows, C, group_rows;    /* group_rows 0 = one group of all rows */
     int32_t x_dt, x2_dt, ldx, ldx2, x_cs, x2_cs, ldo, out_cs;

@@ -144,13 +144,18 @@ __global__ __launch_bounds__(256) void ew_vec_kernel(EwArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- column sums
-// out[g, c] (+)= scale * sum over the rows of group g of X[r, c] * X2[r, c]; chunks of 256 rows per workgroup, deterministic two-stage
-constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs p, int nchunk, int group_rows) {
+// out[g, c] (+)= scale * sum over the rows of group g of X[r, c] * X2[r, c]; chunks of `chunk_rows` rows per workgroup, deterministic two-stage.
+// Chunk = 32 rows up to 2048 rows per group, 64 up to 4096, 128 up to 8192, 256 beyond (at most 64 chunks below 8192 rows): the gradients of the SFT
+// step are sums over 24 ... 768 rows, where 256-row chunks meant 2-6 workgroups per launch, each a chain of 16 dependent memory round trips (33 us for
+// 1 MB of input); the big reductions (the squared gradient norm: 95 k rows) keep their 256-row chunks.
+inline int colsum_chunk_rows(int group_rows) {
+    return group_rows <= 32 ? group_rows : group_rows <= 2048 ? 32 : group_rows <= 4096 ? 64 : group_rows <= 8192 ? 128 : 256;
+}
+__global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs p, int nchunk, int group_rows, int chunk_rows) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, chunk = blockIdx.y, grp = blockIdx.z;
-    const int r0 = grp * group_rows + chunk * CS_ROWS, r1 = min(grp * group_rows + group_rows, r0 + CS_ROWS);
+    const int r0 = grp * group_rows + chunk * chunk_rows, r1 = min(grp * group_rows + group_rows, r0 + chunk_rows);
     float acc = 0.f;
     if (c < p.C) {
         // 8 independent loads in flight per lane: the loop is latency-bound otherwise (64 dependent round trips per workgroup)
@@ -182,14 +187,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(ColsumArgs p, int nchunk, i
 }
 // 4 columns per lane (8- / 16-byte loads): the dense case of every bias / gain / modulation gradient. XB: X is bf16; X2M: 0 none, 1 bf16, 2 f32
 template <bool XB, int X2M>
-__global__ __launch_bounds__(256) void colsum_vec_kernel(ColsumArgs p, int nchunk, int group_rows) {
+__global__ __launch_bounds__(256) void colsum_vec_kernel(ColsumArgs p, int nchunk, int group_rows, int chunk_rows) {
     __shared__ float red[4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 4, chunk = blockIdx.y, grp = blockIdx.z;
-    const int r0 = grp * group_rows + chunk * CS_ROWS, r1 = min(grp * group_rows + group_rows, r0 + CS_ROWS);
+    const int r0 = grp * group_rows + chunk * chunk_rows, r1 = min(grp * group_rows + group_rows, r0 + chunk_rows);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < p.C) {
-        constexpr int U = 4;
+        constexpr int U = 8;     // a 32-row chunk = one round trip per wave (8 rows each, all 8 loads in flight)
         for (int r = r0 + wave; r < r1; r += 4 * U) {
             f32x4 v[U], w[U];
 #pragma unroll
@@ -238,7 +243,16 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(ColsumArgs p, int nch
     const int c = blockIdx.x * 256 + threadIdx.x, grp = blockIdx.y;
     if (c >= p.C) return;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += p.partial[((size_t)grp * nchunk + k) * p.C + c];
+    const float* part = p.partial + (size_t)grp * nchunk * p.C + c;
+    int k = 0;
+    for (; k + 8 <= nchunk; k += 8) {      // 8 loads in flight, added in ascending chunk order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * p.C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nchunk; ++k) s += part[(size_t)k * p.C];
     float* o = p.out + (size_t)grp * p.ldo + (size_t)c * p.out_cs;
     *o = (p.accumulate ? *o : 0.f) + s * p.scale;
 }
@@ -538,7 +552,8 @@ int ina_launch_colsum(const ColsumArgs& p_in, hipStream_t stream) {
     if (p.out_cs <= 0) p.out_cs = 1;
     if (p.ldo <= 0) p.ldo = p.C * p.out_cs;
     if (p.scale == 0.f) p.scale = 1.f;
-    const int groups = p.rows / group_rows, nchunk = (group_rows + CS_ROWS - 1) / CS_ROWS;
+    const int chunk_rows = colsum_chunk_rows(group_rows);
+    const int groups = p.rows / group_rows, nchunk = (group_rows + chunk_rows - 1) / chunk_rows;
     INA_REQUIRE(nchunk == 1 || (p.partial && p.partial_elems >= (int64_t)groups * nchunk * p.C),
                 "colsum: needs a partial buffer of %lld floats", (long long)groups * nchunk * p.C);
     InaProfScope prof(INA_PROF_ELEMENTWISE, 0.0, 0.0, stream);
@@ -549,12 +564,12 @@ int ina_launch_colsum(const ColsumArgs& p_in, hipStream_t stream) {
         const dim3 grid((p.C + 255) / 256, nchunk, groups);
         const int x2m = !p.X2 ? 0 : (p.x2_dt == INA_DT_BF16 ? 1 : 2);
         const bool xb = p.x_dt == INA_DT_BF16;
-#define INA_CS(XB, M) hipLaunchKernelGGL((colsum_vec_kernel<XB, M>), grid, dim3(256), 0, stream, p, nchunk, group_rows)
+#define INA_CS(XB, M) hipLaunchKernelGGL((colsum_vec_kernel<XB, M>), grid, dim3(256), 0, stream, p, nchunk, group_rows, chunk_rows)
         if (xb) { if (x2m == 0) INA_CS(true, 0); else if (x2m == 1) INA_CS(true, 1); else INA_CS(true, 2); }
         else { if (x2m == 0) INA_CS(false, 0); else if (x2m == 1) INA_CS(false, 1); else INA_CS(false, 2); }
 #undef INA_CS
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3((p.C + 63) / 64, nchunk, groups), dim3(256), 0, stream, p, nchunk, group_rows);
+        hipLaunchKernelGGL(colsum_kernel, dim3((p.C + 63) / 64, nchunk, groups), dim3(256), 0, stream, p, nchunk, group_rows, chunk_rows);
     }
     if (nchunk > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((p.C + 255) / 256, groups), dim3(256), 0, stream, p, nchunk);
     INA_HIP_CHECK(hipGetLastError());

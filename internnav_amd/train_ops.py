@@ -104,6 +104,15 @@ def glu_bwd(a, b, dy, da=None, db=None):
     return da, db
 
 
+def colsum_chunks(group_rows: int) -> int:
+    """row chunks (= partial sums per column) the library cuts a group of `group_rows` rows into: csrc/train.hip colsum_chunk_rows - 32-row chunks
+    up to 2048 rows, 64 up to 4096, 128 up to 8192, 256 beyond (the library checks the partial buffer against its own count)."""
+    if group_rows <= 32:
+        return 1
+    chunk = 32 if group_rows <= 2048 else 64 if group_rows <= 4096 else 128 if group_rows <= 8192 else 256
+    return (group_rows + chunk - 1) // chunk
+
+
 def colsum(x, x2=None, out=None, group_rows=0, accumulate=False, scale=1.0, x2_bcast=False, out_cs=1, x_bcast=False):
     """out[g, c] (+)= scale * sum_{rows of group g} x[r, c] * x2[r, c];  x2_bcast: x2 is [rows] (one value per row)."""
     rows = x.shape[0]
@@ -137,7 +146,7 @@ def colsum(x, x2=None, out=None, group_rows=0, accumulate=False, scale=1.0, x2_b
     a.out_cs = out_cs
     a.ldo = out.stride(0) if out.dim() == 2 else Cd * out_cs
     a.rows, a.C, a.group_rows = rows, Cd, gr
-    nchunk = (gr + 255) // 256
+    nchunk = colsum_chunks(gr)
     if nchunk > 1:
         part = torch.empty(groups * nchunk * Cd, dtype=torch.float32, device=x.device)
         a.partial, a.partial_elems = part.data_ptr(), part.numel()
