@@ -19,6 +19,8 @@ timeout 600 python bench.py --workload navdp_s1 > $R/gpurun_out/${TAG}_bench_nav
 timeout 600 python bench.py --workload unet1d_s1 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_unet1d_s1_b64.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_sft.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline --no-prefetch > $R/gpurun_out/${TAG}_bench_sft_noprefetch.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline --no-priority > $R/gpurun_out/${TAG}_bench_sft_nopriority.json 2>> $R/gpurun_out/${TAG}_bench.err
+timeout 600 python bench.py --workload sft --steps 30 --warmup 3 --no-cpu-baseline --no-graph-prefix > $R/gpurun_out/${TAG}_bench_sft_eagerprefix.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --no-variants --dit-ffn 1024 > $R/gpurun_out/${TAG}_bench_n1_dual_b64_ffn1024.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --no-variants --no-frag-weights > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_frag_weights.json 2>> $R/gpurun_out/${TAG}_bench.err
 timeout 600 python bench.py --no-cpu-baseline --no-variants --no-row-chain > $R/gpurun_out/${TAG}_bench_n1_dual_b64_no_row_chain.json 2>> $R/gpurun_out/${TAG}_bench.err
