@@ -500,3 +500,29 @@ def test_nextdit_row_chain_is_selected_by_geometry_not_assumed():
     assert not engine(dit_ffn=768).row_chain
     e = engine(sample_num=20, predict_size=24)
     assert e.ff.shape == (20 * 24, 1536) and e.T == 24
+
+
+def test_colsum_partial_buffer_rule_matches_the_library_source():
+    """train_ops.colsum sizes the partial buffer of ina_colsum with the chunk rule of csrc/train.hip (colsum_chunk_rows): the Python mirror is checked
+    against the C expression parsed out of the source, and against the bounds the kernel comment states (<= 64 chunks below 8192 rows, 256-row chunks beyond)."""
+    import re
+
+    from internnav_amd import train_ops as T
+
+    src = (Path(__file__).resolve().parent.parent / "internnav_amd" / "csrc" / "train.hip").read_text()
+    m = re.search(r"inline int colsum_chunk_rows\(int group_rows\) \{\s*return (.*?);\s*\}", src, re.S)
+    assert m, "colsum_chunk_rows not found in train.hip"
+    expr = m.group(1)
+    steps = re.findall(r"group_rows <= (\d+) \? (\w+)", expr)
+    assert steps[0] == ("32", "group_rows") and expr.strip().endswith(": 256")
+
+    def c_rule(gr):
+        for lim, val in steps:
+            if gr <= int(lim):
+                return gr if val == "group_rows" else int(val)
+        return 256
+    for gr in list(range(1, 70)) + [255, 256, 257, 768, 2047, 2048, 2049, 4096, 4097, 8192, 8193, 65536, 95421]:
+        chunk = c_rule(gr)
+        assert T.colsum_chunks(gr) == (gr + chunk - 1) // chunk, gr
+        if gr <= 8192:
+            assert T.colsum_chunks(gr) <= 64
