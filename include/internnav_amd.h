@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define INA_ABI_VERSION 7
+#define INA_ABI_VERSION 8
 
 /* activation codes (GEMM epilogue) */
 #define INA_ACT_NONE_C 0
@@ -56,7 +56,7 @@ int ina_workspace_retired(void);
 int ina_prof_enable(int on);
 int ina_prof_read(int kind, double* ms_total, int64_t* launches, double* flops, double* bytes);
 /* the same tally restricted to one kernel of the class: sub = GEMM tile config id (18 = gemm_bf16_pp_kernel<256,256,4>, 21 = <192,256,4>,
- * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11 / 14 / 26 / 27 other LDS-DMA tiles, 1-5 gemm_bf16_nt_kernel tiles, 34 / 35 = gemm_bf16_rowpanel_kernel<8|4 waves>, 39 = gemm_bf16_w4_kernel<256> (four-wave 256x256 tile), 40 = gemm_bf16_w4p_kernel<256> (the same tile on fragment-ordered weights), 42 = dit_rowchain_kernel) */
+ * 22 = gemm_bf16_glds_kernel<128,128,2,2,1>, 33 = gemm_bf16_glds_kernel<256,256,4,4,2>, 11 / 14 / 26 / 27 other LDS-DMA tiles, 1-5 gemm_bf16_nt_kernel tiles, 34 / 35 = gemm_bf16_rowpanel_kernel<8|4 waves>, 39 = gemm_bf16_w4_kernel<256> (four-wave 256x256 tile), 40 = gemm_bf16_w4p_kernel<256> (the same tile on fragment-ordered weights), 42 = dit_rowchain_kernel, 43 = gemm_dw_kernel) */
 int ina_prof_read_sub(int kind, int sub, double* ms_total, int64_t* launches, double* flops, double* bytes);
 
 /* ---- C[M,N] = epilogue(A[M,K] . W[N,K]^T): replaces every nn.Linear / patch-embed conv on the path
@@ -588,6 +588,17 @@ typedef struct ina_gemm_nn_args {
     int32_t M, N, K, ldx, ldw, splits;
 } ina_gemm_nn_args;
 int ina_gemm_nn_bf16(const ina_gemm_nn_args* args, void* stream);
+
+/* dW[n, k] += sum_r DY[r, n] * X[r, k] and, with db, db[n] += sum_r DY[r, n]: weight / bias gradient of nn.Linear from the row-major operands of
+ * the backward tape (DY [rows, N] f32 or bf16 - rounded to bf16 for the MFMAs, the bias sum takes the unrounded values; X [rows, K] bf16), one launch
+ * instead of two transposes + a GEMM + two column-sum launches. N, K, lddy, ldx multiples of 8, ldw of 4. */
+typedef struct ina_gemm_dw_args {
+    const void* DY; const void* X;
+    float* dW;                  /* f32 [N, ldw], accumulated into */
+    float* db;                  /* f32 [N], accumulated into, or NULL */
+    int32_t rows, N, K, dy_dt, lddy, ldx, ldw, _pad;
+} ina_gemm_dw_args;
+int ina_gemm_dw(const ina_gemm_dw_args* args, void* stream);
 
 /* backward of ina_attention_bf16 (dense layouts only): f describes the forward call (Q, K, V, O and their strides);
  * dO has O's strides. dQ pass writes lse / delta [B, H, Lq] f32, the dK / dV pass (optional) reads them. dK / dV are indexed by the

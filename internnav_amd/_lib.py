@@ -258,6 +258,11 @@ class AdamwArgs(C.Structure):
                 ("max_norm", c_float), ("grad_scale", c_float), ("_pad", c_int32)]
 
 
+class GemmDwArgs(C.Structure):
+    _fields_ = [("DY", c_void_p), ("X", c_void_p), ("dW", c_void_p), ("db", c_void_p),
+                ("rows", c_int32), ("N", c_int32), ("K", c_int32), ("dy_dt", c_int32), ("lddy", c_int32), ("ldx", c_int32), ("ldw", c_int32), ("_pad", c_int32)]
+
+
 class GemmNnArgs(C.Structure):
     _fields_ = [("X", c_void_p), ("W", c_void_p), ("partial", c_void_p), ("partial_elems", c_int64),
                 ("M", c_int32), ("N", c_int32), ("K", c_int32), ("ldx", c_int32), ("ldw", c_int32), ("splits", c_int32)]
@@ -306,6 +311,7 @@ SYMBOLS = {
     "ina_mse_masked": (C.c_int, [C.POINTER(MseArgs), c_void_p]),
     "ina_adamw": (C.c_int, [C.POINTER(AdamwArgs), c_void_p]),
     "ina_gemm_nn_bf16": (C.c_int, [C.POINTER(GemmNnArgs), c_void_p]),
+    "ina_gemm_dw": (C.c_int, [C.POINTER(GemmDwArgs), c_void_p]),
     "ina_attention_bwd_bf16": (C.c_int, [C.POINTER(AttnBwdArgs), c_void_p]),
     "ina_struct_size": (C.c_int, [C.c_int]),
     "ina_set_workspace_slot": (C.c_int, [C.c_int]),
@@ -318,7 +324,7 @@ SYMBOLS = {
 _lib = None
 # the struct layouts above mirror include/internnav_amd.h at THIS version of the C-ABI (INA_ABI_VERSION there): lib() refuses a shared object
 # built from another version - a stale .so would read pointers at the wrong offsets
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class EngineError(RuntimeError):

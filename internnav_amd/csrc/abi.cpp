@@ -178,7 +178,7 @@ int ina_norm_bf16(const ina_norm_args* args, void* stream) {
     return ina_launch_norm(*args, reinterpret_cast<hipStream_t>(stream));
 }
 
-/* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 resize_u8, 15 qwen_patchify, 16 u8_lut, 17 resize_f32, 18 gn_mish, 19 pad_rows, 20 ddim_step, 21 ew, 22 colsum, 23 norm_bwd, 24 transpose, 25 sparse_rows, 26 small_linear, 27 mse, 28 adamw, 29 gemm_nn, 30 attn_bwd, 31 dit_rowchain */
+/* sizeof() of the k-th argument struct (layout check of the ctypes mirrors): 0 gemm, 1 attn, 2 norm, 3 patchify, 4 embed3, 5 head3, 6 seqpool, 7 select, 8 pool_act, 9 gather, 10 rope, 11 mrope_table, 12 argmax, 13 dit_attn, 14 resize_u8, 15 qwen_patchify, 16 u8_lut, 17 resize_f32, 18 gn_mish, 19 pad_rows, 20 ddim_step, 21 ew, 22 colsum, 23 norm_bwd, 24 transpose, 25 sparse_rows, 26 small_linear, 27 mse, 28 adamw, 29 gemm_nn, 30 attn_bwd, 31 dit_rowchain, 32 gemm_dw */
 int ina_struct_size(int k) {
     switch (k) {
         case 0: return (int)sizeof(ina_gemm_args);
@@ -213,6 +213,7 @@ int ina_struct_size(int k) {
         case 29: return (int)sizeof(ina_gemm_nn_args);
         case 30: return (int)sizeof(ina_attn_bwd_args);
         case 31: return (int)sizeof(ina_dit_rowchain_args);
+        case 32: return (int)sizeof(ina_gemm_dw_args);
         default: return -1;
     }
 }
@@ -250,6 +251,7 @@ INA_ENTRY(ina_small_linear, ina_small_linear_args, ina_launch_small_linear)
 INA_ENTRY(ina_mse_masked, ina_mse_args, ina_launch_mse)
 INA_ENTRY(ina_adamw, ina_adamw_args, ina_launch_adamw)
 INA_ENTRY(ina_gemm_nn_bf16, ina_gemm_nn_args, ina_launch_gemm_nn)
+INA_ENTRY(ina_gemm_dw, ina_gemm_dw_args, ina_launch_gemm_dw)
 INA_ENTRY(ina_attention_bwd_bf16, ina_attn_bwd_args, ina_launch_attention_bwd)
 #undef INA_ENTRY
 

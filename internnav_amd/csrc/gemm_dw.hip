@@ -1,0 +1,148 @@
+// Weight gradient of nn.Linear straight from the row-major operands (gfx950):
+//     dW[n, k] += sum_r DY[r, n] * X[r, k]          db[n] += sum_r DY[r, n]   (optional)
+// DY [rows, N] (f32 or bf16) and X [rows, K] (bf16) are what the backward tape holds; the reduction runs over their SLOW dimension, so the tiled NT
+// GEMM needed K-contiguous copies of both - two transpose launches, the GEMM, and two column-sum launches for the bias: five launches per trained
+// layer in a ~3 000-launch backward chain that is bound by launch latency, not by work (rows = 24 ... 768 in the SFT step). This kernel stages
+// 64-row slabs of both operands in LDS TRANSPOSED (16-byte global loads along n / k, 2-byte LDS stores, 16-byte fragment reads along r), runs
+// MFMA 16x16x32 over them and adds the 64 x 64 tile into the fp32 gradient; workgroups of the first k tile also sum their DY slab columns (from the
+// UNROUNDED values) for the bias gradient. One launch, no scratch, deterministic (r ascending inside a tile, one workgroup per output element).
+// Numerics: DY rounded to bf16 for the MFMAs (as the transposed copy was), fp32 accumulation over r in 32-wide steps.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int DW_T = 64, DW_R = 64, DW_PITCH = 72;   // tile edge, rows per slab, LDS row pitch in bf16 (144 B: 16-byte aligned fragment reads)
+
+template <bool DY32>
+__global__ __launch_bounds__(256) void gemm_dw_kernel(ina_gemm_dw_args p) {
+    __shared__ __attribute__((aligned(16))) bf16 As[2][DW_T * DW_PITCH];   // [buffer][n][r]
+    __shared__ __attribute__((aligned(16))) bf16 Bs[2][DW_T * DW_PITCH];   // [buffer][k][r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * DW_T, k0 = blockIdx.y * DW_T;
+    const int lr = tid >> 3, c8 = (tid & 7) * 8;                         // this thread's rows lr, lr + 32 of a slab and its 8 columns
+    const bool n_ok = n0 + c8 < p.N, k_ok = k0 + c8 < p.K;              // (N, K multiples of 8: a run of 8 is inside or outside)
+    const bool bias = p.db != nullptr && blockIdx.y == 0;
+    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // the wave's 32 x 32 corner of the tile
+    const int fi = lane & 15, fg = lane >> 4;
+
+    f32x4 acc[2][2];                                                     // [n sub-tile][k sub-tile]: lane holds n = fi, k = 4 fg .. 4 fg + 3
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    float a[2][8];
+    bf16x8 b[2];
+    auto load = [&](int r0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + lr + 32 * h;
+            const bool ok = r < p.rows;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[h][j] = 0.f;
+            b[h] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok && n_ok) {
+                if constexpr (DY32) {
+                    const float* q = reinterpret_cast<const float*>(p.DY) + (size_t)r * p.lddy + n0 + c8;
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(q), v = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[h][j] = u[j]; a[h][4 + j] = v[j]; }
+                } else {
+                    const bf16x8 u = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.DY) + (size_t)r * p.lddy + n0 + c8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[h][j] = (float)u[j];
+                }
+            }
+            if (ok && k_ok) b[h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.X) + (size_t)r * p.ldx + k0 + c8);
+        }
+    };
+    auto stage = [&](int buf) {                                           // registers -> LDS, transposed; the bias sums take the unrounded values
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                As[buf][(c8 + j) * DW_PITCH + lr + 32 * h] = (bf16)a[h][j];
+                Bs[buf][(c8 + j) * DW_PITCH + lr + 32 * h] = b[h][j];
+            }
+        if (bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bs[j] += a[0][j] + a[1][j];
+        }
+    };
+
+    // slab c is multiplied out of LDS buffer c & 1 while slab c + 1 waits in registers (staged into the other buffer after the barrier that
+    // retires its last readers) and slab c + 2 is in flight from memory: one barrier per slab, two slabs of latency cover
+    const int nslab = (p.rows + DW_R - 1) / DW_R;
+    load(0);
+    stage(0);
+    if (nslab > 1) load(DW_R);
+    for (int c = 0; c < nslab; ++c) {
+        __syncthreads();
+        if (c + 1 < nslab) {
+            stage((c + 1) & 1);
+            if (c + 2 < nslab) load((c + 2) * DW_R);
+        }
+        const bf16* as = As[c & 1];
+        const bf16* bsm = Bs[c & 1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(as + (wn + i * 16 + fi) * DW_PITCH + kk * 32 + fg * 8);
+                fb[i] = *reinterpret_cast<const bf16x8*>(bsm + (wk + i * 16 + fi) * DW_PITCH + kk * 32 + fg * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // D[4 fg + t][fi] of mfma(first = X^T fragment, second = DY^T fragment): k = 4 fg + t, n = fi
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + wn + i * 16 + fi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wk + j * 16 + fg * 4;
+            if (n < p.N && k < p.K) {                                     // (K multiple of 4: a run of 4 is inside or outside)
+                f32x4* o = reinterpret_cast<f32x4*>(p.dW + (size_t)n * p.ldw + k);
+                *o = *o + acc[i][j];
+            }
+        }
+    }
+    if (bias) {
+        __syncthreads();                                                  // every wave is done with the operand buffers: As becomes the reduction scratch
+        float* red = reinterpret_cast<float*>(&As[0][0]);                 // [32 row slots][64 n] f32 = 8 KB of the 18 KB
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[lr * DW_T + c8 + j] = bs[j];
+        __syncthreads();
+        if (tid < DW_T && n0 + tid < p.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) s += red[r * DW_T + tid];
+            p.db[n0 + tid] += s;
+        }
+    }
+}
+
+}  // namespace
+
+int ina_launch_gemm_dw(const ina_gemm_dw_args& p, hipStream_t stream) {
+    INA_REQUIRE(p.rows > 0 && p.N > 0 && p.K > 0 && p.DY && p.X && p.dW, "gemm_dw: empty problem or null tensor");
+    INA_REQUIRE(p.dy_dt == INA_DT_F32 || p.dy_dt == INA_DT_BF16, "gemm_dw: DY must be f32 or bf16");
+    const size_t des = p.dy_dt == INA_DT_F32 ? 4 : 2;
+    INA_REQUIRE(p.N % 8 == 0 && p.K % 8 == 0 && p.lddy % 8 == 0 && p.ldx % 8 == 0 && p.ldw % 4 == 0 && ((uintptr_t)p.DY % (8 * des)) == 0 &&
+                    ((uintptr_t)p.X % 16) == 0 && ((uintptr_t)p.dW % 16) == 0,
+                "gemm_dw: N, K, lddy, ldx must be multiples of 8 (ldw of 4) and the tensors 16-byte aligned (N=%d K=%d lddy=%d ldx=%d ldw=%d)", p.N, p.K,
+                p.lddy, p.ldx, p.ldw);
+    ina_prof_set_sub(43);
+    InaProfScope prof(INA_PROF_GEMM, 2.0 * p.rows * p.N * p.K, (double)p.rows * (des * p.N + 2.0 * p.K) + 8.0 * p.N * p.K, stream);
+    const dim3 grid((p.N + DW_T - 1) / DW_T, (p.K + DW_T - 1) / DW_T);
+    if (p.dy_dt == INA_DT_F32) hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, stream, p);
+    INA_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -85,4 +85,5 @@ int ina_launch_small_linear(const SmallLinearArgs& p, hipStream_t stream);
 int ina_launch_mse(const MseArgs& p, hipStream_t stream);
 int ina_launch_adamw(const AdamwArgs& p, hipStream_t stream);
 int ina_launch_gemm_nn(const GemmNnArgs& p, hipStream_t stream);
+int ina_launch_gemm_dw(const ina_gemm_dw_args& p, hipStream_t stream);
 int ina_launch_attention_bwd(const AttnBwdArgs& p, hipStream_t stream);

@@ -77,7 +77,7 @@ def prof_enable(on: bool) -> None:
 
 GEMM_SUBS = {18: "gemm_bf16_pp_kernel<256,256,4>", 21: "gemm_bf16_pp_kernel<192,256,4>", 22: "gemm_bf16_glds_kernel<128,128,2,2,1>",
              11: "gemm_bf16_glds_kernel<128,128,2,2,2>", 33: "gemm_bf16_glds_kernel<256,256,4,4,2>", 26: "gemm_bf16_glds_kernel<128,256,2,4,1>", 27: "gemm_bf16_glds_kernel<256,128,4,2,1>", 14: "gemm_bf16_glds_kernel<256,128,4,2,3>", 1: "gemm_bf16_nt_kernel<128,128,64,2,2>",
-             2: "gemm_bf16_nt_kernel<64,128,64,2,2>", 3: "gemm_bf16_nt_kernel<64,128,64,1,4>", 39: "gemm_bf16_w4_kernel<256,1>", 40: "gemm_bf16_w4p_kernel<256>", 42: "dit_rowchain_kernel",
+             2: "gemm_bf16_nt_kernel<64,128,64,2,2>", 3: "gemm_bf16_nt_kernel<64,128,64,1,4>", 39: "gemm_bf16_w4_kernel<256,1>", 40: "gemm_bf16_w4p_kernel<256>", 42: "dit_rowchain_kernel", 43: "gemm_dw_kernel",
              34: "gemm_bf16_rowpanel_kernel<8,4>", 35: "gemm_bf16_rowpanel_kernel<4,4>"}
 
 

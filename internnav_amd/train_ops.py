@@ -285,6 +285,38 @@ def sumsq_parts(flat: torch.Tensor, width: int = 1024) -> torch.Tensor:
     return colsum(v, v).view(-1)
 
 
+GEMM_DW_MAX_ROWS = 2048
+
+
+def gemm_dw_ok(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor) -> bool:
+    """should gemm_dw take these operands (else: two transposes + ops.linear + colsum)? dy [rows, N] f32 | bf16, x [rows, K] bf16, gW f32 [N, K] view.
+    Up to GEMM_DW_MAX_ROWS rows: one workgroup per 64 x 64 tile walks all rows (18 vs 29 us at 768 rows, 6 vs 20 at 96); from ~3 000 rows on the tiled
+    GEMM over transposed copies is ahead (its K loop is pipelined deeper; 232 vs 170 us at 12 288 rows) - profiles/r06z_gemm_dw_vs_five_launches.txt."""
+    if dy.dim() != 2 or x.dim() != 2 or gW.dim() != 2 or x.dtype != torch.bfloat16 or gW.dtype != torch.float32 or dy.dtype not in _DT:
+        return False
+    if dy.shape[0] > GEMM_DW_MAX_ROWS:
+        return False
+    N, K = gW.shape
+    es = dy.element_size()
+    return (dy.shape == (x.shape[0], N) and x.shape[1] == K and dy.stride(1) == 1 and x.stride(1) == 1 and gW.stride(1) == 1 and N % 8 == 0 and K % 8 == 0
+            and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and gW.stride(0) % 4 == 0 and dy.data_ptr() % (8 * es) == 0 and x.data_ptr() % 16 == 0
+            and gW.data_ptr() % 16 == 0)
+
+
+def gemm_dw(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional[torch.Tensor] = None):
+    """gW[n, k] += sum_r dy[r, n] * x[r, k]; gb[n] += sum_r dy[r, n]: weight / bias gradient of nn.Linear in ONE launch from the tape's row-major
+    tensors (csrc/gemm_dw.hip) - the tiled GEMM needed two transposed copies and the bias two column-sum launches."""
+    assert gemm_dw_ok(dy, x, gW)
+    a = _lib.GemmDwArgs()
+    a.DY, a.X, a.dW = dy.data_ptr(), x.data_ptr(), gW.data_ptr()
+    if gb is not None:
+        assert gb.dtype == torch.float32 and gb.is_contiguous() and gb.numel() == gW.shape[0]
+        a.db = gb.data_ptr()
+    a.rows, a.N, a.K, a.dy_dt = dy.shape[0], gW.shape[0], gW.shape[1], _DT[dy.dtype]
+    a.lddy, a.ldx, a.ldw = dy.stride(0), x.stride(0), gW.stride(0)
+    _lib.check(_lib.lib().ina_gemm_dw(C.byref(a), _stream()), "gemm_dw")
+
+
 def gemm_nn(x, w, out=None, out_dtype=torch.float32, splits: Optional[int] = None):
     """out[m, k] = sum_n x[m, n] * w[n, k] for a few rows (m <= 16): dX of a frozen nn.Linear with w [N, K] in its stored layout."""
     assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2

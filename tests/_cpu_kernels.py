@@ -152,6 +152,16 @@ def transpose(x, pad=8, out=None):
     return y
 
 
+def gemm_dw_ok(dy, x, gW):
+    return dy.dim() == 2 and x.dim() == 2 and gW.dim() == 2 and gW.shape[0] % 8 == 0 and gW.shape[1] % 8 == 0
+
+
+def gemm_dw(dy, x, gW, gb=None):
+    gW.add_(dy.to(BF).float().t() @ x.float())
+    if gb is not None:
+        gb.add_(dy.float().sum(0))
+
+
 def sparse_rows(inp, idx, coef, out=None, accumulate=False):
     w = torch.where(idx >= 0, coef, torch.zeros_like(coef))
     s = (inp[idx.clamp_min(0).long()] * w.unsqueeze(-1)).sum(1)
@@ -216,7 +226,7 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, p_bf16=None, sumsq_parts=
 OPS = dict(linear=linear, norm=norm, attention=attention, patchify=patchify)
 TRAIN_OPS = dict(affine=affine, act_fwd=act_fwd, act_bwd=act_bwd, glu_fwd=glu_fwd, glu_bwd=glu_bwd, colsum=colsum, norm_bwd=norm_bwd, transpose=transpose,
                  sparse_rows=sparse_rows, small_linear=small_linear, mse_masked=mse_masked, dropout=dropout, attention_bwd=attention_bwd,
-                 sumsq_parts=sumsq_parts, adamw=adamw)
+                 sumsq_parts=sumsq_parts, adamw=adamw, gemm_dw=gemm_dw, gemm_dw_ok=gemm_dw_ok)
 
 
 def install(monkeypatch):

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol(built_lib):
         assert hasattr(h, name), f"{name} declared in include/internnav_amd.h but not exported"
     from internnav_amd import _lib
 
-    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().ina_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_graft_entry_build_passes_on_the_current_abi(built_lib):
@@ -46,7 +46,7 @@ def test_struct_sizes_match_header(built_lib):
                _lib.SeqpoolArgs, _lib.SelectArgs, _lib.PoolActArgs, _lib.GatherArgs,
                _lib.RopeArgs, _lib.MropeTableArgs, _lib.ArgmaxArgs, _lib.DitAttnArgs, _lib.ResizeU8Args, _lib.QwenPatchifyArgs, _lib.U8LutArgs, _lib.ResizeF32Args, _lib.GnMishArgs, _lib.PadRowsArgs, _lib.DdimStepArgs,
                _lib.EwArgs, _lib.ColsumArgs, _lib.NormBwdArgs, _lib.TransposeArgs, _lib.SparseRowsArgs, _lib.SmallLinearArgs, _lib.MseArgs,
-               _lib.AdamwArgs, _lib.GemmNnArgs, _lib.AttnBwdArgs, _lib.DitRowchainArgs]
+               _lib.AdamwArgs, _lib.GemmNnArgs, _lib.AttnBwdArgs, _lib.DitRowchainArgs, _lib.GemmDwArgs]
     for k, m in enumerate(mirrors):
         assert ctypes.sizeof(m) == _lib.lib().ina_struct_size(k), f"struct {k} ({m.__name__}) layout mismatch"
     assert _lib.lib().ina_struct_size(len(mirrors)) == -1

@@ -346,3 +346,53 @@ def test_attention_dropout_forward_backward(dev, B, Lq, Lk, H, D, causal):
     for name, a, b in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         err = (a.float() - b).abs()
         assert err.max().item() < 2.5e-2 * b.abs().max().item() and err.mean().item() < 4e-3 * b.abs().mean().item() + 1e-6, name
+
+
+@pytest.mark.parametrize("rows,N,K,dy32", [(768, 384, 384, True), (864, 1536, 384, False), (100, 72, 136, True), (5, 8, 8, False), (33, 64, 200, True), (2048, 128, 64, True),
+                                              (768, 3072, 384, False)])
+def test_gemm_dw_weight_and_bias_gradient_in_one_launch(dev, rows, N, K, dy32):
+    """ina_gemm_dw (csrc/gemm_dw.hip): gW += bf16(dy)^T x, gb += sum_r dy from the row-major operands - against the fp64 product of the same
+    bf16-rounded operands (tolerance: fp32 accumulation over `rows` terms) and against the launches it replaces (two transposes + the tiled GEMM +
+    the column sums). Ragged tile edges, rows that are not a multiple of the 32-row slab, row-strided views, accumulation into existing values."""
+    from internnav_amd import ops
+    from internnav_amd import train_ops as T
+
+    g = torch.Generator(device="cpu").manual_seed(rows * 7 + N)
+    big_dy = torch.randn(rows, N + 16, generator=g).to(dev)
+    big_x = torch.randn(rows, K + 8, generator=g).to(dev).bfloat16()
+    dy = (big_dy if dy32 else big_dy.bfloat16())[:, 8:8 + N]               # row-strided views (lddy = N + 16, ldx = K + 8)
+    x = big_x[:, :K]
+    store = torch.randn(N + 8, K + 4, generator=g).to(dev)                  # gradient rows inside a larger buffer (ldw = K + 4)
+    store0 = store.clone()
+    gW = store[8:, :K]
+    gb = torch.randn(N, generator=g).to(dev)
+    gW0, gb0 = gW.clone(), gb.clone()
+    assert T.gemm_dw_ok(dy, x, gW)
+    T.gemm_dw(dy, x, gW, gb)
+    torch.cuda.synchronize()
+    ref_w = gW0.double() + dy.bfloat16().double().t() @ x.double()
+    ref_b = gb0.double() + dy.double().sum(0)
+    scale = (dy.bfloat16().double().abs().t() @ x.double().abs()).max().item()
+    assert (gW.double() - ref_w).abs().max().item() <= 2e-6 * scale + 1e-6, ((gW.double() - ref_w).abs().max().item(), scale)
+    assert (gb.double() - ref_b).abs().max().item() <= 1e-5 * dy.double().abs().sum(0).max().item() + 1e-6
+    assert torch.equal(store[:8], store0[:8]) and torch.equal(store[:, K:], store0[:, K:])      # the rest of the buffer is untouched
+    # the launches it replaces give the same gradient to fp32 summation order
+    gW2, gb2 = gW0.clone(), gb0.clone()
+    ops.linear(T.transpose(dy.bfloat16().contiguous()), T.transpose(x.contiguous()), out=gW2, residual=gW2)
+    T.colsum(dy.contiguous(), out=gb2, accumulate=True)
+    assert (gW - gW2).abs().max().item() <= 4e-6 * scale + 1e-6
+    assert (gb - gb2).abs().max().item() <= 2e-5 * dy.double().abs().sum(0).max().item() + 1e-6
+    # without a bias pointer nothing but gW moves; a shape the kernel does not take is refused by the predicate, not by a crash
+    gW3 = gW0.clone()
+    T.gemm_dw(dy, x, gW3)
+    assert torch.equal(gW3, gW)
+    assert not T.gemm_dw_ok(dy[:, :N - 4], x, gW[:N - 4]) and not T.gemm_dw_ok(dy, x.float(), gW)
+
+
+def test_gemm_dw_is_not_offered_beyond_its_row_limit(dev):
+    from internnav_amd import train_ops as T
+
+    x = torch.zeros(T.GEMM_DW_MAX_ROWS + 64, 64, device=dev, dtype=torch.bfloat16)
+    dy = torch.zeros(T.GEMM_DW_MAX_ROWS + 64, 128, device=dev)
+    gW = torch.zeros(128, 64, device=dev)
+    assert T.gemm_dw_ok(dy[: T.GEMM_DW_MAX_ROWS], x[: T.GEMM_DW_MAX_ROWS], gW) and not T.gemm_dw_ok(dy, x, gW)
