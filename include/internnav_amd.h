@@ -591,12 +591,16 @@ int ina_gemm_nn_bf16(const ina_gemm_nn_args* args, void* stream);
 
 /* dW[n, k] += sum_r DY[r, n] * X[r, k] and, with db, db[n] += sum_r DY[r, n]: weight / bias gradient of nn.Linear from the row-major operands of
  * the backward tape (DY [rows, N] f32 or bf16 - rounded to bf16 for the MFMAs, the bias sum takes the unrounded values; X [rows, K] bf16), one launch
- * instead of two transposes + a GEMM + two column-sum launches. N, K, lddy, ldx multiples of 8, ldw of 4. */
+ * instead of two transposes + a GEMM + two column-sum launches (two launches with `splits` row ranges: long reductions over few tiles). N, K, lddy, ldx
+ * multiples of 8, ldw of 4. */
 typedef struct ina_gemm_dw_args {
     const void* DY; const void* X;
     float* dW;                  /* f32 [N, ldw], accumulated into */
     float* db;                  /* f32 [N], accumulated into, or NULL */
-    int32_t rows, N, K, dy_dt, lddy, ldx, ldw, _pad;
+    float* partial;             /* splits > 1: f32 scratch [splits * N * (K + 1)] (per-range tiles, then per-range bias sums) */
+    int64_t partial_elems;
+    int32_t rows, N, K, dy_dt, lddy, ldx, ldw;
+    int32_t splits;             /* <= 1: one launch, every tile walks all rows; 2 .. 64: the rows in that many ranges (grid.z) + a launch that adds them in order */
 } ina_gemm_dw_args;
 int ina_gemm_dw(const ina_gemm_dw_args* args, void* stream);
 

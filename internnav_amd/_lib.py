@@ -259,8 +259,8 @@ class AdamwArgs(C.Structure):
 
 
 class GemmDwArgs(C.Structure):
-    _fields_ = [("DY", c_void_p), ("X", c_void_p), ("dW", c_void_p), ("db", c_void_p),
-                ("rows", c_int32), ("N", c_int32), ("K", c_int32), ("dy_dt", c_int32), ("lddy", c_int32), ("ldx", c_int32), ("ldw", c_int32), ("_pad", c_int32)]
+    _fields_ = [("DY", c_void_p), ("X", c_void_p), ("dW", c_void_p), ("db", c_void_p), ("partial", c_void_p), ("partial_elems", c_int64),
+                ("rows", c_int32), ("N", c_int32), ("K", c_int32), ("dy_dt", c_int32), ("lddy", c_int32), ("ldx", c_int32), ("ldw", c_int32), ("splits", c_int32)]
 
 
 class GemmNnArgs(C.Structure):

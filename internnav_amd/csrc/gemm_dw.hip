@@ -6,6 +6,9 @@
 // 64-row slabs of both operands in LDS TRANSPOSED (16-byte global loads along n / k, 2-byte LDS stores, 16-byte fragment reads along r), runs
 // MFMA 16x16x32 over them and adds the 64 x 64 tile into the fp32 gradient; workgroups of the first k tile also sum their DY slab columns (from the
 // UNROUNDED values) for the bias gradient. One launch, no scratch, deterministic (r ascending inside a tile, one workgroup per output element).
+// Long reductions over few tiles (the memory-encoder layers: 12 288 rows into a 384 x 384 gradient = 36 tiles of 192 slabs) are cut into `splits`
+// row ranges (grid.z): every range writes its fp32 tile (and bias sums) into the caller's partial buffer and a second launch adds the ranges in
+// ascending order into dW / db - two launches instead of five, 8x the workgroups, still one summation order.
 // Numerics: DY rounded to bf16 for the MFMAs (as the transposed copy was), fp32 accumulation over r in 32-wide steps.
 #include "common.h"
 #include "kernels.h"
@@ -74,15 +77,21 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(ina_gemm_dw_args p) {
 
     // slab c is multiplied out of LDS buffer c & 1 while slab c + 1 waits in registers (staged into the other buffer after the barrier that
     // retires its last readers) and slab c + 2 is in flight from memory: one barrier per slab, two slabs of latency cover
-    const int nslab = (p.rows + DW_R - 1) / DW_R;
-    load(0);
-    stage(0);
-    if (nslab > 1) load(DW_R);
+    const int total = (p.rows + DW_R - 1) / DW_R;
+    const int per = (total + (int)gridDim.z - 1) / (int)gridDim.z;       // slabs per row range (splits > 1: grid.z ranges, partial outputs)
+    const int s0 = blockIdx.z * per;
+    const int nslab = max(0, min(total - s0, per));
+    const int rbase = s0 * DW_R;
+    if (nslab > 0) {
+        load(rbase);
+        stage(0);
+    }
+    if (nslab > 1) load(rbase + DW_R);
     for (int c = 0; c < nslab; ++c) {
         __syncthreads();
         if (c + 1 < nslab) {
             stage((c + 1) & 1);
-            if (c + 2 < nslab) load((c + 2) * DW_R);
+            if (c + 2 < nslab) load(rbase + (c + 2) * DW_R);
         }
         const bf16* as = As[c & 1];
         const bf16* bsm = Bs[c & 1];
@@ -108,8 +117,12 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(ina_gemm_dw_args p) {
         for (int j = 0; j < 2; ++j) {
             const int k = k0 + wk + j * 16 + fg * 4;
             if (n < p.N && k < p.K) {                                     // (K multiple of 4: a run of 4 is inside or outside)
-                f32x4* o = reinterpret_cast<f32x4*>(p.dW + (size_t)n * p.ldw + k);
-                *o = *o + acc[i][j];
+                if (gridDim.z > 1) {
+                    *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.z * p.N + n) * p.K + k) = acc[i][j];
+                } else {
+                    f32x4* o = reinterpret_cast<f32x4*>(p.dW + (size_t)n * p.ldw + k);
+                    *o = *o + acc[i][j];
+                }
             }
         }
     }
@@ -123,8 +136,27 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(ina_gemm_dw_args p) {
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < 32; ++r) s += red[r * DW_T + tid];
-            p.db[n0 + tid] += s;
+            if (gridDim.z > 1) p.partial[(size_t)gridDim.z * p.N * p.K + (size_t)blockIdx.z * p.N + n0 + tid] = s;
+            else p.db[n0 + tid] += s;
         }
+    }
+}
+
+// dW[n, k] += sum_z partial[z][n][k] (z ascending), db[n] += sum_z partial_b[z][n]: 4 columns per thread
+__global__ __launch_bounds__(256) void gemm_dw_reduce_kernel(ina_gemm_dw_args p) {
+    const size_t quads = (size_t)p.N * (p.K / 4);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < quads) {
+        const int n = (int)(i / (p.K / 4)), k = (int)(i % (p.K / 4)) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splits; ++z) s += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)z * p.N + n) * p.K + k);
+        f32x4* o = reinterpret_cast<f32x4*>(p.dW + (size_t)n * p.ldw + k);
+        *o = *o + s;
+    } else if (p.db && i - quads < (size_t)p.N) {
+        const int n = (int)(i - quads);
+        float s = 0.f;
+        for (int z = 0; z < p.splits; ++z) s += p.partial[(size_t)p.splits * p.N * p.K + (size_t)z * p.N + n];
+        p.db[n] += s;
     }
 }
 
@@ -140,9 +172,19 @@ int ina_launch_gemm_dw(const ina_gemm_dw_args& p, hipStream_t stream) {
                 p.lddy, p.ldx, p.ldw);
     ina_prof_set_sub(43);
     InaProfScope prof(INA_PROF_GEMM, 2.0 * p.rows * p.N * p.K, (double)p.rows * (des * p.N + 2.0 * p.K) + 8.0 * p.N * p.K, stream);
-    const dim3 grid((p.N + DW_T - 1) / DW_T, (p.K + DW_T - 1) / DW_T);
-    if (p.dy_dt == INA_DT_F32) hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, stream, p);
+    const int splits = p.splits > 1 ? p.splits : 1;
+    INA_REQUIRE(splits <= 64 && (splits == 1 || (p.partial && ((uintptr_t)p.partial % 16) == 0 && p.partial_elems >= (int64_t)splits * p.N * (p.K + 1))),
+                "gemm_dw: %d row ranges need a 16-byte aligned partial buffer of splits * N * (K + 1) = %lld floats (got %lld)", splits,
+                (long long)splits * p.N * (p.K + 1), (long long)p.partial_elems);
+    const dim3 grid((p.N + DW_T - 1) / DW_T, (p.K + DW_T - 1) / DW_T, splits);
+    ina_gemm_dw_args q = p;
+    q.splits = splits;
+    if (p.dy_dt == INA_DT_F32) hipLaunchKernelGGL(gemm_dw_kernel<true>, grid, dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL(gemm_dw_kernel<false>, grid, dim3(256), 0, stream, q);
+    if (splits > 1) {
+        const size_t work = (size_t)p.N * (p.K / 4) + (p.db ? (size_t)p.N : 0);
+        hipLaunchKernelGGL(gemm_dw_reduce_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, q);
+    }
     INA_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -285,25 +285,34 @@ def sumsq_parts(flat: torch.Tensor, width: int = 1024) -> torch.Tensor:
     return colsum(v, v).view(-1)
 
 
-GEMM_DW_MAX_ROWS = 2048
+GEMM_DW_MAX_TILES_LONG = 144     # 64 x 64 tiles of the gradient up to which gemm_dw also takes reductions over more than 2048 rows
+GEMM_DW_SLABS_PER_RANGE = 24      # 64-row slabs a workgroup of gemm_dw walks before the rows are cut into ranges (grid.z) with a reduce launch behind
+
+
+def gemm_dw_splits(rows: int) -> int:
+    """row ranges of gemm_dw: 1 (one launch) up to 2048 rows, then ranges of ~1536 rows, at most 16"""
+    if rows <= 2048:
+        return 1
+    return min(16, (rows + 64 * GEMM_DW_SLABS_PER_RANGE - 1) // (64 * GEMM_DW_SLABS_PER_RANGE))
 
 
 def gemm_dw_ok(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor) -> bool:
-    """should gemm_dw take these operands (else: two transposes + ops.linear + colsum)? dy [rows, N] f32 | bf16, x [rows, K] bf16, gW f32 [N, K] view.
-    Up to GEMM_DW_MAX_ROWS rows: one workgroup per 64 x 64 tile walks all rows (18 vs 29 us at 768 rows, 6 vs 20 at 96); from ~3 000 rows on the tiled
-    GEMM over transposed copies is ahead (its K loop is pipelined deeper; 232 vs 170 us at 12 288 rows) - profiles/r06z_gemm_dw_vs_five_launches.txt."""
+    """can gemm_dw take these operands (else: two transposes + ops.linear + colsum)? dy [rows, N] f32 | bf16, x [rows, K] bf16, gW f32 [N, K] view.
+    (profiles/r06z_gemm_dw_vs_five_launches.txt: 18 vs 29 us at 768 rows, 6 vs 20 at 96; long reductions run as row ranges + a reduce launch)"""
     if dy.dim() != 2 or x.dim() != 2 or gW.dim() != 2 or x.dtype != torch.bfloat16 or gW.dtype != torch.float32 or dy.dtype not in _DT:
         return False
-    if dy.shape[0] > GEMM_DW_MAX_ROWS:
-        return False
     N, K = gW.shape
+    # the kernel is built for the latency-bound corner (few tiles, any number of rows; or few rows): a big gradient over many rows is throughput
+    # work, where the tiled GEMM over transposed copies is ahead (2304 x 768 over 12 288 rows: 250 vs 346 us; 384 x 384: 170 vs 60)
+    if dy.shape[0] > 2048 and ((N + 63) // 64) * ((K + 63) // 64) > GEMM_DW_MAX_TILES_LONG:
+        return False
     es = dy.element_size()
     return (dy.shape == (x.shape[0], N) and x.shape[1] == K and dy.stride(1) == 1 and x.stride(1) == 1 and gW.stride(1) == 1 and N % 8 == 0 and K % 8 == 0
             and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and gW.stride(0) % 4 == 0 and dy.data_ptr() % (8 * es) == 0 and x.data_ptr() % 16 == 0
             and gW.data_ptr() % 16 == 0)
 
 
-def gemm_dw(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional[torch.Tensor] = None):
+def gemm_dw(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional[torch.Tensor] = None, splits: Optional[int] = None):
     """gW[n, k] += sum_r dy[r, n] * x[r, k]; gb[n] += sum_r dy[r, n]: weight / bias gradient of nn.Linear in ONE launch from the tape's row-major
     tensors (csrc/gemm_dw.hip) - the tiled GEMM needed two transposed copies and the bias two column-sum launches."""
     assert gemm_dw_ok(dy, x, gW)
@@ -314,6 +323,10 @@ def gemm_dw(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor, gb: Optional[to
         a.db = gb.data_ptr()
     a.rows, a.N, a.K, a.dy_dt = dy.shape[0], gW.shape[0], gW.shape[1], _DT[dy.dtype]
     a.lddy, a.ldx, a.ldw = dy.stride(0), x.stride(0), gW.stride(0)
+    a.splits = gemm_dw_splits(a.rows) if splits is None else splits
+    if a.splits > 1:
+        part = torch.empty(a.splits * a.N * (a.K + 1), dtype=torch.float32, device=dy.device)
+        a.partial, a.partial_elems = part.data_ptr(), part.numel()
     _lib.check(_lib.lib().ina_gemm_dw(C.byref(a), _stream()), "gemm_dw")
 
 

@@ -389,10 +389,34 @@ def test_gemm_dw_weight_and_bias_gradient_in_one_launch(dev, rows, N, K, dy32):
     assert not T.gemm_dw_ok(dy[:, :N - 4], x, gW[:N - 4]) and not T.gemm_dw_ok(dy, x.float(), gW)
 
 
-def test_gemm_dw_is_not_offered_beyond_its_row_limit(dev):
+@pytest.mark.parametrize("rows,N,K,splits", [(12288, 384, 384, None), (2100, 128, 72, None), (3000, 72, 136, 5), (130, 64, 64, 4), (4096, 1536, 384, None)])
+def test_gemm_dw_row_ranges_and_ordered_reduce(dev, rows, N, K, splits):
+    """long reductions: the rows in `splits` ranges (grid.z), per-range tiles in the partial buffer, a second launch adding them in ascending order -
+    uneven ranges, an EMPTY last range (130 rows = 3 slabs in 4 ranges), the automatic range count; same bounds as the one-launch form, and the
+    result does not depend on how often it is run (no atomics)."""
     from internnav_amd import train_ops as T
 
-    x = torch.zeros(T.GEMM_DW_MAX_ROWS + 64, 64, device=dev, dtype=torch.bfloat16)
-    dy = torch.zeros(T.GEMM_DW_MAX_ROWS + 64, 128, device=dev)
-    gW = torch.zeros(128, 64, device=dev)
-    assert T.gemm_dw_ok(dy[: T.GEMM_DW_MAX_ROWS], x[: T.GEMM_DW_MAX_ROWS], gW) and not T.gemm_dw_ok(dy, x, gW)
+    g = torch.Generator(device="cpu").manual_seed(rows + N)
+    dy = torch.randn(rows, N, generator=g).to(dev)
+    x = torch.randn(rows, K, generator=g).to(dev).bfloat16()
+    gW0, gb0 = torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    if splits is None:
+        assert T.gemm_dw_splits(rows) > 1
+    outs = []
+    for _ in range(2):
+        gW, gb = gW0.clone(), gb0.clone()
+        T.gemm_dw(dy, x, gW, gb, splits=splits)
+        torch.cuda.synchronize()
+        outs.append((gW, gb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    gW, gb = outs[0]
+    ref_w = gW0.double() + dy.bfloat16().double().t() @ x.double()
+    ref_b = gb0.double() + dy.double().sum(0)
+    scale = (dy.bfloat16().double().abs().t() @ x.double().abs()).max().item()
+    assert (gW.double() - ref_w).abs().max().item() <= 2e-6 * scale + 1e-6
+    assert (gb.double() - ref_b).abs().max().item() <= 1e-5 * dy.double().abs().sum(0).max().item() + 1e-6
+    assert T.gemm_dw_splits(2048) == 1 and T.gemm_dw_splits(2049) == 2 and T.gemm_dw_splits(10 ** 6) == 16
+    # offered for long reductions only while the gradient has few tiles (the tiled GEMM keeps the throughput-bound shapes)
+    big = torch.zeros(4096, 2304, device=dev)
+    assert T.gemm_dw_ok(dy, x, gW0) and not T.gemm_dw_ok(big, torch.zeros(4096, 768, device=dev, dtype=torch.bfloat16), torch.zeros(2304, 768, device=dev))
+    assert T.gemm_dw_ok(big[:2048], torch.zeros(2048, 768, device=dev, dtype=torch.bfloat16), torch.zeros(2304, 768, device=dev))
