@@ -3,7 +3,7 @@
 // DY [rows, N] (f32 or bf16) and X [rows, K] (bf16) are what the backward tape holds; the reduction runs over their SLOW dimension, so the tiled NT
 // GEMM needed K-contiguous copies of both - two transpose launches, the GEMM, and two column-sum launches for the bias: five launches per trained
 // layer in a ~3 000-launch backward chain that is bound by launch latency, not by work (rows = 24 ... 768 in the SFT step). This kernel stages
-// 64-row slabs of both operands in LDS TRANSPOSED (16-byte global loads along n / k, 2-byte LDS stores, 16-byte fragment reads along r), runs
+// 32-row slabs of both operands in LDS TRANSPOSED (16-byte global loads along n / k, 2-byte LDS stores, 16-byte fragment reads along r), runs
 // MFMA 16x16x32 over them and adds the 64 x 64 tile into the fp32 gradient; workgroups of the first k tile also sum their DY slab columns (from the
 // UNROUNDED values) for the bias gradient. One launch, no scratch, deterministic (r ascending inside a tile, one workgroup per output element).
 // Long reductions over few tiles (the memory-encoder layers: 12 288 rows into a 384 x 384 gradient = 36 tiles of 192 slabs) are cut into `splits`
@@ -15,127 +15,160 @@
 
 namespace {
 
-constexpr int DW_T = 64, DW_R = 64, DW_PITCH = 72;   // tile edge, rows per slab, LDS row pitch in bf16 (144 B: 16-byte aligned fragment reads)
+constexpr int DW_T = 64, DW_R = 32, DW_PITCH = 36;   // tile edge, rows per slab, LDS row pitch in bf16 (72 B = 18 dwords: the eight 8-row groups of a
+                                                     // write instruction start 16 banks apart, 8-byte accesses are 2-way = the minimum for 128 dwords)
+constexpr int DW_WAVE_LDS = 2 * DW_T * DW_PITCH;     // bf16 elements of one wave's operand images (n-major and k-major)
 
+// The four waves of a workgroup work on the SAME 64 x 64 tile over DIFFERENT slabs (wave w: slabs w, w + 4, ...): no workgroup barrier in the
+// main loop, four slabs' loads in flight per CU - the launch is latency-bound (36-144 workgroups), so the waves' memory round trips have to overlap.
+// A lane loads FOUR CONSECUTIVE rows 4 (l / 8) + h x 8 columns of each operand per slab (two slabs ahead in registers), so the transposed LDS image is
+// written 8 bytes at a time ([column][4 rows]) instead of 2 - the 2-byte form (32 conflicted writes per operand) was what bound the first versions. The waves' tiles are added at the
+// end in a fixed order ((w0 + w2) + (w1 + w3)) through LDS.
 template <bool DY32>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(ina_gemm_dw_args p) {
-    __shared__ __attribute__((aligned(16))) bf16 As[2][DW_T * DW_PITCH];   // [buffer][n][r]
-    __shared__ __attribute__((aligned(16))) bf16 Bs[2][DW_T * DW_PITCH];   // [buffer][k][r]
+    __shared__ __attribute__((aligned(16))) bf16 lds[4 * DW_WAVE_LDS];                  // 36 KiB; reused as 32 KiB of fp32 for the final adds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16* As = lds + wave * DW_WAVE_LDS;                                                // [n][r]
+    bf16* Bs = As + DW_T * DW_PITCH;                                                    // [k][r]
     const int n0 = blockIdx.x * DW_T, k0 = blockIdx.y * DW_T;
-    const int lr = tid >> 3, c8 = (tid & 7) * 8;                         // this thread's rows lr, lr + 32 of a slab and its 8 columns
-    const bool n_ok = n0 + c8 < p.N, k_ok = k0 + c8 < p.K;              // (N, K multiples of 8: a run of 8 is inside or outside)
+    const int rq = lane >> 3, c8 = (lane & 7) * 8;
+    const bool n_ok = n0 + c8 < p.N, k_ok = k0 + c8 < p.K;                             // (N, K multiples of 8: a run of 8 is inside or outside)
     const bool bias = p.db != nullptr && blockIdx.y == 0;
-    const int wn = (wave >> 1) * 32, wk = (wave & 1) * 32;               // the wave's 32 x 32 corner of the tile
     const int fi = lane & 15, fg = lane >> 4;
 
-    f32x4 acc[2][2];                                                     // [n sub-tile][k sub-tile]: lane holds n = fi, k = 4 fg .. 4 fg + 3
+    f32x4 acc[4][4];                                                                    // [n sub-tile][k sub-tile]: lane holds n = fi, k = 4 fg .. 4 fg + 3
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    float a[2][8];
-    bf16x8 b[2];
-    auto load = [&](int r0) {
+    const int total = (p.rows + DW_R - 1) / DW_R;
+    const int per = (total + (int)gridDim.z - 1) / (int)gridDim.z;                      // slabs per row range (splits > 1: grid.z ranges, partial outputs)
+    const int s0 = blockIdx.z * per;
+    const int nslab = max(0, min(total - s0, per));                                     // slabs of this workgroup; wave w takes w, w + 4, ...
+
+    float a[2][4][8];
+    bf16x8 b[2][4];
+    auto load = [&](int set, int slab) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int r = r0 + lr + 32 * h;
-            const bool ok = r < p.rows;
+        for (int h = 0; h < 4; ++h) {
+            const int r = (s0 + slab) * DW_R + 4 * rq + h;
+            const bool ok = slab < nslab && r < p.rows;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[h][j] = 0.f;
-            b[h] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 8; ++j) a[set][h][j] = 0.f;
+            b[set][h] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (ok && n_ok) {
                 if constexpr (DY32) {
                     const float* q = reinterpret_cast<const float*>(p.DY) + (size_t)r * p.lddy + n0 + c8;
                     const f32x4 u = *reinterpret_cast<const f32x4*>(q), v = *reinterpret_cast<const f32x4*>(q + 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { a[h][j] = u[j]; a[h][4 + j] = v[j]; }
+                    for (int j = 0; j < 4; ++j) { a[set][h][j] = u[j]; a[set][h][4 + j] = v[j]; }
                 } else {
                     const bf16x8 u = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.DY) + (size_t)r * p.lddy + n0 + c8);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) a[h][j] = (float)u[j];
+                    for (int j = 0; j < 8; ++j) a[set][h][j] = (float)u[j];
                 }
             }
-            if (ok && k_ok) b[h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.X) + (size_t)r * p.ldx + k0 + c8);
+            if (ok && k_ok) b[set][h] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.X) + (size_t)r * p.ldx + k0 + c8);
         }
     };
-    auto stage = [&](int buf) {                                           // registers -> LDS, transposed; the bias sums take the unrounded values
+    auto step = [&](int set) {      // one slab: registers -> this wave's LDS images (transposed), 16 MFMAs; the bias sums take the unrounded values
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                As[buf][(c8 + j) * DW_PITCH + lr + 32 * h] = (bf16)a[h][j];
-                Bs[buf][(c8 + j) * DW_PITCH + lr + 32 * h] = b[h][j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const bf16x4 va = {(bf16)a[set][0][j], (bf16)a[set][1][j], (bf16)a[set][2][j], (bf16)a[set][3][j]};
+            const bf16x4 vb = {b[set][0][j], b[set][1][j], b[set][2][j], b[set][3][j]};
+            *reinterpret_cast<bf16x4*>(As + (c8 + j) * DW_PITCH + 4 * rq) = va;
+            *reinterpret_cast<bf16x4*>(Bs + (c8 + j) * DW_PITCH + 4 * rq) = vb;
+        }
         if (bias) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bs[j] += a[0][j] + a[1][j];
+            for (int j = 0; j < 8; ++j) bs[j] += (a[set][0][j] + a[set][1][j]) + (a[set][2][j] + a[set][3][j]);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              // the wave's own writes have landed (no other wave touches this image)
+        bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                                   // (8-byte halves: the 72-byte pitch is not 16-byte aligned)
+            const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(As + (i * 16 + fi) * DW_PITCH + fg * 8);
+            const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(As + (i * 16 + fi) * DW_PITCH + fg * 8 + 4);
+            const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(Bs + (i * 16 + fi) * DW_PITCH + fg * 8);
+            const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(Bs + (i * 16 + fi) * DW_PITCH + fg * 8 + 4);
+            fa[i] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            fb[i] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              // fragments are in registers before the image is overwritten
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
 
-    // slab c is multiplied out of LDS buffer c & 1 while slab c + 1 waits in registers (staged into the other buffer after the barrier that
-    // retires its last readers) and slab c + 2 is in flight from memory: one barrier per slab, two slabs of latency cover
-    const int total = (p.rows + DW_R - 1) / DW_R;
-    const int per = (total + (int)gridDim.z - 1) / (int)gridDim.z;       // slabs per row range (splits > 1: grid.z ranges, partial outputs)
-    const int s0 = blockIdx.z * per;
-    const int nslab = max(0, min(total - s0, per));
-    const int rbase = s0 * DW_R;
-    if (nslab > 0) {
-        load(rbase);
-        stage(0);
-    }
-    if (nslab > 1) load(rbase + DW_R);
-    for (int c = 0; c < nslab; ++c) {
-        __syncthreads();
-        if (c + 1 < nslab) {
-            stage((c + 1) & 1);
-            if (c + 2 < nslab) load(rbase + (c + 2) * DW_R);
-        }
-        const bf16* as = As[c & 1];
-        const bf16* bsm = Bs[c & 1];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(as + (wn + i * 16 + fi) * DW_PITCH + kk * 32 + fg * 8);
-                fb[i] = *reinterpret_cast<const bf16x8*>(bsm + (wk + i * 16 + fi) * DW_PITCH + kk * 32 + fg * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    // two register sets: slab t is multiplied while slabs t + 4 and t + 8 (this wave's next two) are in flight
+    load(0, wave);
+    load(1, wave + 4);
+    for (int t = wave; t < nslab; t += 8) {
+        step(0);
+        load(0, t + 8);
+        if (t + 4 < nslab) {
+            step(1);
+            load(1, t + 12);
         }
     }
-    // D[4 fg + t][fi] of mfma(first = X^T fragment, second = DY^T fragment): k = 4 fg + t, n = fi
+
+    // ---- add the four waves' tiles: w2, w3 -> LDS; w0 += w2, w1 += w3; w1 -> LDS; w0 += w1 (fixed order)
+    __syncthreads();                                                                    // every wave is done with its operand images
+    float* red = reinterpret_cast<float*>(lds);                                         // [2][16 sub-tiles][64 lanes][4] f32 = 32 KiB
+    if (wave >= 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int n = n0 + wn + i * 16 + fi;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + wk + j * 16 + fg * 4;
-            if (n < p.N && k < p.K) {                                     // (K multiple of 4: a run of 4 is inside or outside)
-                if (gridDim.z > 1) {
-                    *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.z * p.N + n) * p.K + k) = acc[i][j];
-                } else {
-                    f32x4* o = reinterpret_cast<f32x4*>(p.dW + (size_t)n * p.ldw + k);
-                    *o = *o + acc[i][j];
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(red + (((wave - 2) * 16 + i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(red + ((wave * 16 + i * 4 + j) * 64 + lane) * 4);
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(red + ((i * 4 + j) * 64 + lane) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // D[4 fg + t][fi] of mfma(first = X^T fragment, second = DY^T fragment): k = 4 fg + t, n = fi
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + i * 16 + fi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j * 16 + fg * 4;
+                const f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(red + ((i * 4 + j) * 64 + lane) * 4);
+                if (n < p.N && k < p.K) {                                               // (K multiple of 4: a run of 4 is inside or outside)
+                    if (gridDim.z > 1) {
+                        *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.z * p.N + n) * p.K + k) = v;
+                    } else {
+                        f32x4* o = reinterpret_cast<f32x4*>(p.dW + (size_t)n * p.ldw + k);
+                        *o = *o + v;
+                    }
                 }
             }
         }
     }
     if (bias) {
-        __syncthreads();                                                  // every wave is done with the operand buffers: As becomes the reduction scratch
-        float* red = reinterpret_cast<float*>(&As[0][0]);                 // [32 row slots][64 n] f32 = 8 KB of the 18 KB
+        __syncthreads();                                                                // wave 0 has read the tile scratch
+        float* rb = reinterpret_cast<float*>(lds);                                      // [4 waves x 8 row lanes][64 n]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) red[lr * DW_T + c8 + j] = bs[j];
+        for (int j = 0; j < 8; ++j) rb[(wave * 8 + rq) * DW_T + c8 + j] = bs[j];
         __syncthreads();
         if (tid < DW_T && n0 + tid < p.N) {
             float s = 0.f;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) s += red[r * DW_T + tid];
+            for (int r = 0; r < 32; ++r) s += rb[r * DW_T + tid];
             if (gridDim.z > 1) p.partial[(size_t)gridDim.z * p.N * p.K + (size_t)blockIdx.z * p.N + n0 + tid] = s;
             else p.db[n0 + tid] += s;
         }

@@ -285,7 +285,7 @@ def sumsq_parts(flat: torch.Tensor, width: int = 1024) -> torch.Tensor:
     return colsum(v, v).view(-1)
 
 
-GEMM_DW_MAX_TILES_LONG = 144     # 64 x 64 tiles of the gradient up to which gemm_dw also takes reductions over more than 2048 rows
+GEMM_DW_MAX_TILES_LONG = 512     # 64 x 64 tiles of the gradient up to which gemm_dw also takes reductions over more than 2048 rows (2304 x 768 = 432)
 GEMM_DW_SLABS_PER_RANGE = 24      # 64-row slabs a workgroup of gemm_dw walks before the rows are cut into ranges (grid.z) with a reduce launch behind
 
 
@@ -298,12 +298,13 @@ def gemm_dw_splits(rows: int) -> int:
 
 def gemm_dw_ok(dy: torch.Tensor, x: torch.Tensor, gW: torch.Tensor) -> bool:
     """can gemm_dw take these operands (else: two transposes + ops.linear + colsum)? dy [rows, N] f32 | bf16, x [rows, K] bf16, gW f32 [N, K] view.
-    (profiles/r06z_gemm_dw_vs_five_launches.txt: 18 vs 29 us at 768 rows, 6 vs 20 at 96; long reductions run as row ranges + a reduce launch)"""
+    (profiles/r06z_gemm_dw_vs_five_launches.txt: 14 vs 29 us at 768 rows, 8 vs 20 at 96, 35 vs 170 at 12 288; long reductions run as row ranges +
+    a reduce launch)"""
     if dy.dim() != 2 or x.dim() != 2 or gW.dim() != 2 or x.dtype != torch.bfloat16 or gW.dtype != torch.float32 or dy.dtype not in _DT:
         return False
     N, K = gW.shape
-    # the kernel is built for the latency-bound corner (few tiles, any number of rows; or few rows): a big gradient over many rows is throughput
-    # work, where the tiled GEMM over transposed copies is ahead (2304 x 768 over 12 288 rows: 250 vs 346 us; 384 x 384: 170 vs 60)
+    # measured ahead of the five launches on every System-1 layer shape (24 ... 12 288 rows, 384 x 384 ... 2304 x 768); bigger gradients over long
+    # reductions are not its case (and would want splits x N x K floats of scratch): they keep the tiled GEMM
     if dy.shape[0] > 2048 and ((N + 63) // 64) * ((K + 63) // 64) > GEMM_DW_MAX_TILES_LONG:
         return False
     es = dy.element_size()

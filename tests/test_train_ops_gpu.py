@@ -389,7 +389,7 @@ def test_gemm_dw_weight_and_bias_gradient_in_one_launch(dev, rows, N, K, dy32):
     assert not T.gemm_dw_ok(dy[:, :N - 4], x, gW[:N - 4]) and not T.gemm_dw_ok(dy, x.float(), gW)
 
 
-@pytest.mark.parametrize("rows,N,K,splits", [(12288, 384, 384, None), (2100, 128, 72, None), (3000, 72, 136, 5), (130, 64, 64, 4), (4096, 1536, 384, None)])
+@pytest.mark.parametrize("rows,N,K,splits", [(12288, 384, 384, None), (2100, 128, 72, None), (3000, 72, 136, 5), (130, 64, 64, 4), (4096, 1536, 384, None), (12288, 2304, 768, None)])
 def test_gemm_dw_row_ranges_and_ordered_reduce(dev, rows, N, K, splits):
     """long reductions: the rows in `splits` ranges (grid.z), per-range tiles in the partial buffer, a second launch adding them in ascending order -
     uneven ranges, an EMPTY last range (130 rows = 3 slabs in 4 ranges), the automatic range count; same bounds as the one-launch form, and the
@@ -417,6 +417,6 @@ def test_gemm_dw_row_ranges_and_ordered_reduce(dev, rows, N, K, splits):
     assert (gb.double() - ref_b).abs().max().item() <= 1e-5 * dy.double().abs().sum(0).max().item() + 1e-6
     assert T.gemm_dw_splits(2048) == 1 and T.gemm_dw_splits(2049) == 2 and T.gemm_dw_splits(10 ** 6) == 16
     # offered for long reductions only while the gradient has few tiles (the tiled GEMM keeps the throughput-bound shapes)
-    big = torch.zeros(4096, 2304, device=dev)
-    assert T.gemm_dw_ok(dy, x, gW0) and not T.gemm_dw_ok(big, torch.zeros(4096, 768, device=dev, dtype=torch.bfloat16), torch.zeros(2304, 768, device=dev))
-    assert T.gemm_dw_ok(big[:2048], torch.zeros(2048, 768, device=dev, dtype=torch.bfloat16), torch.zeros(2304, 768, device=dev))
+    big = torch.zeros(4096, 4096, device=dev)
+    assert T.gemm_dw_ok(dy, x, gW0) and not T.gemm_dw_ok(big, torch.zeros(4096, 1024, device=dev, dtype=torch.bfloat16), torch.zeros(4096, 1024, device=dev))
+    assert T.gemm_dw_ok(big[:2048], torch.zeros(2048, 1024, device=dev, dtype=torch.bfloat16), torch.zeros(4096, 1024, device=dev))
